@@ -1,0 +1,139 @@
+"""CPU: the oracle (oracle/scflow_oracle.py) against golden vectors produced by
+the reference's own source files (tests/golden/make_golden.py).  Tolerances
+are fp32 round-off (different op grouping only)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from scflow_amd.synthetic import make_inputs
+from scflow_amd.weights import fill_state_dict
+
+
+def _load(golden_dir, name):
+    d = np.load(os.path.join(golden_dir, name))
+    return {k: (torch.from_numpy(d[k]) if d[k].dtype.kind in 'fi' and d[k].shape != () else d[k])
+            for k in d.files}
+
+
+def _close(a, b, atol, rtol=1e-5):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs()
+    lim = atol + rtol * b.abs()
+    assert bool((err <= lim).all()), f'max err {float(err.max()):.3e} (atol {atol})'
+
+
+@pytest.mark.parametrize('name', ['corr_pyramid.npz', 'corr_pyramid_12x20.npz'])
+def test_corr_pyramid(golden_dir, name):
+    g = _load(golden_dir, name)
+    pyr = oracle.correlation_pyramid(g['feat1'], g['feat2'], 4)
+    for i, p in enumerate(pyr):
+        _close(p, g[f'level{i}'], atol=2e-5)
+
+
+@pytest.mark.parametrize('name', ['corr_lookup.npz', 'corr_lookup_12x20.npz'])
+def test_corr_lookup(golden_dir, name):
+    g = _load(golden_dir, name)
+    pyr = oracle.correlation_pyramid(g['feat1'], g['feat2'], 4)
+    out = oracle.corr_lookup(pyr, g['flow'].clone(), 4)
+    assert out.shape[1] == 4 * 81
+    _close(out, g['out'], atol=2e-5)
+
+
+def test_corr_lookup_channel_order(golden_dir):
+    """channel k = 81*l + 9*a + b samples x_off = a-4, y_off = b-4."""
+    g = _load(golden_dir, 'corr_lookup_onehot.npz')
+    pyr = oracle.correlation_pyramid(g['feat1'], g['feat2'], 4)
+    out = oracle.corr_lookup(pyr, torch.zeros((1, 2, 16, 16)), 4)
+    _close(out, g['out'], atol=1e-6)
+    # query (x=8,y=8), target (x=5,y=10): x_off=-3 -> a=1, y_off=+2 -> b=6 -> k=15
+    assert int(out[0, :81, 8, 8].argmax()) == 9 * 1 + 6
+    assert abs(float(out[0, 15, 8, 8]) - 16.0 / 2.0) < 1e-4   # 4*4/sqrt(4)
+
+
+def test_pose_math(golden_dir):
+    g = _load(golden_dir, 'pose_math.npz')
+    r, t = oracle.pose_from_delta_pose(g['d_rot'], g['d_trans'], g['rot'], g['trans'])
+    _close(r, g['rot_new'], atol=1e-6)
+    _close(t, g['trans_new'], atol=1e-4)
+    pts = [oracle.unproject_depth(g['depth'][i], g['k'][i], g['rot'][i], g['trans'][i])
+           for i in range(3)]
+    assert [len(a) for a, _ in pts] == list(g['npts'])
+    _close(pts[0][0], g['pts2d_0'], atol=0)
+    _close(pts[0][1], g['pts3d_0'], atol=1e-3)
+    for inv, key in ((0., 'flow_inv0'), (400., 'flow_inv400')):
+        f = oracle.flow_from_pose_and_points(r, t, g['k'], [a for a, _ in pts],
+                                             [b for _, b in pts], 32, 32, invalid_num=inv)
+        _close(f, g[key], atol=1e-4)
+
+
+@pytest.mark.parametrize('kind', ['IN', 'BN'])
+def test_encoder(golden_dir, kind):
+    g = _load(golden_dir, f'encoder_{kind}.npz')
+    keys = json.load(open(os.path.join(golden_dir, 'state_dict_keys.json')))['shapes']
+    pre = 'render_encoder.' if kind == 'IN' else 'context.'
+    sd = fill_state_dict({k[len(pre):]: v for k, v in keys.items() if k.startswith(pre)}, seed=3)
+    out = oracle.raft_encoder(g['x'], sd, '', kind)
+    _close(out, g['out'], atol=5e-5)
+
+
+def test_update_block(golden_dir):
+    g = _load(golden_dir, 'update_block.npz')
+    keys = json.load(open(os.path.join(golden_dir, 'state_dict_keys.json')))['shapes']
+    shapes = {k[len('decoder.'):]: v for k, v in keys.items()
+              if k.startswith(('decoder.encoder.', 'decoder.gru.', 'decoder.flow_pred.',
+                               'decoder.mask_pred.'))}
+    sd = fill_state_dict(shapes, seed=4)
+    motion = oracle.motion_encoder(g['corr'], g['flow'], sd, 'encoder.')
+    _close(motion, g['motion'], atol=2e-5)
+    h_new = oracle.sepconv_gru(g['h'], torch.cat([g['cxt'], motion], 1), sd, 'gru.')
+    _close(h_new, g['h_new'], atol=2e-5)
+    _close(oracle.xhead(h_new, sd, 'flow_pred.', 'flow'), g['d_flow'], atol=2e-5)
+    _close(oracle.xhead(h_new, sd, 'mask_pred.', 'mask'), g['mask_logit'], atol=2e-5)
+
+
+def test_pose_head_label_quirk(golden_dir):
+    """mixed labels: every sample is decoded with class label[0]."""
+    g = _load(golden_dir, 'pose_head.npz')
+    keys = json.load(open(os.path.join(golden_dir, 'state_dict_keys.json')))['shapes']
+    sd = fill_state_dict({k: v for k, v in keys.items() if k.startswith('decoder.pose_pred.')},
+                         seed=4)
+    x = torch.randn((3, 224, 32, 32), generator=torch.Generator().manual_seed(int(g['x_seed'])))
+    r, t = oracle.multiclass_pose_head(x, g['label'], sd, 'decoder.pose_pred.')
+    _close(r, g['rot'], atol=1e-5)
+    _close(t, g['trans'], atol=1e-5)
+    r2, t2 = oracle.multiclass_pose_head(x, torch.tensor([2, 2, 2]), sd, 'decoder.pose_pred.')
+    _close(r2, g['rot'], atol=1e-5)       # == "all label[0]"
+    r5, _ = oracle.multiclass_pose_head(x, torch.tensor([5, 5, 5]), sd, 'decoder.pose_pred.')
+    _close(r5, g['rot_label5'], atol=1e-5)
+    assert float((r5 - r).abs().max()) > 1e-4
+
+
+def test_full_refiner(golden_dir):
+    g = _load(golden_dir, 'refiner_full.npz')
+    keys = json.load(open(os.path.join(golden_dir, 'state_dict_keys.json')))['shapes']
+    sd = fill_state_dict(keys, seed=int(g['weight_seed']))
+    inp = make_inputs(int(g['n']), 256, 256, seed=int(g['input_seed']))
+    assert torch.equal(inp['label'], g['label'])
+    with torch.no_grad():
+        fr, fl, hf, cf = oracle.extract_feat(inp['render_images'], inp['real_images'], sd)
+        _close(fr[:, ::8], g['feat_render'], atol=1e-4)
+        _close(fl[:, ::8], g['feat_real'], atol=1e-4)
+        _close(hf[:, ::8], g['h_feat'], atol=1e-4)
+        _close(cf[:, ::8], g['cxt_feat'], atol=1e-4)
+        outs = oracle.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'],
+                               inp['ref_translation'], inp['depth'], inp['internel_k'],
+                               inp['label'], sd, iters=int(g['iters']))
+    names = ['flow_from_pose', 'flow_from_pred', 'rotation', 'translation', 'mask',
+             'delta_rotation', 'delta_translation']
+    tol = dict(flow_from_pose=1e-3, flow_from_pred=1e-3, rotation=1e-5, translation=2e-3,
+               mask=1e-4, delta_rotation=1e-5, delta_translation=1e-5)
+    for nm, seq in zip(names, outs):
+        st = torch.stack(list(seq))
+        if st.dim() == 5:
+            st = st[..., ::4, ::4]
+        _close(st, g[nm], atol=tol[nm])
