@@ -1,0 +1,175 @@
+/*
+ * scflow_hip.h -- C ABI of libscflow_hip.so: hand-written gfx950 (MI355X) kernels for
+ * the SCFlow recurrent flow/pose refinement hot path.
+ *
+ * Conventions (all entry points)
+ *   - plain C, no C++/torch types; every pointer is a DEVICE pointer to fp32 data laid
+ *     out exactly as the reference's contiguous NCHW torch tensors unless stated;
+ *   - pointers are borrowed: nothing is allocated, freed or retained;
+ *   - work is enqueued asynchronously on `stream` (a hipStream_t; NULL = default
+ *     stream); the call returns after launch, it never synchronises;
+ *   - return value: SCF_OK (0) or a negative SCF_E* code; scf_error_string() decodes;
+ *   - thread-safety: calls are independent; concurrent calls on different streams OK.
+ *
+ * The reference is pure Python on torch (no FFI of its own).  Each entry point names the
+ * reference operator (file:line under the reference checkout) whose arithmetic it
+ * replaces; INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ */
+#ifndef SCFLOW_HIP_H
+#define SCFLOW_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* scf_stream_t; /* bit-compatible with hipStream_t */
+
+enum {
+  SCF_OK = 0,
+  SCF_EINVAL = -1,      /* bad argument (null pointer, non-positive size, ...) */
+  SCF_EUNSUPPORTED = -2,/* shape/config outside what the kernels implement */
+  SCF_ELAUNCH = -3,     /* HIP reported a launch error */
+  SCF_ENODEVICE = -4    /* no gfx950 device visible */
+};
+
+#define SCF_MAX_LEVELS 8
+
+/* activation codes used by scf_conv2d / scf_linear */
+enum { SCF_ACT_NONE = 0, SCF_ACT_RELU = 1, SCF_ACT_SIGMOID = 2, SCF_ACT_TANH = 3 };
+
+/* fused epilogues of scf_conv2d */
+enum {
+  SCF_CONV_PLAIN = 0,
+  SCF_CONV_GRU_ZR = 1, /* rows [0,Cout/2): z=sigmoid -> out; rows [Cout/2,Cout): r=sigmoid, aux = r*h */
+  SCF_CONV_GRU_Q = 2   /* q=tanh; out = (1-z)*h + z*q                                   */
+};
+
+int scf_version(void);
+const char* scf_error_string(int code);
+/* number of HIP devices visible (>=0) or SCF_ENODEVICE */
+int scf_device_count(void);
+
+/* ---------------------------------------------------------------------------------
+ * Correlation volume + pyramid.            replaces CorrelationPyramid.forward
+ *                                          models/decoder/raft_decoder.py:35-58
+ * level0[n, i, j] = sum_c feat1[n,c,i] * feat2[n,c,j] / sqrt(C)   (i, j in [0, h*w))
+ * level(l+1) = 2x2/stride-2 average pool of level l over the target (j) dims.
+ * levels[l] : (N*h*w, 1, h>>l, w>>l) contiguous, l < L (host array of device ptrs).
+ * MFMA (v_mfma_f32_32x32x2_f32) contraction; exact fp32 fma chain over c.
+ * --------------------------------------------------------------------------------- */
+int scf_corr_build(const float* feat1, const float* feat2, float* const* levels,
+                   int N, int C, int h, int w, int L, scf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Multi-scale correlation lookup.          replaces CorrLookup.forward
+ *                                          models/utils/corr_lookup.py:102-136
+ * out[n, 81*l + 9*a + b, y, x] = bilinear(level l of query (n,y,x)) sampled at
+ *   ((x + flow[n,0,y,x]) / 2^l + a - r, (y + flow[n,1,y,x]) / 2^l + b - r),
+ * zero padding, align_corners=True semantics; out is (N, L*(2r+1)^2, h, w).
+ * HBM-bound gather: 2904 B/query algorithmic traffic at r=4, L=4.
+ * --------------------------------------------------------------------------------- */
+int scf_corr_lookup(const float* const* levels, const float* flow, float* out,
+                    int N, int h, int w, int r, int L, scf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Direct convolution as implicit GEMM on MFMA with fused epilogue.
+ * replaces every torch conv2d (+bias +BN(eval) +residual +activation +GRU gating) on
+ * the path: raft_encoder.py:286-314, resnet.py:67-94, raft_decoder.py:152-166,
+ * :235-253, :292-294, scflow_decoder.py:216-217, pose_head.py:148-160.
+ *
+ * Input = channel-concatenation of up to two NCHW segments (avoids torch.cat).
+ * Weights are pre-packed by scf_pack_conv_weight_size/scf_pack layout rules:
+ *   wp[((chunk*T + t)*KC + cl) * Mld + co],  chunk = ci / KC, cl = ci % KC, t = ky*KW+kx,
+ *   rows for ci >= Cin are zero, Mld = row stride (>= Cout, multiple of 4).
+ * Epilogue order: v = acc / out_div (+bias) -> v*scale+shift -> +res -> act -> mode.
+ * --------------------------------------------------------------------------------- */
+typedef struct scf_conv_desc {
+  const float* in0; const float* in1;   /* input segments (in1 may be NULL)            */
+  int32_t C0, C1;                       /* channels of each segment                    */
+  int64_t in0_nstride, in1_nstride;     /* floats between consecutive samples          */
+  int32_t N, H, W;                      /* batch, input height/width                   */
+  const float* wp;                      /* packed weights                              */
+  int64_t w_nstride;                    /* 0 = shared weights; else per-sample stride  */
+  int32_t Mld;                          /* packed row stride                           */
+  int32_t Cout;
+  int32_t KH, KW, stride, pad_h, pad_w;
+  int32_t KC;                           /* channel chunk used at packing time (2 or 8)  */
+  float* out; int64_t out_nstride;
+  const float* bias;                    /* [Cout] or NULL                              */
+  const float* scale; const float* shift; /* [Cout] each or both NULL (BN eval)        */
+  const float* res; int64_t res_nstride;  /* residual added before act, or NULL        */
+  float out_div;                        /* accumulator divided by this (1 = off)       */
+  int32_t act, act2, act_split;         /* act for co < act_split, act2 otherwise;
+                                           act_split <= 0 -> act everywhere            */
+  int32_t mode;                         /* SCF_CONV_*                                  */
+  const float* gru_h; int64_t gru_h_nstride; /* hidden state (ZR, Q)                   */
+  float* gru_aux; int64_t gru_aux_nstride;   /* ZR: r*h destination                    */
+  const float* gru_z; int64_t gru_z_nstride; /* Q: z                                   */
+} scf_conv_desc;
+
+int scf_conv2d(const scf_conv_desc* desc, scf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * InstanceNorm2d(eps, affine=False) [+ residual] [+ ReLU] over N*C planes of HW floats.
+ * replaces F.instance_norm at resnet.py:75-86 / raft_encoder.py:300-302 (norm_cfg IN).
+ * out = relu?( (x - mean) * rsqrt(var_biased + eps) + res? ).  In-place allowed.
+ * --------------------------------------------------------------------------------- */
+int scf_instance_norm(const float* x, const float* res, float* out, int64_t planes,
+                      int HW, float eps, int relu, scf_stream_t stream);
+
+/* GroupNorm(G, eps, affine) + ReLU on (N, C, HW).     replaces pose_head.py:151-159 */
+int scf_group_norm_relu(const float* x, const float* gamma, const float* beta, float* out,
+                        int N, int C, int HW, int G, float eps, scf_stream_t stream);
+
+/* y[n, o] = act(sum_k W[o,k] x[n,k] + b[o]);  W row-major (O, K). replaces nn.Linear
+ * at pose_head.py:166-172, 203-206.                                                 */
+int scf_linear(const float* x, const float* W, const float* b, float* y, int N, int K,
+               int O, int act, scf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Pose head tail + pose update.  replaces pose_head.py:207-210 (class select) and
+ * get_pose_from_delta_pose, models/utils/pose.py:124-149 (+ :153-169 ortho6d).
+ * rot_all (N, num_class*6), trans_all (N, num_class*3) are the two linear heads' outputs.
+ * label_mode 0 reproduces the reference (every sample uses class label[0]);
+ * label_mode 1 uses label[n].   Outputs: d_rot (N,6), d_trans (N,3), R_out (N,3,3),
+ * t_out (N,3).  R_out/t_out may alias R_in/t_in.
+ * --------------------------------------------------------------------------------- */
+int scf_pose_update(const float* rot_all, const float* trans_all, const int64_t* label,
+                    int num_class, int label_mode, const float* R_in, const float* t_in,
+                    float* d_rot, float* d_trans, float* R_out, float* t_out, int N,
+                    scf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Pose-induced flow (dense form of cal_3d_2d_corr + get_flow_from_delta_pose_and_points,
+ * models/utils/pose.py:44-64, 66-88).  For every pixel with depth > 0:
+ *   P = R0^-1 (K^-1 [x y 1]^T d - t0);  p = K (R P + t);  flow = (p_x/p_z - x, p_y/p_z - y)
+ * else flow = invalid_num.  depth (N,H,W); K,R0,R (N,3,3); t0,t (N,3); flow (N,2,H,W).
+ * --------------------------------------------------------------------------------- */
+int scf_reproject_flow(const float* depth, const float* K, const float* R0, const float* t0,
+                       const float* R, const float* t, float* flow, int N, int H, int W,
+                       float invalid_num, scf_stream_t stream);
+
+/* object-frame points of every pixel (dense cal_3d_2d_corr): pts (N,3,H,W), 0 where
+ * depth <= 0.  Test/diagnostic entry; scf_reproject_flow recomputes them on the fly. */
+int scf_unproject_depth(const float* depth, const float* K, const float* R0, const float* t0,
+                        float* pts, int N, int H, int W, scf_stream_t stream);
+
+/* out = mul * bilinear_resize(a + b?) with align_corners=True (F.interpolate semantics,
+ * scflow_decoder.py:188-197, 222-227).  a, b: (planes, Hin, Win); out (planes, Hout, Wout) */
+int scf_resize_bilinear(const float* a, const float* b, float* out, int64_t planes, int Hin,
+                        int Win, int Hout, int Wout, float mul, scf_stream_t stream);
+
+/* 2x2 stride-2 average pool over (planes, Hin, Win) -> (planes, Hin/2, Win/2)          */
+int scf_avgpool2x2(const float* x, float* out, int64_t planes, int Hin, int Win,
+                   scf_stream_t stream);
+
+/* elementwise helpers used for glue (split tanh/relu of the context features etc.)   */
+int scf_copy_strided(const float* src, int64_t src_nstride, float* dst, int64_t dst_nstride,
+                     int N, int64_t count, scf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCFLOW_HIP_H */

@@ -1,3 +1,19 @@
-"""scflow_amd -- MI355X-native implementation of SCFlow's recurrent
-flow/pose refinement hot path."""
+"""scflow_amd -- MI355X-native implementation of SCFlow's recurrent flow/pose
+refinement hot path.
+
+Public surface = the reference's registry API for this path:
+``build_refiner(cfg)`` / ``REFINERS`` / ``ENCODERS`` / ``DECODERS`` / ``HEAD`` and
+the registered classes (``SCFlowRefiner``, ``RAFTEncoder``, ``SCFlowDecoder``,
+``MultiClassPoseHead``) plus the operator-level seam (``CorrelationPyramid``,
+``CorrLookup``).  All arithmetic runs in libscflow_hip.so (include/scflow_hip.h).
+"""
 __version__ = '0.1.0'
+
+from .registry import (DECODERS, ENCODERS, HEAD, REFINERS, Registry, build_decoder,  # noqa: F401
+                       build_encoder, build_from_cfg, build_head, build_refiner)
+from .modules import (ConvGRU, CorrelationPyramid, CorrLookup, MotionEncoder,  # noqa: F401
+                      MultiClassPoseHead, RAFTEncoder, SCFlowDecoder, XHead)
+from .refiner import SCFlowRefiner  # noqa: F401
+from .config import scflow_model_cfg  # noqa: F401
+from .weights import fill_state_dict  # noqa: F401
+from .synthetic import make_inputs  # noqa: F401

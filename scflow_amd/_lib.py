@@ -1,0 +1,98 @@
+"""ctypes binding of libscflow_hip.so (C ABI declared in include/scflow_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  If the shared
+object has not been built, ``load()`` raises with the build command.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libscflow_hip.so')
+
+SCF_OK = 0
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+CONV_PLAIN, CONV_GRU_ZR, CONV_GRU_Q = 0, 1, 2
+MAX_LEVELS = 8
+
+_fp = C.c_void_p  # device pointers travel as integers
+
+
+class ConvDesc(C.Structure):
+    """mirror of ``scf_conv_desc`` (include/scflow_hip.h)."""
+    _fields_ = [
+        ('in0', _fp), ('in1', _fp),
+        ('C0', C.c_int32), ('C1', C.c_int32),
+        ('in0_nstride', C.c_int64), ('in1_nstride', C.c_int64),
+        ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+        ('wp', _fp), ('w_nstride', C.c_int64),
+        ('Mld', C.c_int32), ('Cout', C.c_int32),
+        ('KH', C.c_int32), ('KW', C.c_int32), ('stride', C.c_int32),
+        ('pad_h', C.c_int32), ('pad_w', C.c_int32), ('KC', C.c_int32),
+        ('out', _fp), ('out_nstride', C.c_int64),
+        ('bias', _fp), ('scale', _fp), ('shift', _fp),
+        ('res', _fp), ('res_nstride', C.c_int64),
+        ('out_div', C.c_float),
+        ('act', C.c_int32), ('act2', C.c_int32), ('act_split', C.c_int32),
+        ('mode', C.c_int32),
+        ('gru_h', _fp), ('gru_h_nstride', C.c_int64),
+        ('gru_aux', _fp), ('gru_aux_nstride', C.c_int64),
+        ('gru_z', _fp), ('gru_z_nstride', C.c_int64),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/scflow_hip.h declares
+SIGNATURES = {
+    'scf_version': (C.c_int, []),
+    'scf_error_string': (C.c_char_p, [C.c_int]),
+    'scf_device_count': (C.c_int, []),
+    'scf_corr_build': (C.c_int, [_fp, _fp, C.POINTER(_fp), C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, _fp]),
+    'scf_corr_lookup': (C.c_int, [C.POINTER(_fp), _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, _fp]),
+    'scf_conv2d': (C.c_int, [C.POINTER(ConvDesc), _fp]),
+    'scf_instance_norm': (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int, C.c_float, C.c_int, _fp]),
+    'scf_group_norm_relu': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_float, _fp]),
+    'scf_linear': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'scf_pose_update': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp,
+                                  C.c_int, _fp]),
+    'scf_reproject_flow': (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int,
+                                     C.c_int, C.c_float, _fp]),
+    'scf_unproject_depth': (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    'scf_resize_bilinear': (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_float, _fp]),
+    'scf_avgpool2x2': (C.c_int, [_fp, _fp, C.c_int64, C.c_int, C.c_int, _fp]),
+    'scf_copy_strided': (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int, C.c_int64, _fp]),
+}
+
+_lib = None
+
+
+class ScflowHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen the HIP library (once) and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ScflowHipError(
+            f'{LIB_PATH} is missing: the HIP kernels are the product and there is no fallback. '
+            'Build it with `python scflow_amd/csrc/build.py` (hipcc --offload-arch=gfx950).')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != SCF_OK:
+        msg = load().scf_error_string(code).decode()
+        raise ScflowHipError(f'{what} failed: {msg} ({code})')

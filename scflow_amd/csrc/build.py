@@ -1,0 +1,36 @@
+"""Build libscflow_hip.so (gfx950) in-tree with hipcc.  No torch involved: the library is a
+plain C-ABI shared object (include/scflow_hip.h)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ['capi.hip', 'corr_lookup.hip', 'conv_mfma.hip', 'resample.hip', 'pose.hip', 'norm.hip']
+OUT = os.path.join(HERE, 'libscflow_hip.so')
+
+
+def needs_build() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(HERE, s) for s in SOURCES] + [
+        os.path.join(HERE, 'scf_common.h'),
+        os.path.join(HERE, '..', '..', 'include', 'scflow_hip.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+           '-Wall', '-Wno-unused-function']
+    if verbose:
+        cmd.append('-Rpass-analysis=kernel-resource-usage')
+    cmd += [os.path.join(HERE, s) for s in SOURCES] + ['-o', OUT]
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose='-v' in sys.argv))

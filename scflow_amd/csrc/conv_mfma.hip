@@ -1,0 +1,334 @@
+// Direct 2-D convolution as an implicit GEMM on the fp32 matrix cores of gfx950
+// (v_mfma_f32_32x32x2_f32: exact fp32 fma chain, 157 TFLOP/s chip peak), NCHW in / NCHW
+// out, with the whole post-conv epilogue of the SCFlow hot path fused in.  The same kernel
+// builds the 4-D correlation volume (per-sample "weights" = feat1, 1x1, out_div = sqrt(C)).
+//
+// GEMM view (D = A * B, "weights-stationary transposed" so that NCHW is the natural layout
+// of every operand -- no im2col, no layout conversion anywhere on the path):
+//     D[co, pix] = sum_k  A[co, k] * B[k, pix]
+//     A[co, k]   = packed weight wp[k][co]          (lane <-> co, contiguous in memory)
+//     B[k, pix]  = input[ci][oy*s+ky-p][ox*s+kx-p]  (lane <-> pixel, contiguous along x)
+//     k          = (channel chunk, tap, channel in chunk)
+// For the 32x32x2 MFMA a lane holds ONE A and ONE B scalar per instruction (A[l&31][l>>5],
+// B[l>>5][l&31]), so both operands are read from LDS with conflict-free ds_read_b32 and the
+// 32x32 result tile (col = lane&31 = pixel) stores as 128-B rows straight into NCHW.
+//
+// Block = 256 threads = 4 waves.  Block tile = (WM*32 output channels) x (WN*128 pixels);
+// every wave owns WN pixel fragments of 32 pixels (FR rows x FC cols, FC = min(32, pow2(Wo)))
+// and all WM channel fragments -> WM*WN accumulators of 16 VGPRs.
+// Per channel chunk (KC channels, all taps) the block stages
+//     weights  [KC*T][BM]      (straight copy of the packed rows, float4)
+//     patch    [KC][PH][PW]    (input window incl. halo, zero padded)
+// in LDS, then issues T*KC/2 k-steps of WM*WN MFMAs.  2-3 blocks are resident per CU, so
+// one block's staging overlaps another's MFMA phase.
+#include "scf_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvK {
+  const float* in0; const float* in1;
+  int C0, Cin;
+  long long in0_ns, in1_ns;
+  int H, W, Ho, Wo;
+  const float* wp; long long w_ns;
+  int Mld, Cout, Krows;
+  int KH, KW, T, stride, pad_h, pad_w, KC, nchunk;
+  int fc_log2, tiles_x, tiles_y, mblocks, PH, PW;
+  int wvec;
+  float* out; long long out_ns;
+  const float* bias; const float* scale; const float* shift;
+  const float* res; long long res_ns;
+  float out_div;
+  int act, act2, act_split, mode;
+  const float* gru_h; long long gru_h_ns;
+  float* gru_aux; long long gru_aux_ns;
+  const float* gru_z; long long gru_z_ns;
+};
+
+// all taps of one staged channel chunk: NCP = KC/2 k-steps (channel pairs) per tap
+template <int WM, int WN, int NCP>
+__device__ __forceinline__ void mfma_taps(f32x16 (&acc)[WM][WN], const float* wl, const float* pl,
+                                          const int (&boff)[WN], int T, int KW, int KC, int BM,
+                                          int PW, int PHW, int half, int l32) {
+  for (int t = 0; t < T; ++t) {
+    const int ky = t / KW, kx = t - ky * KW;
+    const float* wt = wl + (t * KC + half) * BM + l32;
+    const float* pt = pl + ky * PW + kx;
+#pragma unroll
+    for (int c = 0; c < NCP; ++c) {
+      const int cp = 2 * c;
+      float a[WM], b[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = wt[cp * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[j] = pt[cp * PHW + boff[j]];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+}
+
+template <int WM, int WN, int KC>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int BM = WM * 32;
+  constexpr int NFRAG = WN * 4;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l32 = lane & 31, half = lane >> 5;
+
+  const int lb = scf_xcd_remap(blockIdx.x, gridDim.x);
+  const int mblk = lb % p.mblocks;
+  const int tile = lb / p.mblocks;
+  const int m0 = mblk * BM;
+
+  const int FC = 1 << p.fc_log2, FR = 32 >> p.fc_log2, TR = NFRAG * FR;
+  const int txi = tile % p.tiles_x;
+  const int t2 = tile / p.tiles_x;
+  const int tyi = t2 % p.tiles_y;
+  const int n = t2 / p.tiles_y;
+  const int ty0 = tyi * TR, tx0 = txi * FC;
+  const int s = p.stride;
+  const int iy0 = ty0 * s - p.pad_h, ix0 = tx0 * s - p.pad_w;
+  const int PH = p.PH, PW = p.PW, PHW = PH * PW;
+  const int T = p.T;
+
+  float* wl = lds;
+  float* pl = lds + KC * T * BM;
+
+  const int fr = l32 >> p.fc_log2, fc = l32 & (FC - 1);
+  int boff[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) boff[j] = (((wave * WN + j) * FR + fr) * s) * PW + fc * s + half * PHW;
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const long long HWin = (long long)p.H * p.W;
+  const float* in0n = p.in0 + (long long)n * p.in0_ns;
+  const float* in1n = p.in1 ? p.in1 + (long long)n * p.in1_ns : nullptr;
+  const float* wpn = p.wp + (long long)n * p.w_ns;
+  const int rows = KC * T;
+
+  for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+    __syncthreads();
+    // ---- stage the input window (zero padded) ----
+    const int c0 = chunk * KC;
+    for (int row = wave; row < KC * PH; row += 4) {
+      const int cl = row / PH, py = row - cl * PH;
+      const int cg = c0 + cl, iy = iy0 + py;
+      const bool rok = cg < p.Cin && iy >= 0 && iy < p.H;
+      const float* src = nullptr;
+      if (rok) src = (cg < p.C0 ? in0n + cg * HWin : in1n + (cg - p.C0) * HWin) + (long long)iy * p.W;
+      float* dst = pl + row * PW;
+      for (int px = lane; px < PW; px += 64) {
+        const int ix = ix0 + px;
+        float v = 0.f;
+        if (rok && ix >= 0 && ix < p.W) v = src[ix];
+        dst[px] = v;
+      }
+    }
+    // ---- stage the weight rows of this chunk ----
+    const long long krow0 = (long long)chunk * rows;
+    const float* wsrc = wpn + krow0 * p.Mld + m0;
+    if (p.wvec && m0 + BM <= p.Mld && krow0 + rows <= p.Krows) {
+      constexpr int B4 = BM / 4;
+      for (int e = tid; e < rows * B4; e += 256) {
+        const int r = e / B4, c4 = e - r * B4;
+        *reinterpret_cast<float4*>(wl + r * BM + c4 * 4) =
+            *reinterpret_cast<const float4*>(wsrc + (long long)r * p.Mld + c4 * 4);
+      }
+    } else {
+      for (int e = tid; e < rows * BM; e += 256) {
+        const int r = e / BM, c = e - r * BM;
+        float v = 0.f;
+        if (m0 + c < p.Mld && krow0 + r < p.Krows) v = wsrc[(long long)r * p.Mld + c];
+        wl[e] = v;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA phase ----
+    mfma_taps<WM, WN, KC / 2>(acc, wl, pl, boff, T, p.KW, KC, BM, PW, PHW, half, l32);
+  }
+
+  // ---- epilogue: C/D layout col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*half ----
+  const long long HWo = (long long)p.Ho * p.Wo;
+  const bool use_div = p.out_div != 1.0f;
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int oy = ty0 + (wave * WN + j) * FR + fr, ox = tx0 + fc;
+    const bool pok = oy < p.Ho && ox < p.Wo;
+    const long long pix = (long long)oy * p.Wo + ox;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (pok && co < p.Cout) {
+        float v = acc[i][j][r];
+        if (use_div) v = v / p.out_div;
+        if (p.bias) v += p.bias[co];
+        if (p.mode == SCF_CONV_PLAIN) {
+          if (p.scale) v = v * p.scale[co] + p.shift[co];
+          if (p.res) v += p.res[(long long)n * p.res_ns + co * HWo + pix];
+          const int a = (p.act_split > 0 && co >= p.act_split) ? p.act2 : p.act;
+          p.out[(long long)n * p.out_ns + co * HWo + pix] = scf_apply_act(v, a);
+        } else if (p.mode == SCF_CONV_GRU_ZR) {
+          const float sg = 1.f / (1.f + expf(-v));
+          const int hc = p.Cout >> 1;
+          if (co < hc) {
+            p.out[(long long)n * p.out_ns + co * HWo + pix] = sg;
+          } else {
+            const int c2 = co - hc;
+            const float hv = p.gru_h[(long long)n * p.gru_h_ns + c2 * HWo + pix];
+            p.gru_aux[(long long)n * p.gru_aux_ns + c2 * HWo + pix] = sg * hv;
+          }
+        } else {  // SCF_CONV_GRU_Q
+          const float q = tanhf(v);
+          const float z = p.gru_z[(long long)n * p.gru_z_ns + co * HWo + pix];
+          const float hv = p.gru_h[(long long)n * p.gru_h_ns + co * HWo + pix];
+          p.out[(long long)n * p.out_ns + co * HWo + pix] = (1.f - z) * hv + z * q;
+        }
+        }
+      }
+    }
+  }
+}
+
+template <int WM, int WN>
+static int launch_conv(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
+  if (k.KC == 8)
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, 8>), dim3(nblk), dim3(256), lds_bytes, st, k);
+  else
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, 2>), dim3(nblk), dim3(256), lds_bytes, st, k);
+  return scf_launch_status();
+}
+
+static int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
+  if (!d || !d->in0 || !d->wp || !d->out) return SCF_EINVAL;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C0 <= 0 || d->C1 < 0 || d->Cout <= 0) return SCF_EINVAL;
+  if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->pad_h < 0 || d->pad_w < 0) return SCF_EINVAL;
+  if (d->C1 > 0 && !d->in1) return SCF_EINVAL;
+  if (d->KC != 2 && d->KC != 8) return SCF_EUNSUPPORTED;
+  if (d->Mld < d->Cout) return SCF_EINVAL;
+  if (d->mode == SCF_CONV_GRU_ZR && (!d->gru_h || !d->gru_aux || (d->Cout & 1))) return SCF_EINVAL;
+  if (d->mode == SCF_CONV_GRU_Q && (!d->gru_h || !d->gru_z)) return SCF_EINVAL;
+  if ((d->scale == nullptr) != (d->shift == nullptr)) return SCF_EINVAL;
+
+  ConvK k;
+  k.in0 = d->in0; k.in1 = d->C1 > 0 ? d->in1 : nullptr;
+  k.C0 = d->C0; k.Cin = d->C0 + d->C1;
+  k.in0_ns = d->in0_nstride; k.in1_ns = d->in1_nstride;
+  k.H = d->H; k.W = d->W;
+  k.Ho = (d->H + 2 * d->pad_h - d->KH) / d->stride + 1;
+  k.Wo = (d->W + 2 * d->pad_w - d->KW) / d->stride + 1;
+  if (k.Ho <= 0 || k.Wo <= 0) return SCF_EINVAL;
+  k.wp = d->wp; k.w_ns = d->w_nstride; k.Mld = d->Mld; k.Cout = d->Cout;
+  k.KH = d->KH; k.KW = d->KW; k.T = d->KH * d->KW; k.stride = d->stride;
+  k.pad_h = d->pad_h; k.pad_w = d->pad_w; k.KC = d->KC;
+  k.nchunk = (k.Cin + k.KC - 1) / k.KC;
+  // shared packed weights carry zero rows up to nchunk*KC*T; per-sample "weights" (correlation
+  // build: a raw feature map) only have Cin*T rows.
+  k.Krows = d->w_nstride ? k.Cin * k.T : k.nchunk * k.KC * k.T;
+  k.wvec = ((d->Mld & 3) == 0) && ((d->w_nstride & 3) == 0) && (((uintptr_t)d->wp & 15) == 0);
+  k.out = d->out; k.out_ns = d->out_nstride;
+  k.bias = d->bias; k.scale = d->scale; k.shift = d->shift;
+  k.res = d->res; k.res_ns = d->res_nstride;
+  k.out_div = d->out_div == 0.f ? 1.f : d->out_div;
+  k.act = d->act; k.act2 = d->act2; k.act_split = d->act_split; k.mode = d->mode;
+  k.gru_h = d->gru_h; k.gru_h_ns = d->gru_h_nstride;
+  k.gru_aux = d->gru_aux; k.gru_aux_ns = d->gru_aux_nstride;
+  k.gru_z = d->gru_z; k.gru_z_ns = d->gru_z_nstride;
+
+  const int FC = next_pow2(k.Wo) < 32 ? next_pow2(k.Wo) : 32;
+  int fl = 0;
+  while ((1 << fl) < FC) ++fl;
+  k.fc_log2 = fl;
+  const int FR = 32 / FC;
+
+  // tile shape selection
+  const int frags_m = (k.Cout + 31) / 32;
+  int WM;
+  if (frags_m <= 4) WM = frags_m;
+  else if (frags_m % 4 == 0) WM = 4;
+  else if (frags_m % 3 == 0) WM = 3;
+  else WM = 4;
+  k.mblocks = (frags_m + WM - 1) / WM;
+  auto ntiles = [&](int WN) {
+    const int TR = WN * 4 * FR;
+    return (long long)d->N * ((k.Ho + TR - 1) / TR) * ((k.Wo + FC - 1) / FC);
+  };
+  // at most 4 accumulator fragments (64 VGPRs) per wave: WN = 2 only for WM <= 2
+  int WN = (WM <= 2 && ntiles(2) * k.mblocks >= 512) ? 2 : 1;
+  size_t lds_bytes = 0;
+  for (;;) {
+    const int TR = WN * 4 * FR;
+    k.PH = (TR - 1) * k.stride + k.KH;
+    k.PW = (FC - 1) * k.stride + k.KW;
+    lds_bytes = ((size_t)k.KC * k.T * WM * 32 + (size_t)k.KC * k.PH * k.PW) * sizeof(float);
+    if (lds_bytes <= 64 * 1024 || WN == 1) break;
+    WN = 1;
+  }
+  if (lds_bytes > 64 * 1024) return SCF_EUNSUPPORTED;
+  {
+    const int TR = WN * 4 * FR;
+    k.tiles_y = (k.Ho + TR - 1) / TR;
+    k.tiles_x = (k.Wo + FC - 1) / FC;
+  }
+  const long long nblk = (long long)d->N * k.tiles_y * k.tiles_x * k.mblocks;
+  if (nblk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
+  hipStream_t st = scf_stream(stream);
+#define SCF_CASE(M, Nn) if (WM == M && WN == Nn) return launch_conv<M, Nn>(k, (int)nblk, lds_bytes, st);
+  SCF_CASE(1, 1) SCF_CASE(1, 2) SCF_CASE(2, 1) SCF_CASE(2, 2)
+  SCF_CASE(3, 1) SCF_CASE(4, 1)
+#undef SCF_CASE
+  return SCF_EUNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------
+// Correlation volume + pyramid: CorrelationPyramid.forward, raft_decoder.py:35-58.
+// level0 = conv2d(1x1) with per-sample weights feat1[n] ([C][hw] is already the packed
+// [K][M] layout), divided by sqrt(C); levels 1.. = cascaded 2x2 average pools.
+// ---------------------------------------------------------------------------------
+extern "C" int scf_corr_build(const float* feat1, const float* feat2, float* const* levels, int N,
+                              int C, int h, int w, int L, scf_stream_t stream) {
+  if (!feat1 || !feat2 || !levels || N <= 0 || C <= 0 || h <= 0 || w <= 0 || L <= 0) return SCF_EINVAL;
+  if (L > SCF_MAX_LEVELS) return SCF_EUNSUPPORTED;
+  for (int l = 0; l < L; ++l)
+    if (!levels[l]) return SCF_EINVAL;
+  const int hw = h * w;
+  scf_conv_desc d = {};
+  d.in0 = feat2; d.C0 = C; d.in0_nstride = (int64_t)C * hw;
+  d.N = N; d.H = h; d.W = w;
+  d.wp = feat1; d.w_nstride = (int64_t)C * hw; d.Mld = hw; d.Cout = hw;
+  d.KH = d.KW = 1; d.stride = 1; d.pad_h = d.pad_w = 0;
+  d.KC = (C % 8 == 0) ? 8 : 2;
+  d.out = levels[0]; d.out_nstride = (int64_t)hw * hw;
+  d.out_div = sqrtf((float)C);
+  d.act = SCF_ACT_NONE; d.mode = SCF_CONV_PLAIN;
+  int rc = scf_conv2d(&d, stream);
+  if (rc != SCF_OK) return rc;
+  int lh = h, lw = w;
+  for (int l = 1; l < L; ++l) {
+    if (lh < 2 || lw < 2) return SCF_EINVAL;
+    rc = scf_avgpool2x2(levels[l - 1], levels[l], (int64_t)N * hw, lh, lw, stream);
+    if (rc != SCF_OK) return rc;
+    lh /= 2;
+    lw /= 2;
+  }
+  return SCF_OK;
+}

@@ -1,0 +1,158 @@
+// Multi-scale correlation lookup (RAFT/SCFlow "CorrLookup") for gfx950.
+//
+// Reference semantics: models/utils/corr_lookup.py:102-136 (+ bilinear_sample :31-67).
+//
+// Roofline: HBM-bound gather.  Per query and level the kernel touches the (2r+2)^2
+// footprint of that query's private correlation map once (400 B at r=4) and writes
+// (2r+1)^2 outputs (324 B); no byte is shared between queries, so the algorithmic
+// traffic is 4*(400+324)+8 = 2904 B/query.
+//
+// Work decomposition (wave64):
+//   block = 256 threads = 4 waves handling the same 32 consecutive queries;
+//   wave w owns pyramid level w (levels w, w+4, ... when L > 4).
+//   load phase : the wave's 64 lanes sweep the 32 x (2r+2)^2 footprint elements in
+//                element order -> every wave-load covers contiguous rows of one or two
+//                queries' maps (coalesced 40-B runs), exactly the algorithmic bytes are
+//                requested, out-of-map taps become 0 (zero padding);
+//                values are parked in LDS at an ODD per-query stride (bank-conflict
+//                free for the transposed read that follows).
+//   compute    : lane = (query, half); the two half-waves split the x-offsets; bilinear
+//                weights are per (query, level) constants because offsets are integers.
+//   store      : out[n, k, y, x]; each half-wave writes 32 consecutive queries of one
+//                channel = one full 128-B line.
+#include "scf_common.h"
+
+struct LookupParams {
+  const float* lvl[SCF_MAX_LEVELS];
+  int lh[SCF_MAX_LEVELS];
+  int lw[SCF_MAX_LEVELS];
+  const float* flow;
+  float* out;
+  int N, h, w, L;
+  long long total_q;
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void corr_lookup_kernel(LookupParams p) {
+  constexpr int FW = 2 * R + 2;       // footprint width
+  constexpr int FS = FW * FW;         // footprint size
+  constexpr int FSP = FS | 1;         // odd LDS stride per query
+  constexpr int D = 2 * R + 1;        // window width
+  constexpr int QB = 32;              // queries per block
+  __shared__ float fp[4][QB * FSP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l32 = lane & 31, half = lane >> 5;
+  const long long gq0 = (long long)blockIdx.x * QB;
+  const int hw = p.h * p.w;
+  const int ktot = p.L * D * D;
+
+  // this lane's query (both half-waves hold the same 32 queries)
+  const long long gq = gq0 + l32;
+  const bool qvalid = gq < p.total_q;
+  int n = 0, q = 0;
+  float qx = 0.f, qy = 0.f;
+  if (qvalid) {
+    n = (int)(gq / hw);
+    q = (int)(gq - (long long)n * hw);
+    const int y = q / p.w, x = q - y * p.w;
+    const float* fl = p.flow + (long long)n * 2 * hw + q;
+    qx = (float)x + fl[0];
+    qy = (float)y + fl[hw];
+  }
+  float* myfp = fp[wave];
+
+  for (int lvl = wave; lvl < p.L; lvl += 4) {
+    const int lh = p.lh[lvl], lw = p.lw[lvl];
+    const long long msz = (long long)lh * lw;
+    const float* base = p.lvl[lvl];
+    // Reference quirk at degenerate sizes: coordinates are normalised with max(size-1, 1) and
+    // grid_sample(align_corners=True) de-normalises with (size-1), so along a size-1 axis
+    // EVERY tap lands exactly on index 0 (corr_lookup.py:64-67).
+    const bool flat_x = lw == 1, flat_y = lh == 1;
+    const float inv = 1.0f / (float)(1 << lvl);
+    float cx = flat_x ? (float)R : qx * inv;          // exact power-of-two scaling
+    float cy = flat_y ? (float)R : qy * inv;
+    cx = fminf(fmaxf(cx, -30000.f), 30000.f);         // far outside any map -> all taps 0
+    cy = fminf(fmaxf(cy, -30000.f), 30000.f);
+    if (!(cx == cx)) cx = -30000.f;                   // NaN flow: treat as out of range
+    if (!(cy == cy)) cy = -30000.f;
+    const float x0f = floorf(cx), y0f = floorf(cy);
+    const int x0 = (int)x0f - R, y0 = (int)y0f - R;
+    const int packed = (x0 & 0xffff) | (y0 << 16);
+
+
+    // ---- load phase: 32*FS footprint elements, 64 per wave-instruction ----
+    constexpr int NIT = (QB * FS + 63) / 64;
+#pragma unroll 10
+    for (int it = 0; it < NIT; ++it) {
+      const int e = it * 64 + lane;
+      const int qq = e / FS;
+      const int rem = e - qq * FS;
+      const int row = rem / FW, col = rem - row * FW;
+      const int pk = __shfl(packed, qq & 31);
+      const int xx = flat_x ? 0 : (int)(short)(pk & 0xffff) + col;
+      const int yy = flat_y ? 0 : (pk >> 16) + row;
+      const bool ok = (qq < QB) && (gq0 + qq < p.total_q) && xx >= 0 && xx < lw && yy >= 0 && yy < lh;
+      float v = 0.f;
+      if (ok) v = base[(gq0 + qq) * msz + (long long)yy * lw + xx];
+      if (qq < QB) myfp[qq * FSP + rem] = v;
+    }
+    __builtin_amdgcn_wave_barrier();  // same-wave LDS ops complete in order
+
+    // ---- compute + store ----
+    const float tx = cx - x0f, ty = cy - y0f;
+    const float wx0 = (x0f + 1.f) - cx, wy0 = (y0f + 1.f) - cy;   // grid_sample: (x_se - x)
+    const float nw = wx0 * wy0, ne = tx * wy0, sw = wx0 * ty, se = tx * ty;
+    const float* f = myfp + l32 * FSP;
+    const int i0 = half ? (D + 1) / 2 : 0;
+    const int i1 = half ? D : (D + 1) / 2;
+    float colA[FW], colB[FW];
+#pragma unroll
+    for (int r = 0; r < FW; ++r) colA[r] = f[r * FW + i0];
+    float* o = p.out + ((long long)n * ktot + (long long)lvl * D * D) * hw + q;
+    for (int i = i0; i < i1; ++i) {
+#pragma unroll
+      for (int r = 0; r < FW; ++r) colB[r] = f[r * FW + i + 1];
+      if (qvalid) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          const float v = colA[j] * nw + colB[j] * ne + colA[j + 1] * sw + colB[j + 1] * se;
+          o[(long long)(i * D + j) * hw] = v;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < FW; ++r) colA[r] = colB[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+extern "C" int scf_corr_lookup(const float* const* levels, const float* flow, float* out, int N,
+                               int h, int w, int r, int L, scf_stream_t stream) {
+  if (!levels || !flow || !out || N <= 0 || h <= 0 || w <= 0 || L <= 0) return SCF_EINVAL;
+  if (L > SCF_MAX_LEVELS) return SCF_EUNSUPPORTED;
+  LookupParams p;
+  int lh = h, lw = w;
+  for (int l = 0; l < L; ++l) {
+    if (!levels[l] || lh <= 0 || lw <= 0) return SCF_EINVAL;
+    p.lvl[l] = levels[l];
+    p.lh[l] = lh;
+    p.lw[l] = lw;
+    lh /= 2;
+    lw /= 2;
+  }
+  p.flow = flow;
+  p.out = out;
+  p.N = N; p.h = h; p.w = w; p.L = L;
+  p.total_q = (long long)N * h * w;
+  const int nblk = (int)scf_cdiv(p.total_q, 32);
+  switch (r) {
+    case 4: hipLaunchKernelGGL(corr_lookup_kernel<4>, dim3(nblk), dim3(256), 0, scf_stream(stream), p); break;
+    case 3: hipLaunchKernelGGL(corr_lookup_kernel<3>, dim3(nblk), dim3(256), 0, scf_stream(stream), p); break;
+    case 2: hipLaunchKernelGGL(corr_lookup_kernel<2>, dim3(nblk), dim3(256), 0, scf_stream(stream), p); break;
+    case 1: hipLaunchKernelGGL(corr_lookup_kernel<1>, dim3(nblk), dim3(256), 0, scf_stream(stream), p); break;
+    default: return SCF_EUNSUPPORTED;
+  }
+  return scf_launch_status();
+}

@@ -1,0 +1,220 @@
+// InstanceNorm (+residual, +ReLU), GroupNorm+ReLU and the small linear layers of the pose
+// head, for gfx950.  All are memory-bound: one workgroup per normalisation group keeps the
+// group in registers (single HBM read, single write), two-pass variance in fp32.
+#include "scf_common.h"
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// sum over a 256-thread workgroup, result broadcast to every thread
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------------------------
+// InstanceNorm2d(eps, affine=False, no running stats): F.instance_norm on the feature
+// encoder (norm_cfg IN; resnet.py:75-86, raft_encoder.py:300-302).  One block per (n, c)
+// plane; VEC4 float4 per thread cached in registers.
+// ---------------------------------------------------------------------------------
+template <int VEC4>
+__global__ __launch_bounds__(256) void instance_norm_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ res,
+                                                            float* __restrict__ out, int HW,
+                                                            float eps, int relu) {
+  __shared__ float red[4];
+  const long long pl = blockIdx.x;
+  const float4* xp = reinterpret_cast<const float4*>(x + pl * HW);
+  const int n4 = HW >> 2;
+  float4 v[VEC4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC4; ++i) {
+    const int idx = i * 256 + threadIdx.x;
+    v[i] = idx < n4 ? xp[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = block_sum_256(s, red) / (float)HW;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC4; ++i) {
+    const int idx = i * 256 + threadIdx.x;
+    if (idx < n4) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float var = block_sum_256(q, red) / (float)HW;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  float4* op = reinterpret_cast<float4*>(out + pl * HW);
+  const float4* rp = res ? reinterpret_cast<const float4*>(res + pl * HW) : nullptr;
+#pragma unroll
+  for (int i = 0; i < VEC4; ++i) {
+    const int idx = i * 256 + threadIdx.x;
+    if (idx < n4) {
+      float4 o;
+      o.x = (v[i].x - mean) * rstd;
+      o.y = (v[i].y - mean) * rstd;
+      o.z = (v[i].z - mean) * rstd;
+      o.w = (v[i].w - mean) * rstd;
+      if (rp) {
+        const float4 r = rp[idx];
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+      }
+      if (relu) {
+        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+      }
+      op[idx] = o;
+    }
+  }
+}
+
+// generic fallback (any HW): three sweeps, the 2nd/3rd hit L2
+__global__ __launch_bounds__(256) void instance_norm_generic_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ res,
+                                                                    float* __restrict__ out, int HW,
+                                                                    float eps, int relu) {
+  __shared__ float red[4];
+  const long long pl = blockIdx.x;
+  const float* xp = x + pl * HW;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) s += xp[i];
+  const float mean = block_sum_256(s, red) / (float)HW;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    const float a = xp[i] - mean;
+    q += a * a;
+  }
+  const float var = block_sum_256(q, red) / (float)HW;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    float o = (xp[i] - mean) * rstd;
+    if (res) o += res[pl * HW + i];
+    if (relu) o = fmaxf(o, 0.f);
+    out[pl * HW + i] = o;
+  }
+}
+
+extern "C" int scf_instance_norm(const float* x, const float* res, float* out, int64_t planes,
+                                 int HW, float eps, int relu, scf_stream_t stream) {
+  if (!x || !out || planes <= 0 || HW <= 0) return SCF_EINVAL;
+  if (planes > 0x7fffffffLL) return SCF_EUNSUPPORTED;
+  hipStream_t st = scf_stream(stream);
+  const dim3 grid((unsigned)planes), blk(256);
+  const bool vec = (HW % 4 == 0) && ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)res) & 15) == 0);
+  const int n4 = HW / 4;
+  if (vec && n4 <= 256) hipLaunchKernelGGL(instance_norm_kernel<1>, grid, blk, 0, st, x, res, out, HW, eps, relu);
+  else if (vec && n4 <= 1024) hipLaunchKernelGGL(instance_norm_kernel<4>, grid, blk, 0, st, x, res, out, HW, eps, relu);
+  else if (vec && n4 <= 4096) hipLaunchKernelGGL(instance_norm_kernel<16>, grid, blk, 0, st, x, res, out, HW, eps, relu);
+  else hipLaunchKernelGGL(instance_norm_generic_kernel, grid, blk, 0, st, x, res, out, HW, eps, relu);
+  return scf_launch_status();
+}
+
+// ---------------------------------------------------------------------------------
+// GroupNorm(G, eps) with affine + ReLU: pose_head.py:151-159 (norm_cfg GN, 32 groups).
+// Channels of a group are contiguous in NCHW, so a group is one contiguous run of
+// (C/G)*HW floats.  One block per (n, g).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void group_norm_relu_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              float* __restrict__ out, int C, int HW,
+                                                              int G, float eps) {
+  __shared__ float red[4];
+  const int n = blockIdx.x / G, g = blockIdx.x % G;
+  const int cpg = C / G;
+  const int cnt = cpg * HW;
+  const long long base = ((long long)n * C + (long long)g * cpg) * HW;
+  const float* xp = x + base;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < cnt; i += 256) s += xp[i];
+  const float mean = block_sum_256(s, red) / (float)cnt;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < cnt; i += 256) {
+    const float a = xp[i] - mean;
+    q += a * a;
+  }
+  const float var = block_sum_256(q, red) / (float)cnt;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  for (int i = threadIdx.x; i < cnt; i += 256) {
+    const int c = g * cpg + i / HW;
+    const float o = (xp[i] - mean) * rstd * gamma[c] + beta[c];
+    out[base + i] = fmaxf(o, 0.f);
+  }
+}
+
+extern "C" int scf_group_norm_relu(const float* x, const float* gamma, const float* beta, float* out,
+                                   int N, int C, int HW, int G, float eps, scf_stream_t stream) {
+  if (!x || !gamma || !beta || !out || N <= 0 || C <= 0 || HW <= 0 || G <= 0) return SCF_EINVAL;
+  if (C % G != 0) return SCF_EUNSUPPORTED;
+  hipLaunchKernelGGL(group_norm_relu_kernel, dim3(N * G), dim3(256), 0, scf_stream(stream), x, gamma,
+                     beta, out, C, HW, G, eps);
+  return scf_launch_status();
+}
+
+// ---------------------------------------------------------------------------------
+// nn.Linear (+ReLU): pose_head.py:166-172, 203-206.  Weight-streaming GEMV batch: one wave
+// per output feature streams its weight row once (float4) and dots it with up to NB sample
+// rows (activations are L2 resident), wave-level shuffle reduction.
+// ---------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x,
+                                                     const float* __restrict__ W,
+                                                     const float* __restrict__ b,
+                                                     float* __restrict__ y, int N, int K, int O,
+                                                     int act) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + wave;
+  const int n0 = blockIdx.y * NB;
+  if (o >= O) return;
+  float acc[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) acc[i] = 0.f;
+  const float* wrow = W + (long long)o * K;
+  if ((K & 3) == 0) {
+    for (int k = lane * 4; k < K; k += 256) {
+      const float4 w = *reinterpret_cast<const float4*>(wrow + k);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        if (n0 + i < N) {
+          const float4 xv = *reinterpret_cast<const float4*>(x + (long long)(n0 + i) * K + k);
+          acc[i] += (w.x * xv.x + w.y * xv.y) + (w.z * xv.z + w.w * xv.w);
+        }
+      }
+    }
+  } else {
+    for (int k = lane; k < K; k += 64) {
+      const float w = wrow[k];
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        if (n0 + i < N) acc[i] += w * x[(long long)(n0 + i) * K + k];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const float s = wave_sum(acc[i]);
+    if (lane == 0 && n0 + i < N) {
+      float v = s + (b ? b[o] : 0.f);
+      y[(long long)(n0 + i) * O + o] = scf_apply_act(v, act);
+    }
+  }
+}
+
+extern "C" int scf_linear(const float* x, const float* W, const float* b, float* y, int N, int K,
+                          int O, int act, scf_stream_t stream) {
+  if (!x || !W || !y || N <= 0 || K <= 0 || O <= 0) return SCF_EINVAL;
+  if ((((uintptr_t)x | (uintptr_t)W) & 15) != 0 && (K & 3) == 0) return SCF_EUNSUPPORTED;
+  constexpr int NB = 8;
+  const dim3 grid((O + 3) / 4, (N + NB - 1) / NB);
+  if (grid.y > 65535) return SCF_EUNSUPPORTED;
+  hipLaunchKernelGGL(linear_kernel<NB>, grid, dim3(256), 0, scf_stream(stream), x, W, b, y, N, K, O,
+                     act);
+  return scf_launch_status();
+}

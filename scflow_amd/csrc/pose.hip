@@ -1,0 +1,194 @@
+// Pose-induced flow ("shape constraint" re-projection), dense un-projection and the pose
+// update of the SCFlow decoder loop, for gfx950.
+//
+// The reference compacts foreground pixels with torch.nonzero (a device->host sync and a
+// variable-length python list per sample, models/utils/pose.py:44-64) and scatters the
+// projected flow back (:66-88).  Scatter targets are exactly the compacted pixels, so the
+// computation is an independent per-pixel map: this file keeps it dense (depth > 0 mask),
+// which removes the sync, the index tensors and the python loop over the batch.
+#include "scf_common.h"
+
+// 3x3 inverse in fp64 (adjugate), rounded to fp32.  The reference uses torch.inverse (fp32
+// LU); both are within a few fp32 ulp of the true inverse.
+__device__ inline void inv3x3(const float* m, float* o) {
+  const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7],
+               i = m[8];
+  const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  const double det = a * A + b * B + c * C;
+  const double id = 1.0 / det;
+  o[0] = (float)(A * id);
+  o[1] = (float)(-(b * i - c * h) * id);
+  o[2] = (float)((b * f - c * e) * id);
+  o[3] = (float)(B * id);
+  o[4] = (float)((a * i - c * g) * id);
+  o[5] = (float)(-(a * f - c * d) * id);
+  o[6] = (float)(C * id);
+  o[7] = (float)(-(a * h - b * g) * id);
+  o[8] = (float)((a * e - b * d) * id);
+}
+
+struct PoseMats {
+  float Kinv[9], R0inv[9], t0[3], K[9], R[9], t[3];
+};
+
+__device__ inline void load_mats(PoseMats* s, const float* K, const float* R0, const float* t0,
+                                 const float* R, const float* t, int n) {
+  const int tid = threadIdx.x;
+  if (tid == 0) inv3x3(K + 9 * n, s->Kinv);
+  if (tid == 64) inv3x3(R0 + 9 * n, s->R0inv);
+  if (tid >= 128 && tid < 137) {
+    s->K[tid - 128] = K[9 * n + tid - 128];
+    if (R) s->R[tid - 128] = R[9 * n + tid - 128];
+  }
+  if (tid >= 192 && tid < 195) {
+    s->t0[tid - 192] = t0[3 * n + tid - 192];
+    if (t) s->t[tid - 192] = t[3 * n + tid - 192];
+  }
+  __syncthreads();
+}
+
+// object-frame point of pixel (x, y) with depth d: lift_2d_to_3d, pose.py:26-41
+__device__ __forceinline__ void unproject(const PoseMats& s, float x, float y, float d, float& X,
+                                          float& Y, float& Z) {
+  const float hx = x * d, hy = y * d, hz = d;
+  const float cx = s.Kinv[0] * hx + s.Kinv[1] * hy + s.Kinv[2] * hz - s.t0[0];
+  const float cy = s.Kinv[3] * hx + s.Kinv[4] * hy + s.Kinv[5] * hz - s.t0[1];
+  const float cz = s.Kinv[6] * hx + s.Kinv[7] * hy + s.Kinv[8] * hz - s.t0[2];
+  X = s.R0inv[0] * cx + s.R0inv[1] * cy + s.R0inv[2] * cz;
+  Y = s.R0inv[3] * cx + s.R0inv[4] * cy + s.R0inv[5] * cz;
+  Z = s.R0inv[6] * cx + s.R0inv[7] * cy + s.R0inv[8] * cz;
+}
+
+__global__ __launch_bounds__(256) void reproject_flow_kernel(
+    const float* __restrict__ depth, const float* __restrict__ K, const float* __restrict__ R0,
+    const float* __restrict__ t0, const float* __restrict__ R, const float* __restrict__ t,
+    float* __restrict__ flow, int H, int W, float invalid) {
+  __shared__ PoseMats s;
+  const int n = blockIdx.y;
+  load_mats(&s, K, R0, t0, R, t, n);
+  const int hw = H * W;
+  const float* dp = depth + (long long)n * hw;
+  float* fx = flow + (long long)n * 2 * hw;
+  float* fy = fx + hw;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < hw; idx += gridDim.x * blockDim.x) {
+    const float d = dp[idx];
+    float u = invalid, v = invalid;
+    if (d > 0.f) {
+      const int yi = idx / W, xi = idx - yi * W;
+      const float x = (float)xi, y = (float)yi;
+      float X, Y, Z;
+      unproject(s, x, y, d, X, Y, Z);
+      // p = K (R P + t): get_flow_from_delta_pose_and_points, pose.py:82-86
+      const float px = s.R[0] * X + s.R[1] * Y + s.R[2] * Z + s.t[0];
+      const float py = s.R[3] * X + s.R[4] * Y + s.R[5] * Z + s.t[1];
+      const float pz = s.R[6] * X + s.R[7] * Y + s.R[8] * Z + s.t[2];
+      const float qx = s.K[0] * px + s.K[1] * py + s.K[2] * pz;
+      const float qy = s.K[3] * px + s.K[4] * py + s.K[5] * pz;
+      const float qz = s.K[6] * px + s.K[7] * py + s.K[8] * pz;
+      u = qx / qz - x;
+      v = qy / qz - y;
+    }
+    fx[idx] = u;
+    fy[idx] = v;
+  }
+}
+
+extern "C" int scf_reproject_flow(const float* depth, const float* K, const float* R0,
+                                  const float* t0, const float* R, const float* t, float* flow,
+                                  int N, int H, int W, float invalid_num, scf_stream_t stream) {
+  if (!depth || !K || !R0 || !t0 || !R || !t || !flow || N <= 0 || H <= 0 || W <= 0) return SCF_EINVAL;
+  if (N > 65535) return SCF_EUNSUPPORTED;
+  const int bx = (int)(scf_cdiv((int64_t)H * W, 256) < 64 ? scf_cdiv((int64_t)H * W, 256) : 64);
+  hipLaunchKernelGGL(reproject_flow_kernel, dim3(bx, N), dim3(256), 0, scf_stream(stream), depth, K,
+                     R0, t0, R, t, flow, H, W, invalid_num);
+  return scf_launch_status();
+}
+
+__global__ __launch_bounds__(256) void unproject_depth_kernel(
+    const float* __restrict__ depth, const float* __restrict__ K, const float* __restrict__ R0,
+    const float* __restrict__ t0, float* __restrict__ pts, int H, int W) {
+  __shared__ PoseMats s;
+  const int n = blockIdx.y;
+  load_mats(&s, K, R0, t0, nullptr, nullptr, n);
+  const int hw = H * W;
+  const float* dp = depth + (long long)n * hw;
+  float* o = pts + (long long)n * 3 * hw;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < hw; idx += gridDim.x * blockDim.x) {
+    const float d = dp[idx];
+    float X = 0.f, Y = 0.f, Z = 0.f;
+    if (d > 0.f) {
+      const int yi = idx / W, xi = idx - yi * W;
+      unproject(s, (float)xi, (float)yi, d, X, Y, Z);
+    }
+    o[idx] = X;
+    o[hw + idx] = Y;
+    o[2 * hw + idx] = Z;
+  }
+}
+
+extern "C" int scf_unproject_depth(const float* depth, const float* K, const float* R0,
+                                   const float* t0, float* pts, int N, int H, int W,
+                                   scf_stream_t stream) {
+  if (!depth || !K || !R0 || !t0 || !pts || N <= 0 || H <= 0 || W <= 0) return SCF_EINVAL;
+  if (N > 65535) return SCF_EUNSUPPORTED;
+  const int bx = (int)(scf_cdiv((int64_t)H * W, 256) < 64 ? scf_cdiv((int64_t)H * W, 256) : 64);
+  hipLaunchKernelGGL(unproject_depth_kernel, dim3(bx, N), dim3(256), 0, scf_stream(stream), depth,
+                     K, R0, t0, pts, H, W);
+  return scf_launch_status();
+}
+
+// class select (pose_head.py:207-210) + ortho6d -> R (pose.py:153-169) + pose compose
+// (pose.py:124-149, depth_transform='exp', weight=10).  One thread per sample.
+__global__ void pose_update_kernel(const float* __restrict__ rot_all,
+                                   const float* __restrict__ trans_all,
+                                   const long long* __restrict__ label, int num_class,
+                                   int label_mode, const float* R_in, const float* t_in,
+                                   float* __restrict__ d_rot, float* __restrict__ d_trans,
+                                   float* R_out, float* t_out, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  long long cls = label_mode ? label[n] : label[0];
+  if (cls < 0) cls += num_class;                 // torch.index_select rejects these; stay in range
+  if (cls < 0) cls = 0;
+  if (cls >= num_class) cls = num_class - 1;
+  const float* a = rot_all + ((long long)n * num_class + cls) * 6;
+  const float* dt = trans_all + ((long long)n * num_class + cls) * 3;
+  float o6[6], dtr[3];
+  for (int i = 0; i < 6; ++i) { o6[i] = a[i]; d_rot[n * 6 + i] = o6[i]; }
+  for (int i = 0; i < 3; ++i) { dtr[i] = dt[i]; d_trans[n * 3 + i] = dtr[i]; }
+  // x = normalize(a); z = normalize(x X b); y = z X x
+  float nx = sqrtf(o6[0] * o6[0] + o6[1] * o6[1] + o6[2] * o6[2]);
+  nx = fmaxf(nx, 1e-12f);
+  const float x0 = o6[0] / nx, x1 = o6[1] / nx, x2 = o6[2] / nx;
+  float z0 = x1 * o6[5] - x2 * o6[4], z1 = x2 * o6[3] - x0 * o6[5], z2 = x0 * o6[4] - x1 * o6[3];
+  float nz = fmaxf(sqrtf(z0 * z0 + z1 * z1 + z2 * z2), 1e-12f);
+  z0 /= nz; z1 /= nz; z2 /= nz;
+  const float y0 = z1 * x2 - z2 * x1, y1 = z2 * x0 - z0 * x2, y2 = z0 * x1 - z1 * x0;
+  const float Rd[9] = {x0, y0, z0, x1, y1, z1, x2, y2, z2};   // columns [x y z]
+  float Rs[9], ts[3];
+  for (int i = 0; i < 9; ++i) Rs[i] = R_in[n * 9 + i];
+  for (int i = 0; i < 3; ++i) ts[i] = t_in[n * 3 + i];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c)
+      R_out[n * 9 + r * 3 + c] = Rd[r * 3 + 0] * Rs[0 * 3 + c] + Rd[r * 3 + 1] * Rs[1 * 3 + c] +
+                                 Rd[r * 3 + 2] * Rs[2 * 3 + c];
+  const float vz = ts[2] / expf(dtr[2]);
+  const float vx = vz * (dtr[0] / 10.f + ts[0] / ts[2]);
+  const float vy = vz * (dtr[1] / 10.f + ts[1] / ts[2]);
+  t_out[n * 3 + 0] = vx;
+  t_out[n * 3 + 1] = vy;
+  t_out[n * 3 + 2] = vz;
+}
+
+extern "C" int scf_pose_update(const float* rot_all, const float* trans_all, const int64_t* label,
+                               int num_class, int label_mode, const float* R_in, const float* t_in,
+                               float* d_rot, float* d_trans, float* R_out, float* t_out, int N,
+                               scf_stream_t stream) {
+  if (!rot_all || !trans_all || !label || !R_in || !t_in || !d_rot || !d_trans || !R_out || !t_out ||
+      N <= 0 || num_class <= 0)
+    return SCF_EINVAL;
+  hipLaunchKernelGGL(pose_update_kernel, dim3((N + 63) / 64), dim3(64), 0, scf_stream(stream),
+                     rot_all, trans_all, (const long long*)label, num_class, label_mode, R_in, t_in,
+                     d_rot, d_trans, R_out, t_out, N);
+  return scf_launch_status();
+}

@@ -1,0 +1,100 @@
+// Bilinear resize (align_corners=True), 2x2 average pooling and strided copies.
+// All three are pure HBM streaming kernels: one output element per thread, coalesced along
+// the innermost (x) dimension, grid capped and grid-strided.
+#include "scf_common.h"
+
+// F.interpolate(mode='bilinear', align_corners=True): scflow_decoder.py:188-197 (1/8 flow
+// down-sampling, mixed with the 1/scale factor) and :222-227 (x8 up-sampling of flow+dflow
+// and of the mask).  src = dst * (in-1)/(out-1); the +1 neighbour is clamped at the edge.
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ a,
+                                                              const float* __restrict__ b,
+                                                              float* __restrict__ out,
+                                                              long long planes, int Hin, int Win,
+                                                              int Hout, int Wout, float sh, float sw,
+                                                              float mul) {
+  const long long total = planes * Hout * Wout;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(idx % Wout);
+    const long long t = idx / Wout;
+    const int oy = (int)(t % Hout);
+    const long long pl = t / Hout;
+    const float fy = sh * (float)oy, fx = sw * (float)ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hin - 1 ? 1 : 0), x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const long long base = pl * Hin * Win;
+    float v00 = a[base + (long long)y0 * Win + x0], v01 = a[base + (long long)y0 * Win + x1];
+    float v10 = a[base + (long long)y1 * Win + x0], v11 = a[base + (long long)y1 * Win + x1];
+    if (b) {
+      v00 += b[base + (long long)y0 * Win + x0];
+      v01 += b[base + (long long)y0 * Win + x1];
+      v10 += b[base + (long long)y1 * Win + x0];
+      v11 += b[base + (long long)y1 * Win + x1];
+    }
+    out[idx] = mul * (hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11));
+  }
+}
+
+extern "C" int scf_resize_bilinear(const float* a, const float* b, float* out, int64_t planes,
+                                   int Hin, int Win, int Hout, int Wout, float mul,
+                                   scf_stream_t stream) {
+  if (!a || !out || planes <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return SCF_EINVAL;
+  const float sh = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
+  const float sw = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
+  const long long total = (long long)planes * Hout * Wout;
+  const int grid = (int)(scf_cdiv(total, 256) < 8192 ? scf_cdiv(total, 256) : 8192);
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), a, b,
+                     out, (long long)planes, Hin, Win, Hout, Wout, sh, sw, mul);
+  return scf_launch_status();
+}
+
+// nn.AvgPool2d(2, 2) of CorrelationPyramid (raft_decoder.py:32, 54-56): window summed in
+// row-major order, then divided by 4.
+__global__ __launch_bounds__(256) void avgpool2x2_kernel(const float* __restrict__ x,
+                                                         float* __restrict__ out, long long planes,
+                                                         int Hin, int Win, int Ho, int Wo) {
+  const long long total = planes * Ho * Wo;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(idx % Wo);
+    const long long t = idx / Wo;
+    const int oy = (int)(t % Ho);
+    const long long pl = t / Ho;
+    const float* s = x + pl * Hin * Win + (long long)(2 * oy) * Win + 2 * ox;
+    out[idx] = (((s[0] + s[1]) + s[Win]) + s[Win + 1]) * 0.25f;
+  }
+}
+
+extern "C" int scf_avgpool2x2(const float* x, float* out, int64_t planes, int Hin, int Win,
+                              scf_stream_t stream) {
+  if (!x || !out || planes <= 0 || Hin < 2 || Win < 2) return SCF_EINVAL;
+  const int Ho = Hin / 2, Wo = Win / 2;
+  const long long total = (long long)planes * Ho * Wo;
+  const int grid = (int)(scf_cdiv(total, 256) < 16384 ? scf_cdiv(total, 256) : 16384);
+  hipLaunchKernelGGL(avgpool2x2_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), x, out,
+                     (long long)planes, Hin, Win, Ho, Wo);
+  return scf_launch_status();
+}
+
+__global__ __launch_bounds__(256) void copy_strided_kernel(const float* __restrict__ src,
+                                                           long long sns, float* __restrict__ dst,
+                                                           long long dns, int N, long long count) {
+  const long long total = (long long)N * count;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const long long n = idx / count, r = idx - n * count;
+    dst[n * dns + r] = src[n * sns + r];
+  }
+}
+
+extern "C" int scf_copy_strided(const float* src, int64_t src_nstride, float* dst,
+                                int64_t dst_nstride, int N, int64_t count, scf_stream_t stream) {
+  if (!src || !dst || N <= 0 || count <= 0) return SCF_EINVAL;
+  const long long total = (long long)N * count;
+  const int grid = (int)(scf_cdiv(total, 256) < 8192 ? scf_cdiv(total, 256) : 8192);
+  hipLaunchKernelGGL(copy_strided_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), src,
+                     (long long)src_nstride, dst, (long long)dst_nstride, N, (long long)count);
+  return scf_launch_status();
+}

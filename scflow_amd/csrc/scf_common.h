@@ -1,0 +1,37 @@
+// Shared helpers for the gfx950 kernels of libscflow_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/scflow_hip.h"
+
+#define SCF_WAVE 64
+
+static inline int scf_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SCF_OK : SCF_ELAUNCH;
+}
+
+static inline hipStream_t scf_stream(scf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int64_t scf_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// XCD-aware block remap (bijective for any grid size): consecutive LOGICAL ids run on the
+// same XCD so that blocks sharing an input halo / a weight slab hit the same L2.
+// Hardware places physical block b on XCD b % 8 (observed, used for speed only).
+__device__ __forceinline__ int scf_xcd_remap(int b, int nblk) {
+  const int nx = 8;
+  int q = nblk / nx, r = nblk % nx;
+  int xcd = b % nx, slot = b / nx;
+  int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+
+__device__ __forceinline__ float scf_apply_act(float v, int act) {
+  switch (act) {
+    case SCF_ACT_RELU: return v > 0.f ? v : 0.f;
+    case SCF_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    case SCF_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}

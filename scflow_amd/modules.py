@@ -1,0 +1,504 @@
+"""Host-side mirror of the reference's encoder / decoder / head classes.
+
+Each class keeps the reference's constructor signature, registry name and
+``state_dict`` key layout (tests/golden/state_dict_keys.json),
+so the reference ``model=`` config dict and reference checkpoints apply
+unchanged -- but ``forward`` only sequences hand-written gfx950 kernels through
+``scflow_amd.ops`` (C ABI, include/scflow_hip.h).  The ``torch.nn`` leaf
+modules below are parameter containers: their own ``forward`` is never called,
+and there is no CPU fallback (ops reject non-GPU tensors).
+
+Kernel-layout copies of the parameters (``PackedConv``) are built lazily on the
+parameters' device and dropped whenever the module is moved or re-loaded.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_GRU_Q, CONV_GRU_ZR, PackedConv)
+from .registry import DECODERS, ENCODERS, HEAD, build_head
+
+Tensor = torch.Tensor
+
+_ACTS = {None: ACT_NONE, 'ReLU': ACT_RELU, 'Sigmoid': ACT_SIGMOID, 'Tanh': ACT_TANH}
+
+
+def _act_code(act_cfg: Optional[dict]) -> int:
+    if act_cfg is None:
+        return ACT_NONE
+    kind = act_cfg.get('type')
+    if kind not in _ACTS:
+        raise NotImplementedError(f'activation {kind} has no HIP epilogue')
+    return _ACTS[kind]
+
+
+class HipModule(nn.Module):
+    """nn.Module whose kernel-layout parameter cache follows .to()/load_state_dict()."""
+
+    def _drop_packed(self) -> None:
+        for m in self.modules():
+            if isinstance(m, HipModule):
+                m.__dict__['_packed'] = None
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._drop_packed()
+        return out
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self._drop_packed()
+        return out
+
+    def _pack(self):
+        raise NotImplementedError
+
+    @property
+    def packed(self):
+        if self.__dict__.get('_packed') is None:
+            with torch.no_grad():
+                self.__dict__['_packed'] = self._pack()
+        return self.__dict__['_packed']
+
+
+class ConvBlock(HipModule):
+    """parameter layout of mmcv ``ConvModule``: ``.conv`` (+ ``.gn``); conv -> norm -> act,
+    bias iff no norm."""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, padding=0, act_cfg=dict(type='ReLU'),
+                 norm_cfg: Optional[dict] = None):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, kernel_size, stride=stride, padding=padding,
+                              bias=norm_cfg is None)
+        self.act = _act_code(act_cfg)
+        self.groups = None
+        if norm_cfg is not None:
+            if norm_cfg.get('type') != 'GN':
+                raise NotImplementedError('ConvBlock supports GN only (pose head)')
+            self.groups = norm_cfg['num_groups']
+            self.gn = nn.GroupNorm(self.groups, cout, eps=norm_cfg.get('eps', 1e-5))
+
+    def _pack(self) -> PackedConv:
+        c = self.conv
+        return PackedConv.from_weight(c.weight, c.bias, stride=c.stride[0], padding=c.padding)
+
+    def forward(self, x0: Tensor, x1: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+        if self.groups is None:
+            return ops.conv2d(self.packed, x0, x1, out=out, act=self.act)
+        y = ops.conv2d(self.packed, x0, x1)
+        if self.act != ACT_RELU:
+            raise NotImplementedError('GN is fused with ReLU only')
+        return ops.group_norm_relu(y, self.gn.weight, self.gn.bias, self.groups, self.gn.eps, out=out)
+
+
+# =============================================================== encoder
+class _BasicBlock(HipModule):
+    """backbone/resnet.py:14-94 parameters: conv1, {in,bn}1, conv2, {in,bn}2, downsample."""
+
+    def __init__(self, inplanes, planes, stride, kind, downsample: bool):
+        super().__init__()
+        tag = 'in' if kind == 'IN' else 'bn'
+        mk = (lambda c: nn.InstanceNorm2d(c)) if kind == 'IN' else (lambda c: nn.BatchNorm2d(c))
+        self.kind, self.stride, self.tag = kind, stride, tag
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=True)
+        setattr(self, tag + '1', mk(planes))
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=True)
+        setattr(self, tag + '2', mk(planes))
+        self.downsample = None
+        if downsample:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride=stride, bias=True),
+                                            mk(planes))
+
+    def _bn(self, m):
+        return (m.weight, m.bias, m.running_mean, m.running_var) if self.kind == 'BN' else None
+
+    def _pack(self):
+        n1, n2 = getattr(self, self.tag + '1'), getattr(self, self.tag + '2')
+        eps = n1.eps
+        p = dict(c1=PackedConv.from_weight(self.conv1.weight, self.conv1.bias, self.stride, 1,
+                                           bn=self._bn(n1), eps=eps),
+                 c2=PackedConv.from_weight(self.conv2.weight, self.conv2.bias, 1, 1,
+                                           bn=self._bn(n2), eps=eps))
+        if self.downsample is not None:
+            ds = self.downsample[0]
+            p['ds'] = PackedConv.from_weight(ds.weight, ds.bias, self.stride, 0,
+                                             bn=self._bn(self.downsample[1]), eps=eps)
+        return p
+
+    def forward(self, x: Tensor) -> Tensor:
+        """resnet.py:67-94.  BN (eval) is folded into the conv epilogue; IN needs the
+        whole plane, so it is its own kernel (residual add + ReLU fused there)."""
+        p = self.packed
+        if self.kind == 'BN':
+            y = ops.conv2d(p['c1'], x, act=ACT_RELU)
+            idt = ops.conv2d(p['ds'], x) if 'ds' in p else x
+            return ops.conv2d(p['c2'], y, res=idt, act=ACT_RELU)
+        y = ops.conv2d(p['c1'], x)
+        ops.instance_norm(y, relu=True, out=y)
+        y2 = ops.conv2d(p['c2'], y)
+        if 'ds' in p:
+            idt = ops.conv2d(p['ds'], x)
+            ops.instance_norm(idt, out=idt)
+        else:
+            idt = x
+        return ops.instance_norm(y2, res=idt, relu=True, out=y2)
+
+
+@ENCODERS.register_module()
+class RAFTEncoder(HipModule):
+    """encoder/raft_encoder.py:13-314, net_type 'Basic' (the SCFlow config):
+    7x7/s2 stem, three stages of two BasicBlocks (64, 96, 128; strides 1, 2, 2), 1x1 head.
+    ``norm_cfg`` IN -> feature encoder, BN -> context encoder (eval statistics)."""
+
+    def __init__(self, in_channels: int, out_channels: int, scale: float = 1 / 8,
+                 net_type: str = 'Basic', norm_cfg: dict = dict(type='BN', requires_grad=True),
+                 init_cfg=None, **unsupported) -> None:
+        super().__init__()
+        if net_type != 'Basic':
+            raise NotImplementedError("only net_type='Basic' is built (SCFlow config)")
+        bad = {k: v for k, v in unsupported.items()
+               if v not in (None, False, -1) and k not in ('conv_cfg',)}
+        if bad:
+            raise NotImplementedError(f'RAFTEncoder options not built: {sorted(bad)}')
+        kind = norm_cfg['type']
+        if kind not in ('IN', 'BN', 'SyncBN'):
+            raise NotImplementedError(f'norm {kind}')
+        kind = 'IN' if kind == 'IN' else 'BN'
+        self.kind, self.tag = kind, ('in' if kind == 'IN' else 'bn')
+        self.in_channels, self.out_channels, self.scale = in_channels, out_channels, scale
+        mk = (lambda c: nn.InstanceNorm2d(c)) if kind == 'IN' else (lambda c: nn.BatchNorm2d(c))
+        self.stem_stride = 1 if scale == 1 / 4 else 2
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, stride=self.stem_stride, padding=3, bias=True)
+        setattr(self, self.tag + '1', mk(64))
+        inplanes = 64
+        self.res_layers = []
+        for i, (planes, stride) in enumerate(zip((64, 96, 128), (1, 2, 2)), start=1):
+            layer = nn.Sequential(
+                _BasicBlock(inplanes, planes, stride, kind, stride != 1 or inplanes != planes),
+                _BasicBlock(planes, planes, 1, kind, False))
+            self.add_module(f'res_layer{i}', layer)
+            self.res_layers.append(f'res_layer{i}')
+            inplanes = planes
+        self.conv2 = nn.Conv2d(128, out_channels, 1)
+
+    def _pack(self):
+        n1 = getattr(self, self.tag + '1')
+        bn = (n1.weight, n1.bias, n1.running_mean, n1.running_var) if self.kind == 'BN' else None
+        return dict(stem=PackedConv.from_weight(self.conv1.weight, self.conv1.bias,
+                                                self.stem_stride, 3, bn=bn, eps=n1.eps),
+                    head=PackedConv.from_weight(self.conv2.weight, self.conv2.bias, 1, 0))
+
+    def forward(self, x: Tensor, out: Optional[Tensor] = None, head_act: int = ACT_NONE,
+                head_act2: int = ACT_NONE, head_split: int = 0) -> Tensor:
+        """raft_encoder.py:286-314.  ``out`` / ``head_*`` let the caller have the 1x1 head
+        write (with a split tanh/relu epilogue) straight into a slice of a larger buffer."""
+        p = self.packed
+        if self.kind == 'BN':
+            x = ops.conv2d(p['stem'], x, act=ACT_RELU)
+        else:
+            x = ops.conv2d(p['stem'], x)
+            ops.instance_norm(x, relu=True, out=x)
+        for name in self.res_layers:
+            for blk in getattr(self, name):
+                x = blk(x)
+        return ops.conv2d(p['head'], x, out=out, act=head_act, act2=head_act2,
+                          act_split=head_split)
+
+
+# =============================================================== decoder
+class CorrelationPyramid(HipModule):
+    """decoder/raft_decoder.py:19-58."""
+
+    def __init__(self, num_levels: int = 4) -> None:
+        super().__init__()
+        self.num_levels = num_levels
+
+    def forward(self, feat1: Tensor, feat2: Tensor) -> List[Tensor]:
+        return ops.corr_build(feat1, feat2, self.num_levels)
+
+
+class CorrLookup(HipModule):
+    """utils/corr_lookup.py:71-136 (bilinear, zeros padding, align_corners=True only)."""
+
+    def __init__(self, radius: int = 4, mode: str = 'bilinear', padding_mode: str = 'zeros',
+                 align_corners: bool = True) -> None:
+        super().__init__()
+        if mode != 'bilinear' or padding_mode != 'zeros' or not align_corners:
+            raise NotImplementedError('HIP CorrLookup: bilinear / zeros / align_corners=True')
+        self.r = radius
+
+    def forward(self, corr_pyramid: Sequence[Tensor], flow: Tensor) -> Tensor:
+        return ops.corr_lookup(corr_pyramid, flow, self.r)
+
+
+class MotionEncoder(HipModule):
+    """decoder/raft_decoder.py:61-166, 'Basic' channel plan."""
+
+    def __init__(self, num_levels: int = 4, radius: int = 4, net_type: str = 'Basic',
+                 conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU')) -> None:
+        super().__init__()
+        if net_type not in ('Basic', 'Large') or norm_cfg is not None:
+            raise NotImplementedError('MotionEncoder: Basic, no norm')
+        cin = num_levels * (2 * radius + 1) ** 2
+        self.corr_net = nn.Sequential(ConvBlock(cin, 256, 1, padding=0, act_cfg=act_cfg),
+                                      ConvBlock(256, 192, 3, padding=1, act_cfg=act_cfg))
+        self.flow_net = nn.Sequential(ConvBlock(2, 128, 7, padding=3, act_cfg=act_cfg),
+                                      ConvBlock(128, 64, 3, padding=1, act_cfg=act_cfg))
+        self.out_net = nn.Sequential(ConvBlock(256, 126, 3, padding=1, act_cfg=act_cfg))
+        self.out_channels = [126]
+
+    def forward(self, corr: Tensor, flow: Tensor, out: Optional[Tensor] = None) -> Tensor:
+        """raft_decoder.py:152-166.  -> (N, 128, h, w) = [out_net(126) | flow(2)], optionally
+        written into ``out`` (a channel slice of the GRU input buffer)."""
+        n, _, h, w = flow.shape
+        dev = flow.device
+        if out is None:
+            out = torch.empty((n, 128, h, w), dtype=torch.float32, device=dev)
+        cf = torch.empty((n, 256, h, w), dtype=torch.float32, device=dev)
+        c1 = self.corr_net[0](corr)
+        self.corr_net[1](c1, out=cf[:, :192])
+        f1 = self.flow_net[0](flow)
+        self.flow_net[1](f1, out=cf[:, 192:])
+        self.out_net[0](cf, out=out[:, :126])
+        ops.copy_channels(flow, out[:, 126:128])
+        return out
+
+
+class ConvGRU(HipModule):
+    """decoder/raft_decoder.py:168-253.  z and r share their input, so their weights are
+    stacked into one 256-row convolution whose epilogue emits z and r*h; the q convolution's
+    epilogue applies tanh and the state update (1-z)*h + z*q in place."""
+    _kernel = {'Conv': [3], 'SeqConv': [(1, 5), (5, 1)]}
+    _padding = {'Conv': [1], 'SeqConv': [(0, 2), (2, 0)]}
+
+    def __init__(self, h_channels: int, x_channels: int, net_type: str = 'SeqConv') -> None:
+        super().__init__()
+        self.h_channels, self.x_channels = h_channels, x_channels
+        mk = lambda act: nn.ModuleList([
+            ConvBlock(h_channels + x_channels, h_channels, k, padding=p, act_cfg=dict(type=act))
+            for k, p in zip(self._kernel[net_type], self._padding[net_type])])
+        self.conv_z, self.conv_r, self.conv_q = mk('Sigmoid'), mk('Sigmoid'), mk('Tanh')
+
+    def _pack(self):
+        packs = []
+        for z, r, q in zip(self.conv_z, self.conv_r, self.conv_q):
+            w = torch.cat([z.conv.weight, r.conv.weight], 0)
+            b = torch.cat([z.conv.bias, r.conv.bias], 0)
+            packs.append((PackedConv.from_weight(w, b, 1, z.conv.padding),
+                          PackedConv.from_weight(q.conv.weight, q.conv.bias, 1, q.conv.padding)))
+        return packs
+
+    def forward_inplace(self, hx: Tensor) -> Tensor:
+        """hx: (N, h_ch + x_ch, h, w) = [h | x]; h is updated in place."""
+        hc = self.h_channels
+        n, _, h, w = hx.shape
+        z = torch.empty((n, hc, h, w), dtype=torch.float32, device=hx.device)
+        rh = torch.empty((n, hc, h, w), dtype=torch.float32, device=hx.device)
+        hv, xv = hx[:, :hc], hx[:, hc:]
+        for pzr, pq in self.packed:
+            ops.conv2d(pzr, hx, out=z, mode=CONV_GRU_ZR, gru_h=hv, gru_aux=rh)
+            ops.conv2d(pq, rh, xv, out=hv, mode=CONV_GRU_Q, gru_h=hv, gru_z=z)
+        return hv
+
+    def forward(self, h: Tensor, x: Tensor) -> Tensor:
+        """raft_decoder.py:235-253 signature (copies h, x into one buffer)."""
+        n, _, hh, ww = h.shape
+        hx = torch.empty((n, self.h_channels + self.x_channels, hh, ww), dtype=torch.float32,
+                         device=h.device)
+        ops.copy_channels(h, hx[:, :self.h_channels])
+        ops.copy_channels(x, hx[:, self.h_channels:])
+        return self.forward_inplace(hx)
+
+
+class XHead(HipModule):
+    """decoder/raft_decoder.py:256-294."""
+
+    def __init__(self, in_channels: int, feat_channels: Sequence[int], x_channels: int, x: str):
+        super().__init__()
+        if len(feat_channels) != 1:
+            raise NotImplementedError('XHead: one hidden layer')
+        self.layers = nn.Sequential(ConvBlock(in_channels, feat_channels[0], 3, padding=1))
+        k = 1 if x == 'mask' else 3
+        self.predict_layer = nn.Conv2d(feat_channels[0], x_channels, k, padding=k // 2)
+
+    def _pack(self) -> PackedConv:
+        c = self.predict_layer
+        return PackedConv.from_weight(c.weight, c.bias, 1, c.padding)
+
+    def predict(self, feat: Tensor, act: int = ACT_NONE) -> Tensor:
+        return ops.conv2d(self.packed, feat, act=act)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.predict(self.layers[0](x))
+
+
+@HEAD.register_module()
+class MultiClassPoseHead(HipModule):
+    """head/pose_head.py:110-211."""
+
+    def __init__(self, num_class: int, in_channels: int, net_type: str, norm_cfg: dict,
+                 act_cfg: dict, feat_size: Optional[tuple] = None,
+                 rotation_mode: str = 'quaternion', init_cfg=None):
+        super().__init__()
+        if rotation_mode != 'ortho6d':
+            raise NotImplementedError('quaternion branch needs kornia in the reference and is '
+                                      'not used by the SCFlow config')
+        feat_size = feat_size or {'Basic': (32, 32), 'Large': (64, 64)}[net_type]
+        self.num_class = num_class
+        self.rotation_out_channels = 6
+        convs, cin, size = [], in_channels, feat_size[0] * feat_size[1]
+        for _ in range(3):
+            convs.append(ConvBlock(cin, 128, 3, stride=2, padding=1, act_cfg=act_cfg,
+                                   norm_cfg=norm_cfg))
+            cin, size = 128, int(size / 4)
+        self.conv_layers = nn.Sequential(*convs)
+        self.fc_layers = nn.Sequential(nn.Sequential(nn.Linear(128 * size, 1024), nn.ReLU()),
+                                       nn.Sequential(nn.Linear(1024, 256), nn.ReLU()))
+        self.rotation_pred = nn.Linear(256, 6 * num_class)
+        self.translation_pred = nn.Linear(256, 3 * num_class)
+        # reference label selection uses label[0] for the whole batch (pose_head.py:209-210,
+        # SURVEY.md 8 a8); label_mode=1 selects per sample instead.
+        self.label_mode = 0
+        self.init_weights()
+
+    def init_weights(self):
+        """pose_head.py:187-198: zero heads, identity ortho6d bias."""
+        nn.init.zeros_(self.translation_pred.weight)
+        nn.init.zeros_(self.translation_pred.bias)
+        nn.init.zeros_(self.rotation_pred.weight)
+        with torch.no_grad():
+            self.rotation_pred.bias.copy_(torch.tensor([1., 0., 0., 0., 1., 0.] * self.num_class))
+
+    def features(self, x0: Tensor, x1: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        x = self.conv_layers[0](x0, x1)
+        x = self.conv_layers[1](x)
+        x = self.conv_layers[2](x)
+        x = x.view(x.shape[0], -1)
+        for fc in self.fc_layers:
+            x = ops.linear(x, fc[0].weight, fc[0].bias, ACT_RELU)
+        rot_all = ops.linear(x, self.rotation_pred.weight, self.rotation_pred.bias)
+        trans_all = ops.linear(x, self.translation_pred.weight, self.translation_pred.bias)
+        return rot_all, trans_all
+
+    def forward(self, x: Tensor, label: Tensor) -> Tuple[Tensor, Tensor]:
+        """pose_head.py:201-211 -> (delta rotation (N,6), delta translation (N,3))."""
+        rot_all, trans_all = self.features(x)
+        n = x.shape[0]
+        eye = torch.eye(3, device=x.device).repeat(n, 1, 1)
+        one = torch.ones((n, 3), device=x.device)
+        d_rot, d_trans, _, _ = ops.pose_update(rot_all, trans_all, label, self.num_class, eye, one,
+                                               self.label_mode)
+        return d_rot, d_trans
+
+
+@DECODERS.register_module()
+class SCFlowDecoder(HipModule):
+    """decoder/scflow_decoder.py:18-251."""
+    _h_channels = {'Basic': 128, 'Small': 96}
+    _cxt_channels = {'Basic': 128, 'Small': 64}
+
+    def __init__(self, net_type: str, num_levels: int, radius: int, iters: int, detach_flow: bool,
+                 detach_mask: bool, detach_pose: bool, mask_flow: bool, mask_corr: bool,
+                 pose_head_cfg: dict, depth_transform: str = 'exp',
+                 detach_depth_for_xy: bool = False,
+                 corr_lookup_cfg: dict = dict(align_corners=True), gru_type: str = 'SeqConv',
+                 feat_channels: Union[int, Sequence[int]] = 256, conv_cfg=None, norm_cfg=None,
+                 act_cfg=None) -> None:
+        super().__init__()
+        if net_type != 'Basic':
+            raise NotImplementedError("SCFlowDecoder: net_type='Basic'")
+        if mask_flow or mask_corr:
+            raise NotImplementedError('mask_flow / mask_corr (both False in scflow.py) are not built')
+        if depth_transform != 'exp':
+            raise NotImplementedError("depth_transform='exp' only")
+        self.net_type, self.num_levels, self.radius, self.iters = net_type, num_levels, radius, iters
+        self.h_channels = self._h_channels[net_type]
+        self.cxt_channels = self._cxt_channels[net_type]
+        self.corr_block = CorrelationPyramid(num_levels)
+        cl = dict(corr_lookup_cfg)
+        cl.pop('type', None)
+        cl['radius'] = radius
+        self.corr_lookup = CorrLookup(**cl)
+        self.encoder = MotionEncoder(num_levels, radius, net_type, conv_cfg, norm_cfg, act_cfg)
+        self.gru = ConvGRU(self.h_channels, 126 + 2 + self.cxt_channels, gru_type)
+        self.pose_pred = build_head(pose_head_cfg)
+        fc = [256]    # scflow_decoder.py:73-74: the tuple check always yields [feat_channels]
+        self.flow_pred = XHead(self.h_channels, fc, 2, x='flow')
+        self.mask_pred = XHead(self.h_channels, fc, 1, x='mask')
+        self.delta_flow_encoder = nn.Sequential(ConvBlock(2, 128, 7, padding=3, act_cfg=act_cfg),
+                                                ConvBlock(128, 64, 3, padding=1, act_cfg=act_cfg))
+        self.mask_encoder = nn.Sequential(ConvBlock(1, 64, 3, padding=1, act_cfg=act_cfg),
+                                          ConvBlock(64, 32, 3, padding=1, act_cfg=act_cfg))
+
+    def _pack(self):
+        # the two XHead hidden layers read the same h: one 512-row convolution
+        a, b = self.flow_pred.layers[0].conv, self.mask_pred.layers[0].conv
+        return PackedConv.from_weight(torch.cat([a.weight, b.weight], 0),
+                                      torch.cat([a.bias, b.bias], 0), 1, 1)
+
+    def forward(self, feat_render: Tensor, feat_real: Tensor, h_feat: Tensor, cxt_feat: Tensor,
+                ref_rotation: Tensor, ref_translation: Tensor, depth: Tensor, internel_k: Tensor,
+                label: Tensor, init_flow: Tensor, invalid_flow_num: float):
+        """scflow_decoder.py:150-251 (inference).  Returns the reference's 7-tuple of
+        per-iteration lists."""
+        hc, cc = self.h_channels, self.cxt_channels
+        n, H, W = depth.shape
+        scale = 2 ** (self.num_levels - 1)
+        h, w = H // scale, W // scale
+        dev = depth.device
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        pyramid = self.corr_block(feat_render, feat_real)                          # :172
+        # GRU buffer [h | cxt | motion(126) | flow(2)]; reuse the caller's if it already is one
+        hx = _as_gru_buffer(h_feat, cxt_feat, hc + cc + 128)
+        rot, trans = ref_rotation.contiguous(), ref_translation.contiguous()
+        rot0, trans0 = rot, trans
+        flow = init_flow
+        outs = ([], [], [], [], [], [], [])
+        dm = torch.empty((n, 96, h, w), **f32)
+        heads = torch.empty((n, 512, h, w), **f32)
+        for _ in range(self.iters):
+            flow_lr = ops.resize_bilinear(flow, (h, w), mul=1.0 / scale)           # :196-197
+            corr = self.corr_lookup(pyramid, flow_lr)                              # :198
+            self.encoder(corr, flow_lr, out=hx[:, hc + cc:])                       # :206
+            hv = self.gru.forward_inplace(hx)                                      # :207-208
+            ops.conv2d(self.packed, hv, out=heads, act=ACT_RELU)
+            d_flow = self.flow_pred.predict(heads[:, :256])                        # :210
+            mask = self.mask_pred.predict(heads[:, 256:], act=ACT_SIGMOID)         # :212-213
+            d1 = self.delta_flow_encoder[0](d_flow)                                # :216
+            self.delta_flow_encoder[1](d1, out=dm[:, :64])
+            m1 = self.mask_encoder[0](mask)                                        # :217
+            self.mask_encoder[1](m1, out=dm[:, 64:])
+            rot_all, trans_all = self.pose_pred.features(hv, dm)                   # :218-219
+            d_rot, d_trans, rot, trans = ops.pose_update(                          # :230-236
+                rot_all, trans_all, label, self.pose_pred.num_class, rot, trans,
+                self.pose_pred.label_mode)
+            flow_pred = ops.resize_bilinear(flow_lr, (H, W), mul=float(scale), b=d_flow)  # :222-224
+            up_mask = ops.resize_bilinear(mask, (H, W))                            # :226-227
+            flow = ops.reproject_flow(depth, internel_k, rot0, trans0, rot, trans,  # :239-243
+                                      invalid_flow_num)
+            for lst, v in zip(outs, (flow, flow_pred, rot, trans, up_mask, d_rot, d_trans)):
+                lst.append(v)
+        return outs
+
+
+def _as_gru_buffer(h_feat: Tensor, cxt_feat: Tensor, total: int) -> Tensor:
+    """[h | cxt | ...] buffer of ``total`` channels: zero-copy when h_feat / cxt_feat already
+    are adjacent channel slices of such a buffer (SCFlowRefiner.extract_feat makes them so)."""
+    n, hc, h, w = h_feat.shape
+    cc = cxt_feat.shape[1]
+    base = h_feat._base
+    if (base is not None and base is cxt_feat._base and base.dim() == 4 and base.is_contiguous()
+            and tuple(base.shape) == (n, total, h, w)
+            and h_feat.data_ptr() == base.data_ptr()
+            and cxt_feat.data_ptr() == base.data_ptr() + hc * h * w * 4
+            and h_feat.stride() == base.stride() and cxt_feat.stride() == base.stride()):
+        return base
+    hx = torch.empty((n, total, h, w), dtype=torch.float32, device=h_feat.device)
+    ops.copy_channels(h_feat, hx[:, :hc])
+    ops.copy_channels(cxt_feat, hx[:, hc:hc + cc])
+    return hx

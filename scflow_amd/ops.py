@@ -1,0 +1,335 @@
+"""Operator-level Python wrappers over the C ABI (include/scflow_hip.h).
+
+torch is used for what it is good at here -- owning device memory and exposing
+the current HIP stream; every arithmetic operation below runs in a
+hand-written gfx950 kernel of libscflow_hip.so.  CPU tensors are rejected:
+there is no fallback path.
+
+Tensors may be *sample-strided* NCHW views (a channel slice of a larger
+contiguous NCHW buffer): only the batch stride is free, which is how channel
+concatenations are expressed without copies.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_GRU_Q, CONV_GRU_ZR,
+                   CONV_PLAIN, ConvDesc)
+
+Tensor = torch.Tensor
+
+__all__ = ['PackedConv', 'pack_conv_weight', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
+           'instance_norm', 'group_norm_relu', 'linear', 'pose_update', 'reproject_flow',
+           'unproject_depth', 'resize_bilinear', 'avgpool2x2', 'copy_channels',
+           'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_TANH', 'CONV_PLAIN', 'CONV_GRU_ZR',
+           'CONV_GRU_Q']
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: Tensor, name: str) -> None:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.ScflowHipError(f'{name}: expected a tensor on the GPU (HIP path only, no CPU '
+                                  'fallback)')
+    if t.dtype != torch.float32:
+        raise _lib.ScflowHipError(f'{name}: expected float32, got {t.dtype}')
+
+
+def _dense(t: Tensor, name: str) -> int:
+    _dev(t, name)
+    if not t.is_contiguous():
+        raise _lib.ScflowHipError(f'{name}: expected a contiguous tensor')
+    return t.data_ptr()
+
+
+def _nchw(t: Tensor, name: str) -> Tuple[int, int, int, int, int, int]:
+    """(ptr, N, C, H, W, sample_stride) of a sample-strided NCHW tensor."""
+    _dev(t, name)
+    if t.dim() != 4:
+        raise _lib.ScflowHipError(f'{name}: expected 4-D NCHW')
+    n, c, h, w = t.shape
+    sn, sc, sh, sw = t.stride()
+    ok = (sw == 1 or w == 1) and (sh == w or h == 1) and (sc == h * w or c == 1)
+    if not ok:
+        raise _lib.ScflowHipError(f'{name}: not a sample-strided NCHW view (strides {t.stride()})')
+    if n == 1:
+        sn = c * h * w
+    return t.data_ptr(), n, c, h, w, sn
+
+
+def _opt(t: Optional[Tensor], name: str) -> Optional[int]:
+    return None if t is None else _dense(t, name)
+
+
+# ------------------------------------------------------------------ conv
+def choose_kc(cin: int, kh: int, kw: int) -> int:
+    """channel chunk staged per LDS round: 8, or 2 for thin inputs / wide kernels."""
+    return 2 if (cin < 8 or kh * kw >= 25) else 8
+
+
+def pack_conv_weight(weight: Tensor, kc: int) -> Tuple[Tensor, int]:
+    """(Cout, Cin, KH, KW) -> packed (nchunk*T*KC, Mld) with
+    row = (chunk*T + tap)*KC + channel_in_chunk, col = cout; zero rows for
+    padded channels; Mld = Cout rounded up to 32 (see scf_conv2d)."""
+    cout, cin, kh, kw = weight.shape
+    t = kh * kw
+    nchunk = (cin + kc - 1) // kc
+    mld = (cout + 31) // 32 * 32
+    w = torch.zeros((cout, nchunk * kc, t), dtype=torch.float32, device=weight.device)
+    w[:, :cin] = weight.reshape(cout, cin, t).float()
+    w = w.reshape(cout, nchunk, kc, t).permute(1, 3, 2, 0).reshape(nchunk * t * kc, cout)
+    out = torch.zeros((nchunk * t * kc, mld), dtype=torch.float32, device=weight.device)
+    out[:, :cout] = w
+    return out.contiguous(), mld
+
+
+@dataclass
+class PackedConv:
+    """a convolution's parameters in kernel layout (device resident)."""
+    wp: Tensor
+    bias: Optional[Tensor]
+    scale: Optional[Tensor]
+    shift: Optional[Tensor]
+    cin: int
+    cout: int
+    kh: int
+    kw: int
+    stride: int
+    pad_h: int
+    pad_w: int
+    kc: int
+    mld: int
+
+    @staticmethod
+    def from_weight(weight: Tensor, bias: Optional[Tensor], stride: int = 1,
+                    padding=0, bn: Optional[Sequence[Tensor]] = None,
+                    eps: float = 1e-5) -> 'PackedConv':
+        """``bn`` = (gamma, beta, running_mean, running_var): eval-mode BatchNorm
+        folded into a per-channel scale/shift applied after the bias."""
+        cout, cin, kh, kw = weight.shape
+        kc = choose_kc(cin, kh, kw)
+        wp, mld = pack_conv_weight(weight, kc)
+        ph, pw = (padding, padding) if isinstance(padding, int) else padding
+        scale = shift = None
+        if bn is not None:
+            gamma, beta, mean, var = [b.float() for b in bn]
+            scale = (gamma / torch.sqrt(var + eps)).contiguous()
+            shift = (beta - mean * scale).contiguous()
+        return PackedConv(wp, None if bias is None else bias.float().contiguous(), scale, shift,
+                          cin, cout, kh, kw, stride, ph, pw, kc, mld)
+
+    def out_hw(self, h: int, w: int) -> Tuple[int, int]:
+        return ((h + 2 * self.pad_h - self.kh) // self.stride + 1,
+                (w + 2 * self.pad_w - self.kw) // self.stride + 1)
+
+
+def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optional[Tensor] = None,
+           *, res: Optional[Tensor] = None, act: int = ACT_NONE, act2: int = ACT_NONE,
+           act_split: int = 0, mode: int = CONV_PLAIN, gru_h: Optional[Tensor] = None,
+           gru_aux: Optional[Tensor] = None, gru_z: Optional[Tensor] = None) -> Tensor:
+    """implicit-GEMM MFMA convolution with fused epilogue (scf_conv2d).
+    input = channel concat of x0 and x1; ``out`` may be a channel slice."""
+    p0, n, c0, h, w, s0 = _nchw(x0, 'x0')
+    p1, c1, s1 = None, 0, 0
+    if x1 is not None:
+        p1, n1, c1, h1, w1, s1 = _nchw(x1, 'x1')
+        if (n1, h1, w1) != (n, h, w):
+            raise _lib.ScflowHipError('x0/x1 shape mismatch')
+    if c0 + c1 != pc.cin:
+        raise _lib.ScflowHipError(f'conv expects {pc.cin} input channels, got {c0}+{c1}')
+    ho, wo = pc.out_hw(h, w)
+    if out is None:
+        out = torch.empty((n, pc.cout // 2 if mode == CONV_GRU_ZR else pc.cout, ho, wo),
+                          dtype=torch.float32, device=x0.device)
+    po, no, co, oh, ow, so = _nchw(out, 'out')
+    want_c = pc.cout // 2 if mode == CONV_GRU_ZR else pc.cout   # ZR: only the z half lands in out
+    if (no, co, oh, ow) != (n, want_c, ho, wo):
+        raise _lib.ScflowHipError(f'out has shape {tuple(out.shape)}, expected '
+                                  f'{(n, want_c, ho, wo)}')
+    d = ConvDesc()
+    d.in0, d.in1, d.C0, d.C1 = p0, p1, c0, c1
+    d.in0_nstride, d.in1_nstride = s0, s1
+    d.N, d.H, d.W = n, h, w
+    d.wp, d.w_nstride, d.Mld, d.Cout = pc.wp.data_ptr(), 0, pc.mld, pc.cout
+    d.KH, d.KW, d.stride, d.pad_h, d.pad_w, d.KC = pc.kh, pc.kw, pc.stride, pc.pad_h, pc.pad_w, pc.kc
+    d.out, d.out_nstride = po, so
+    d.bias = None if pc.bias is None else pc.bias.data_ptr()
+    d.scale = None if pc.scale is None else pc.scale.data_ptr()
+    d.shift = None if pc.shift is None else pc.shift.data_ptr()
+    if res is not None:
+        pr, nr, cr, hr, wr, sr = _nchw(res, 'res')
+        if (nr, cr, hr, wr) != (n, pc.cout, ho, wo):
+            raise _lib.ScflowHipError('res shape mismatch')
+        d.res, d.res_nstride = pr, sr
+    d.out_div = 1.0
+    d.act, d.act2, d.act_split, d.mode = act, act2, act_split, mode
+    if gru_h is not None:
+        ph_, _, _, _, _, sh_ = _nchw(gru_h, 'gru_h')
+        d.gru_h, d.gru_h_nstride = ph_, sh_
+    if gru_aux is not None:
+        pa_, _, _, _, _, sa_ = _nchw(gru_aux, 'gru_aux')
+        d.gru_aux, d.gru_aux_nstride = pa_, sa_
+    if gru_z is not None:
+        pz_, _, _, _, _, sz_ = _nchw(gru_z, 'gru_z')
+        d.gru_z, d.gru_z_nstride = pz_, sz_
+    _lib.check(_lib.load().scf_conv2d(C.byref(d), _stream()), 'scf_conv2d')
+    return out
+
+
+# ----------------------------------------------------- correlation volume
+def corr_build(feat1: Tensor, feat2: Tensor, num_levels: int = 4,
+               out: Optional[List[Tensor]] = None) -> List[Tensor]:
+    """CorrelationPyramid.forward (raft_decoder.py:35-58) -> list of
+    (N*h*w, 1, h>>l, w>>l)."""
+    p1 = _dense(feat1, 'feat1')
+    p2 = _dense(feat2, 'feat2')
+    if feat1.shape != feat2.shape or feat1.dim() != 4:
+        raise _lib.ScflowHipError('feat1/feat2 must be equal-shape NCHW')
+    n, c, h, w = feat1.shape
+    if out is None:
+        out = [torch.empty((n * h * w, 1, h >> l, w >> l), dtype=torch.float32,
+                           device=feat1.device) for l in range(num_levels)]
+    arr = (C.c_void_p * num_levels)(*[_dense(t, 'level') for t in out])
+    _lib.check(_lib.load().scf_corr_build(p1, p2, arr, n, c, h, w, num_levels, _stream()),
+               'scf_corr_build')
+    return out
+
+
+def corr_lookup(pyramid: Sequence[Tensor], flow: Tensor, radius: int = 4,
+                out: Optional[Tensor] = None) -> Tensor:
+    """CorrLookup.forward (corr_lookup.py:102-136) -> (N, L*(2r+1)^2, h, w)."""
+    pf = _dense(flow, 'flow')
+    n, two, h, w = flow.shape
+    if two != 2:
+        raise _lib.ScflowHipError('flow must be (N,2,h,w)')
+    L = len(pyramid)
+    for l, lv in enumerate(pyramid):
+        if tuple(lv.shape) != (n * h * w, 1, h >> l, w >> l):
+            raise _lib.ScflowHipError(f'pyramid level {l} has shape {tuple(lv.shape)}')
+    k = L * (2 * radius + 1) ** 2
+    if out is None:
+        out = torch.empty((n, k, h, w), dtype=torch.float32, device=flow.device)
+    arr = (C.c_void_p * L)(*[_dense(t, 'level') for t in pyramid])
+    _lib.check(_lib.load().scf_corr_lookup(arr, pf, _dense(out, 'out'), n, h, w, radius, L,
+                                           _stream()), 'scf_corr_lookup')
+    return out
+
+
+# ------------------------------------------------------------- norms etc.
+def instance_norm(x: Tensor, res: Optional[Tensor] = None, relu: bool = False,
+                  out: Optional[Tensor] = None, eps: float = 1e-5) -> Tensor:
+    px = _dense(x, 'x')
+    n, c, h, w = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.load().scf_instance_norm(px, _opt(res, 'res'), _dense(out, 'out'), n * c,
+                                             h * w, eps, int(relu), _stream()),
+               'scf_instance_norm')
+    return out
+
+
+def group_norm_relu(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float = 1e-5,
+                    out: Optional[Tensor] = None) -> Tensor:
+    px = _dense(x, 'x')
+    n, c, h, w = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.load().scf_group_norm_relu(px, _dense(gamma, 'gamma'), _dense(beta, 'beta'),
+                                               _dense(out, 'out'), n, c, h * w, groups, eps,
+                                               _stream()), 'scf_group_norm_relu')
+    return out
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int = ACT_NONE,
+           out: Optional[Tensor] = None) -> Tensor:
+    px = _dense(x, 'x')
+    n, k = x.shape
+    o = weight.shape[0]
+    if weight.shape[1] != k:
+        raise _lib.ScflowHipError('linear: weight/in_features mismatch')
+    if out is None:
+        out = torch.empty((n, o), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().scf_linear(px, _dense(weight, 'weight'), _opt(bias, 'bias'),
+                                      _dense(out, 'out'), n, k, o, act, _stream()), 'scf_linear')
+    return out
+
+
+def pose_update(rot_all: Tensor, trans_all: Tensor, label: Tensor, num_class: int,
+                rot: Tensor, trans: Tensor, label_mode: int = 0):
+    """-> (d_rot (N,6), d_trans (N,3), R' (N,3,3), t' (N,3))."""
+    n = rot_all.shape[0]
+    if not label.is_cuda or label.dtype != torch.int64 or not label.is_contiguous():
+        raise _lib.ScflowHipError('label must be a contiguous int64 GPU tensor')
+    dev = rot_all.device
+    d_rot = torch.empty((n, 6), dtype=torch.float32, device=dev)
+    d_trans = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    r_out = torch.empty((n, 3, 3), dtype=torch.float32, device=dev)
+    t_out = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().scf_pose_update(
+        _dense(rot_all, 'rot_all'), _dense(trans_all, 'trans_all'), label.data_ptr(), num_class,
+        label_mode, _dense(rot, 'rot'), _dense(trans, 'trans'), d_rot.data_ptr(),
+        d_trans.data_ptr(), r_out.data_ptr(), t_out.data_ptr(), n, _stream()), 'scf_pose_update')
+    return d_rot, d_trans, r_out, t_out
+
+
+def reproject_flow(depth: Tensor, k: Tensor, rot0: Tensor, trans0: Tensor, rot: Tensor,
+                   trans: Tensor, invalid_num: float = 0., out: Optional[Tensor] = None) -> Tensor:
+    n, h, w = depth.shape
+    if out is None:
+        out = torch.empty((n, 2, h, w), dtype=torch.float32, device=depth.device)
+    _lib.check(_lib.load().scf_reproject_flow(
+        _dense(depth, 'depth'), _dense(k, 'k'), _dense(rot0, 'rot0'), _dense(trans0, 'trans0'),
+        _dense(rot, 'rot'), _dense(trans, 'trans'), _dense(out, 'out'), n, h, w,
+        float(invalid_num), _stream()), 'scf_reproject_flow')
+    return out
+
+
+def unproject_depth(depth: Tensor, k: Tensor, rot0: Tensor, trans0: Tensor) -> Tensor:
+    n, h, w = depth.shape
+    out = torch.empty((n, 3, h, w), dtype=torch.float32, device=depth.device)
+    _lib.check(_lib.load().scf_unproject_depth(
+        _dense(depth, 'depth'), _dense(k, 'k'), _dense(rot0, 'rot0'), _dense(trans0, 'trans0'),
+        out.data_ptr(), n, h, w, _stream()), 'scf_unproject_depth')
+    return out
+
+
+def resize_bilinear(a: Tensor, out_hw: Tuple[int, int], mul: float = 1.0,
+                    b: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """mul * F.interpolate(a + b, size=out_hw, mode='bilinear', align_corners=True)."""
+    pa = _dense(a, 'a')
+    n, c, h, w = a.shape
+    ho, wo = out_hw
+    if out is None:
+        out = torch.empty((n, c, ho, wo), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().scf_resize_bilinear(pa, _opt(b, 'b'), _dense(out, 'out'), n * c, h, w,
+                                               ho, wo, float(mul), _stream()),
+               'scf_resize_bilinear')
+    return out
+
+
+def avgpool2x2(x: Tensor) -> Tensor:
+    px = _dense(x, 'x')
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().scf_avgpool2x2(px, out.data_ptr(), n * c, h, w, _stream()),
+               'scf_avgpool2x2')
+    return out
+
+
+def copy_channels(src: Tensor, dst: Tensor) -> Tensor:
+    """copy a sample-strided NCHW tensor into another (same N, C, H, W)."""
+    ps, n, c, h, w, ss = _nchw(src, 'src')
+    pd, n2, c2, h2, w2, sd = _nchw(dst, 'dst')
+    if (n, c, h, w) != (n2, c2, h2, w2):
+        raise _lib.ScflowHipError('copy_channels shape mismatch')
+    _lib.check(_lib.load().scf_copy_strided(ps, ss, pd, sd, n, c * h * w, _stream()),
+               'scf_copy_strided')
+    return dst

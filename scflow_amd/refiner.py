@@ -1,0 +1,123 @@
+"""``SCFlowRefiner`` -- the drop-in boundary of the hot path.
+
+Mirrors models/refiner/scflow_refiner.py:18-179 (+ base_refiner.py:17-64):
+same registry name, constructor keys (``configs/refine_models/scflow.py:16-113``
+applies unchanged), attribute names, ``extract_feat`` / ``get_pose`` /
+``forward_single_pass`` signatures and return structure, same ``state_dict``
+keys.  Renderer, losses, data formatting and PnP re-mapping are outside the hot
+path: their config keys are accepted and ignored, and
+``forward_single_pass`` consumes an already formatted ``data`` dict (what
+``BaseRefiner.format_data_test`` produces, base_refiner.py:79-133).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple, Union
+
+import torch
+
+from . import ops
+from .modules import HipModule
+from .ops import ACT_RELU, ACT_TANH
+from .registry import REFINERS, build_decoder, build_encoder
+
+Tensor = torch.Tensor
+
+
+@REFINERS.register_module()
+class SCFlowRefiner(HipModule):
+    def __init__(self, seperate_encoder: bool, cxt_channels: int, h_channels: int,
+                 cxt_encoder: dict, encoder: dict, decoder: dict, renderer: Optional[dict] = None,
+                 pose_loss_cfg: Optional[dict] = None, flow_loss_cfg: Optional[dict] = None,
+                 mask_loss_cfg: Optional[dict] = None, max_flow: float = 400,
+                 render_augmentations: Optional[list] = None, filter_invalid_flow: bool = True,
+                 freeze_encoder: bool = False, freeze_bn: bool = False,
+                 train_cfg: Optional[dict] = None, test_cfg: Optional[dict] = None,
+                 init_cfg: Optional[Union[list, dict]] = None) -> None:
+        super().__init__()
+        self.seperate_encoder = seperate_encoder
+        if seperate_encoder:
+            self.render_encoder = build_encoder(encoder)
+            self.real_encoder = build_encoder(encoder)
+        else:                                   # base_refiner.py:36-39: one module, two names
+            enc = build_encoder(encoder)
+            self.render_encoder = enc
+            self.real_encoder = enc
+        self.decoder = build_decoder(decoder)
+        self.context = build_encoder(cxt_encoder)
+        self.renderer = None                    # pytorch3d renderer: out of scope
+        self.max_flow = max_flow
+        self.train_cfg = train_cfg or {}
+        self.test_cfg = test_cfg or {}
+        self.h_channels, self.cxt_channels = h_channels, cxt_channels
+        assert self.h_channels == self.decoder.h_channels
+        assert self.cxt_channels == self.decoder.cxt_channels
+        assert self.h_channels + self.cxt_channels == self.context.out_channels
+        self.filter_invalid_flow = filter_invalid_flow
+        self.test_by_flow = self.test_cfg.get('by_flow', False)
+        self.test_iter_num = self.test_cfg.get('iters', self.decoder.iters)
+        self.eval()
+
+    # -------------------------------------------------------------- features
+    def extract_feat(self, render_images: Tensor, real_images: Tensor
+                     ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+        """scflow_refiner.py:88-110 -> (render_feat, real_feat, h_feat, cxt_feat).
+
+        The shared feature encoder runs ONCE on the 2N stacked images (InstanceNorm is per
+        sample, so this equals two separate passes); the context encoder's 1x1 head writes
+        tanh(h) | relu(cxt) straight into the first 256 channels of the GRU input buffer."""
+        n, _, H, W = render_images.shape
+        dev = render_images.device
+        if self.seperate_encoder:
+            render_feat = self.render_encoder(render_images.contiguous())
+            real_feat = self.real_encoder(real_images.contiguous())
+        else:
+            both = torch.empty((2 * n, 3, H, W), dtype=torch.float32, device=dev)
+            ops.copy_channels(render_images, both[:n])
+            ops.copy_channels(real_images, both[n:])
+            feats = self.render_encoder(both)
+            render_feat, real_feat = feats[:n], feats[n:]
+        hc, cc = self.h_channels, self.cxt_channels
+        sc = int(round(1 / self.context.scale))
+        hx = torch.empty((n, hc + cc + 128, H // sc, W // sc), dtype=torch.float32, device=dev)
+        self.context(render_images.contiguous(), out=hx[:, :hc + cc], head_act=ACT_TANH,
+                     head_act2=ACT_RELU, head_split=hc)
+        return render_feat, real_feat, hx[:, :hc], hx[:, hc:hc + cc]
+
+    # ------------------------------------------------------------------ pose
+    def get_pose(self, render_images: Tensor, real_images: Tensor, ref_rotation: Tensor,
+                 ref_translation: Tensor, depth: Tensor, internel_k: Tensor, label: Tensor,
+                 init_flow: Optional[Tensor] = None):
+        """scflow_refiner.py:112-142 -> 7-tuple of length-``iters`` lists
+        (flow_from_pose, flow_from_pred, rotation_preds, translation_preds, mask_preds,
+        delta_rotation_preds, delta_translation_preds)."""
+        feat_render, feat_real, h_feat, cxt_feat = self.extract_feat(render_images, real_images)
+        if init_flow is None:
+            n, _, H, W = real_images.shape
+            init_flow = torch.zeros((n, 2, H, W), dtype=torch.float32, device=feat_render.device)
+        return self.decoder(feat_render, feat_real, h_feat, cxt_feat, ref_rotation,
+                            ref_translation, depth.contiguous(), internel_k.contiguous(),
+                            label=label, init_flow=init_flow, invalid_flow_num=0.)
+
+    def forward_single_pass(self, data: Dict, data_batch: Optional[Dict] = None,
+                            return_loss: bool = False) -> Dict:
+        """scflow_refiner.py:146-179 minus ``remap_pose_to_origin_resoluaion`` (identity for the
+        'adapt_intrinsic' pipeline of the config; cv2 EPnP otherwise -- out of scope)."""
+        labels = data['labels']
+        per_img = data['per_img_patch_num']
+        iters = self.decoder.iters
+        self.decoder.iters = self.test_iter_num
+        try:
+            outs = self.get_pose(data['rendered_images'], data['real_images'],
+                                 data['ref_rotations'], data['ref_translations'],
+                                 data['rendered_depths'], data['internel_k'], labels)
+        finally:
+            self.decoder.iters = iters
+        rot, trans = outs[2][-1], outs[3][-1]
+        return dict(rotations=torch.split(rot, per_img), translations=torch.split(trans, per_img),
+                    labels=torch.split(labels, per_img),
+                    scores=torch.split(torch.ones_like(labels, dtype=torch.float32), per_img))
+
+    def forward(self, data, data_batch=None, return_loss=False):
+        if return_loss:
+            raise NotImplementedError('training is outside the hot path (SURVEY.md section 2)')
+        return self.forward_single_pass(data, data_batch)

@@ -1,0 +1,58 @@
+"""CPU: libscflow_hip.so loads and exports every symbol include/scflow_hip.h declares
+(no compute calls -- there is no GPU here)."""
+import os
+import re
+
+import pytest
+
+from scflow_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'scflow_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(scf_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_built():
+    assert os.path.exists(_lib.LIB_PATH), 'run python scflow_amd/csrc/build.py'
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in scflow_hip.h but not exported'
+        assert name in _lib.SIGNATURES, f'{name} has no ctypes signature in scflow_amd/_lib.py'
+    for name in _lib.SIGNATURES:
+        assert name in declared, f'{name} bound in _lib.py but not declared in the header'
+
+
+def test_version_and_error_strings():
+    lib = _lib.load()
+    assert lib.scf_version() >= 100
+    assert lib.scf_error_string(0) == b'ok'
+    assert b'invalid' in lib.scf_error_string(-1)
+
+
+def test_conv_desc_layout_matches_c():
+    """sizeof(scf_conv_desc) from a C compile must equal the ctypes mirror."""
+    import ctypes, subprocess, tempfile
+    src = '#include "scflow_hip.h"\n#include <stdio.h>\nint main(){printf("%zu\\n", sizeof(scf_conv_desc));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, 't.c')
+        open(c, 'w').write(src)
+        exe = os.path.join(d, 't')
+        subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe], check=True)
+        size = int(subprocess.run([exe], capture_output=True, text=True, check=True).stdout)
+    assert size == ctypes.sizeof(_lib.ConvDesc)
+
+
+def test_ops_reject_cpu_tensors():
+    import torch
+    from scflow_amd import ops
+    with pytest.raises(_lib.ScflowHipError):
+        ops.corr_lookup([torch.zeros(4, 1, 2, 2)], torch.zeros(1, 2, 2, 2))

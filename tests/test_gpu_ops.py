@@ -1,0 +1,272 @@
+"""GPU: every C-ABI operator against the CPU oracle / plain torch fp32 on the
+same seeded inputs.  Tolerances are fp32 round-off (different summation order)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from scflow_amd import ops
+from scflow_amd.synthetic import make_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def close(got, want, atol, rtol=1e-5, what=''):
+    got = got.detach().cpu()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    err = (got - want).abs()
+    lim = atol + rtol * want.abs()
+    assert bool((err <= lim).all()), f'{what}: max err {float(err.max()):.3e} > atol {atol}'
+
+
+# ------------------------------------------------------------ correlation
+@pytest.mark.parametrize('n,c,h,w', [(2, 256, 8, 8), (1, 96, 12, 20), (1, 4, 16, 16),
+                                     (2, 256, 32, 32), (1, 6, 8, 8)])
+def test_corr_build(n, c, h, w):
+    f1, f2 = rnd((n, c, h, w), 1), rnd((n, c, h, w), 2)
+    want = oracle.correlation_pyramid(f1, f2, 4) if min(h, w) >= 8 else \
+        oracle.correlation_pyramid(f1, f2, 3)
+    got = ops.corr_build(f1.to(DEV), f2.to(DEV), len(want))
+    for g, wv in zip(got, want):
+        close(g, wv, atol=3e-5, what='corr level')
+
+
+def test_corr_build_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'corr_pyramid.npz'))
+    got = ops.corr_build(torch.from_numpy(g['feat1']).to(DEV), torch.from_numpy(g['feat2']).to(DEV), 4)
+    for i, lv in enumerate(got):
+        close(lv, torch.from_numpy(g[f'level{i}']), atol=3e-5, what=f'golden level{i}')
+
+
+@pytest.mark.parametrize('n,h,w,r,L', [(2, 16, 16, 4, 4), (1, 12, 20, 4, 3), (3, 32, 32, 4, 4),
+                                       (1, 16, 16, 3, 4), (1, 8, 24, 4, 2)])
+def test_corr_lookup(n, h, w, r, L):
+    f1, f2 = rnd((n, 32, h, w), 3), rnd((n, 32, h, w), 4)
+    pyr = oracle.correlation_pyramid(f1, f2, L)
+    flow = rnd((n, 2, h, w), 5, 3.0)
+    flow[0, :, 0, 0] = torch.tensor([-40., 3.])
+    flow[0, :, 0, 1] = 0.
+    flow[0, :, 1, 1] = torch.tensor([float(w), float(h)])
+    flow[0, :, 2, 2] = torch.tensor([1e9, -1e9])
+    want = oracle.corr_lookup(pyr, flow.clone(), r)
+    got = ops.corr_lookup([p.to(DEV) for p in pyr], flow.to(DEV), r)
+    close(got, want, atol=5e-5, what='lookup')
+
+
+def test_corr_lookup_golden_and_channel_order(golden_dir):
+    for name in ('corr_lookup.npz', 'corr_lookup_12x20.npz', 'corr_lookup_onehot.npz'):
+        g = np.load(os.path.join(golden_dir, name))
+        f1, f2 = torch.from_numpy(g['feat1']), torch.from_numpy(g['feat2'])
+        flow = torch.from_numpy(g['flow']) if 'flow' in g.files else torch.zeros((1, 2, 16, 16))
+        pyr = ops.corr_build(f1.to(DEV), f2.to(DEV), 4)
+        got = ops.corr_lookup(pyr, flow.to(DEV), 4)
+        close(got, torch.from_numpy(g['out']), atol=5e-5, what=name)
+    assert int(got[0, :81, 8, 8].argmax()) == 9 * 1 + 6      # x_off=-3 -> a=1, y_off=+2 -> b=6
+
+
+def test_lookup_of_constant_volume_is_partition_of_unity():
+    """size-independent property: a constant map sampled bilinearly gives the constant for
+    fully in-range windows and 0 far outside."""
+    n, h, w = 1, 32, 32
+    pyr = [torch.full((n * h * w, 1, h >> l, w >> l), 2.5, device=DEV) for l in range(4)]
+    flow = torch.zeros((n, 2, h, w), device=DEV)
+    out = ops.corr_lookup(pyr, flow, 4).cpu()
+    assert torch.allclose(out[0, :81, 16, 16], torch.full((81,), 2.5), atol=1e-6)
+    flow[:] = 1000.
+    assert float(ops.corr_lookup(pyr, flow, 4).abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------ conv
+CONV_CASES = [
+    # n, cin, cout, k, stride, pad, H, W
+    (2, 3, 64, (7, 7), 2, (3, 3), 64, 64),
+    (1, 64, 64, (3, 3), 1, (1, 1), 32, 32),
+    (2, 64, 96, (3, 3), 2, (1, 1), 32, 32),
+    (1, 64, 96, (1, 1), 2, (0, 0), 32, 32),
+    (1, 96, 128, (3, 3), 2, (1, 1), 16, 16),
+    (1, 128, 256, (1, 1), 1, (0, 0), 8, 8),
+    (2, 324, 256, (1, 1), 1, (0, 0), 8, 8),
+    (1, 256, 192, (3, 3), 1, (1, 1), 8, 8),
+    (2, 2, 128, (7, 7), 1, (3, 3), 8, 8),
+    (1, 256, 126, (3, 3), 1, (1, 1), 8, 8),
+    (1, 384, 128, (1, 5), 1, (0, 2), 8, 8),
+    (1, 384, 128, (5, 1), 1, (2, 0), 8, 8),
+    (1, 256, 2, (3, 3), 1, (1, 1), 8, 8),
+    (2, 1, 64, (3, 3), 1, (1, 1), 8, 8),
+    (3, 224, 128, (3, 3), 2, (1, 1), 32, 32),
+    (3, 128, 128, (3, 3), 2, (1, 1), 16, 16),
+    (3, 128, 128, (3, 3), 2, (1, 1), 8, 8),
+    (1, 16, 40, (3, 3), 1, (1, 1), 12, 20),
+    (1, 64, 64, (3, 3), 1, (1, 1), 128, 128),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d(case):
+    n, cin, cout, k, s, p, H, W = case
+    x = rnd((n, cin, H, W), 10)
+    wt = rnd((cout, cin, *k), 11, (1.0 / (cin * k[0] * k[1])) ** 0.5)
+    b = rnd((cout,), 12, 0.1)
+    want = torch.relu(F.conv2d(x, wt, b, stride=s, padding=p))
+    pc = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), stride=s, padding=p)
+    got = ops.conv2d(pc, x.to(DEV), act=ops.ACT_RELU)
+    close(got, want, atol=2e-5, what=str(case))
+
+
+def test_conv2d_two_segments_into_channel_slice():
+    n, h, w = 2, 16, 16
+    xa, xb = rnd((n, 192, h, w), 20), rnd((n, 64, h, w), 21)
+    wt = rnd((126, 256, 3, 3), 22, 0.02)
+    b = rnd((126,), 23, 0.1)
+    want = torch.relu(F.conv2d(torch.cat([xa, xb], 1), wt, b, padding=1))
+    pc = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), padding=1)
+    big = torch.full((n, 256, h, w), -7.0, device=DEV)
+    buf_a = torch.zeros((n, 200, h, w), device=DEV)
+    buf_a[:, 8:200] = xa.to(DEV)
+    ops.conv2d(pc, buf_a[:, 8:200], xb.to(DEV), out=big[:, 128:254], act=ops.ACT_RELU)
+    close(big[:, 128:254], want, atol=2e-5, what='slice')
+    assert float((big[:, :128] + 7.0).abs().max()) == 0.0 and float((big[:, 254:] + 7.0).abs().max()) == 0.0
+
+
+def test_conv2d_bn_residual_split_act():
+    n, c, h, w = 2, 64, 16, 16
+    x, res = rnd((n, c, h, w), 30), rnd((n, 96, h, w), 31)
+    wt, b = rnd((96, c, 3, 3), 32, 0.05), rnd((96,), 33, 0.1)
+    gamma, beta = 1 + 0.1 * rnd((96,), 34), 0.1 * rnd((96,), 35)
+    mean, var = 0.1 * rnd((96,), 36), 1 + 0.2 * rnd((96,), 37).abs()
+    y = F.batch_norm(F.conv2d(x, wt, b, padding=1), mean, var, gamma, beta, False, 0., 1e-5)
+    want = torch.relu(y + res)
+    pc = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), padding=1,
+                                    bn=[t.to(DEV) for t in (gamma, beta, mean, var)])
+    got = ops.conv2d(pc, x.to(DEV), res=res.to(DEV), act=ops.ACT_RELU)
+    close(got, want, atol=3e-5, what='bn+res')
+    # split activation: tanh on the first 32 channels, relu on the rest
+    pc2 = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), padding=1)
+    y2 = F.conv2d(x, wt, b, padding=1)
+    want2 = torch.cat([torch.tanh(y2[:, :32]), torch.relu(y2[:, 32:])], 1)
+    got2 = ops.conv2d(pc2, x.to(DEV), act=ops.ACT_TANH, act2=ops.ACT_RELU, act_split=32)
+    close(got2, want2, atol=2e-5, what='split act')
+
+
+def test_conv2d_gru_fusions():
+    """SepConvGRU pass (raft_decoder.py:235-253) via the fused ZR / Q epilogues."""
+    n, h, w = 2, 8, 8
+    hx = rnd((n, 384, h, w), 40)
+    hx[:, :128] = torch.tanh(hx[:, :128])
+    wz, wr, wq = (rnd((128, 384, 1, 5), s, 0.03) for s in (41, 42, 43))
+    bz, br, bq = (rnd((128,), s, 0.1) for s in (44, 45, 46))
+    hcur, x = hx[:, :128], hx[:, 128:]
+    z = torch.sigmoid(F.conv2d(hx, wz, bz, padding=(0, 2)))
+    r = torch.sigmoid(F.conv2d(hx, wr, br, padding=(0, 2)))
+    q = torch.tanh(F.conv2d(torch.cat([r * hcur, x], 1), wq, bq, padding=(0, 2)))
+    want = (1 - z) * hcur + z * q
+    pzr = ops.PackedConv.from_weight(torch.cat([wz, wr]).to(DEV), torch.cat([bz, br]).to(DEV),
+                                     padding=(0, 2))
+    pq = ops.PackedConv.from_weight(wq.to(DEV), bq.to(DEV), padding=(0, 2))
+    hxd = hx.to(DEV)
+    rh = torch.empty((n, 128, h, w), device=DEV)
+    zr_out = torch.empty((n, 128, h, w), device=DEV)
+    ops.conv2d(pzr, hxd, out=zr_out, mode=ops.CONV_GRU_ZR, gru_h=hxd[:, :128], gru_aux=rh)
+    close(zr_out, z, atol=2e-5, what='z')
+    close(rh, r * hcur, atol=2e-5, what='r*h')
+    ops.conv2d(pq, rh, hxd[:, 128:], out=hxd[:, :128], mode=ops.CONV_GRU_Q, gru_h=hxd[:, :128],
+               gru_z=zr_out)
+    close(hxd[:, :128], want, atol=3e-5, what='h_new')
+    close(hxd[:, 128:], x, atol=0, what='x untouched')
+
+
+# ----------------------------------------------------------- small kernels
+@pytest.mark.parametrize('hw', [(128, 128), (64, 64), (32, 32), (12, 20), (5, 7)])
+def test_instance_norm(hw):
+    x, res = rnd((2, 6, *hw), 50, 2.0) + 0.5, rnd((2, 6, *hw), 51)
+    close(ops.instance_norm(x.to(DEV), relu=True), torch.relu(F.instance_norm(x, eps=1e-5)),
+          atol=2e-5, what='in+relu')
+    close(ops.instance_norm(x.to(DEV)), F.instance_norm(x, eps=1e-5), atol=2e-5, what='in')
+    close(ops.instance_norm(x.to(DEV), res=res.to(DEV), relu=True),
+          torch.relu(F.instance_norm(x, eps=1e-5) + res), atol=2e-5, what='in+res+relu')
+
+
+@pytest.mark.parametrize('hw', [(16, 16), (8, 8), (4, 4)])
+def test_group_norm_relu(hw):
+    x = rnd((3, 128, *hw), 52, 1.5)
+    g, b = 1 + 0.1 * rnd((128,), 53), 0.1 * rnd((128,), 54)
+    close(ops.group_norm_relu(x.to(DEV), g.to(DEV), b.to(DEV), 32),
+          torch.relu(F.group_norm(x, 32, g, b, 1e-5)), atol=2e-5, what='gn')
+
+
+@pytest.mark.parametrize('n,k,o', [(3, 2048, 1024), (1, 1024, 256), (32, 256, 126), (5, 30, 7)])
+def test_linear(n, k, o):
+    x, wt, b = rnd((n, k), 55), rnd((o, k), 56, k ** -0.5), rnd((o,), 57, 0.1)
+    close(ops.linear(x.to(DEV), wt.to(DEV), b.to(DEV), ops.ACT_RELU), torch.relu(F.linear(x, wt, b)),
+          atol=2e-5, what='linear')
+
+
+def test_pose_update_and_label_quirk(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'pose_math.npz'))
+    n, nc = 3, 21
+    rot_all, tr_all = rnd((n, nc * 6), 60), rnd((n, nc * 3), 61, 0.05)
+    label = torch.tensor([2, 5, 7])
+    d_rot, d_tr = torch.from_numpy(g['d_rot']), torch.from_numpy(g['d_trans'])
+    for i in range(n):                                  # plant the golden deltas at class label[0]
+        rot_all.view(n, nc, 6)[i, 2] = d_rot[i]
+        tr_all.view(n, nc, 3)[i, 2] = d_tr[i]
+    R, t = torch.from_numpy(g['rot']), torch.from_numpy(g['trans'])
+    o = ops.pose_update(rot_all.to(DEV), tr_all.to(DEV), label.to(DEV), nc, R.to(DEV), t.to(DEV), 0)
+    close(o[0], d_rot, atol=0, what='d_rot select (reference quirk: label[0] for all)')
+    close(o[2], torch.from_numpy(g['rot_new']), atol=2e-6, what='R')
+    close(o[3], torch.from_numpy(g['trans_new']), atol=2e-4, what='t')
+    o1 = ops.pose_update(rot_all.to(DEV), tr_all.to(DEV), label.to(DEV), nc, R.to(DEV), t.to(DEV), 1)
+    want = rot_all.view(n, nc, 6)[torch.arange(n), label]
+    close(o1[0], want, atol=0, what='per-sample label mode')
+
+
+def test_reproject_and_unproject(golden_dir):
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, 'pose_math.npz')).items()
+         if v.dtype.kind == 'f'}
+    d = lambda k: g[k].to(DEV)
+    for inv, key in ((0., 'flow_inv0'), (400., 'flow_inv400')):
+        got = ops.reproject_flow(d('depth'), d('k'), d('rot'), d('trans'), d('rot_new'),
+                                 d('trans_new'), inv)
+        close(got, g[key], atol=2e-4, what=key)
+    pts = ops.unproject_depth(d('depth'), d('k'), d('rot'), d('trans')).cpu()
+    p2, p3 = oracle.unproject_depth(g['depth'][0], g['k'][0], g['rot'][0], g['trans'][0])
+    dense = pts[0][:, p2[:, 1].long(), p2[:, 0].long()].t()
+    close(dense, p3, atol=2e-3, what='pts3d')
+
+
+def test_reproject_full_size_matches_oracle():
+    inp = make_inputs(2, 256, 256, seed=3)
+    r, t = inp['ref_rotation'], inp['ref_translation'] + torch.tensor([1.5, -2.0, 10.0])
+    pts = [oracle.unproject_depth(inp['depth'][i], inp['internel_k'][i], inp['ref_rotation'][i],
+                                  inp['ref_translation'][i]) for i in range(2)]
+    want = oracle.flow_from_pose_and_points(r, t, inp['internel_k'], [a for a, _ in pts],
+                                            [b for _, b in pts], 256, 256, 0.)
+    got = ops.reproject_flow(inp['depth'].to(DEV), inp['internel_k'].to(DEV), r.to(DEV),
+                             inp['ref_translation'].to(DEV), r.to(DEV), t.to(DEV), 0.)
+    close(got, want, atol=5e-4, what='flow 256')
+
+
+@pytest.mark.parametrize('shape,out', [((2, 2, 256, 256), (32, 32)), ((2, 2, 32, 32), (256, 256)),
+                                       ((1, 1, 32, 32), (256, 256)), ((1, 3, 12, 20), (5, 9))])
+def test_resize_bilinear(shape, out):
+    a, b = rnd(shape, 70, 4.0), rnd(shape, 71)
+    want = 0.125 * F.interpolate(a + b, size=out, mode='bilinear', align_corners=True)
+    close(ops.resize_bilinear(a.to(DEV), out, 0.125, b.to(DEV)), want, atol=2e-6, what='resize')
+    want = F.interpolate(a, size=out, mode='bilinear', align_corners=True)
+    close(ops.resize_bilinear(a.to(DEV), out), want, atol=2e-6, what='resize')
+
+
+def test_avgpool_and_copy():
+    x = rnd((3, 5, 12, 20), 80)
+    close(ops.avgpool2x2(x.to(DEV)), F.avg_pool2d(x, 2, 2), atol=1e-6, what='pool')
+    dst = torch.zeros((3, 9, 12, 20), device=DEV)
+    ops.copy_channels(x.to(DEV), dst[:, 2:7])
+    close(dst[:, 2:7], x, atol=0, what='copy')

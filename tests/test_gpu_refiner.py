@@ -1,0 +1,152 @@
+"""GPU: module-level and end-to-end parity of the HIP refiner against (a) golden
+vectors generated from the reference's source files and (b) the CPU oracle on the same
+seeded inputs.  Stated tolerance (BASELINE.json north_star): flow EPE <= 1e-3 px."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import scflow_amd
+from scflow_amd import ops
+from scflow_amd.registry import ENCODERS, HEAD, build_from_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _g(golden_dir, name):
+    d = np.load(os.path.join(golden_dir, name))
+    return {k: (torch.from_numpy(d[k]) if d[k].dtype.kind in 'fi' and d[k].shape != () else d[k])
+            for k in d.files}
+
+
+def close(got, want, atol, rtol=1e-5, what=''):
+    got = got.detach().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = (got - want).abs()
+    assert bool((err <= atol + rtol * want.abs()).all()), \
+        f'{what}: max err {float(err.max()):.3e} > atol {atol}'
+
+
+def _shapes(golden_dir):
+    return json.load(open(os.path.join(golden_dir, 'state_dict_keys.json')))['shapes']
+
+
+@pytest.fixture(scope='module')
+def model(golden_dir):
+    m = scflow_amd.build_refiner(scflow_amd.scflow_model_cfg())
+    m.load_state_dict(scflow_amd.fill_state_dict(_shapes(golden_dir), seed=0), strict=True)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize('kind', ['IN', 'BN'])
+def test_encoder_golden(golden_dir, kind):
+    g = _g(golden_dir, f'encoder_{kind}.npz')
+    enc = build_from_cfg(dict(type='RAFTEncoder', in_channels=3, out_channels=256,
+                              net_type='Basic', norm_cfg=dict(type=kind)), ENCODERS)
+    pre = 'render_encoder.' if kind == 'IN' else 'context.'
+    sd = scflow_amd.fill_state_dict({k[len(pre):]: v for k, v in _shapes(golden_dir).items()
+                                     if k.startswith(pre)}, seed=3)
+    enc.load_state_dict(sd, strict=True)
+    enc = enc.to(DEV).eval()
+    close(enc(g['x'].to(DEV)), g['out'], atol=1e-4, what=f'encoder {kind}')
+
+
+def test_update_block_golden(golden_dir, model):
+    g = _g(golden_dir, 'update_block.npz')
+    shapes = {k: v for k, v in _shapes(golden_dir).items()
+              if k.startswith(('decoder.encoder.', 'decoder.gru.', 'decoder.flow_pred.',
+                               'decoder.mask_pred.'))}
+    sd = scflow_amd.fill_state_dict({k[len('decoder.'):]: v for k, v in shapes.items()}, seed=4)
+    dec = scflow_amd.build_decoder(scflow_amd.scflow_model_cfg()['decoder'])
+    dec.load_state_dict(sd, strict=False)
+    dec = dec.to(DEV)
+    corr, flow = g['corr'].to(DEV), g['flow'].to(DEV)
+    motion = dec.encoder(corr, flow)
+    close(motion, g['motion'], atol=3e-5, what='motion')
+    h_new = dec.gru(g['h'].to(DEV), torch.cat([g['cxt'].to(DEV), motion], 1))
+    close(h_new, g['h_new'], atol=3e-5, what='gru')
+    close(dec.flow_pred(h_new.contiguous()), g['d_flow'], atol=3e-5, what='flow head')
+    close(dec.mask_pred(h_new.contiguous()), g['mask_logit'], atol=3e-5, what='mask head')
+
+
+def test_pose_head_golden_label_quirk(golden_dir):
+    g = _g(golden_dir, 'pose_head.npz')
+    head = build_from_cfg(scflow_amd.scflow_model_cfg()['decoder']['pose_head_cfg'], HEAD)
+    sd = scflow_amd.fill_state_dict({k: v for k, v in _shapes(golden_dir).items()
+                                     if k.startswith('decoder.pose_pred.')}, seed=4)
+    head.load_state_dict({k[len('decoder.pose_pred.'):]: v for k, v in sd.items()}, strict=True)
+    head = head.to(DEV)
+    x = torch.randn((3, 224, 32, 32), generator=torch.Generator().manual_seed(int(g['x_seed'])))
+    r, t = head(x.to(DEV), g['label'].to(DEV))
+    close(r, g['rot'], atol=2e-5, what='rot (mixed labels -> label[0])')
+    close(t, g['trans'], atol=2e-5, what='trans')
+    r5, t5 = head(x.to(DEV), torch.tensor([5, 5, 5], device=DEV))
+    close(r5, g['rot_label5'], atol=2e-5, what='rot label 5')
+
+
+def test_full_refiner_golden(golden_dir, model):
+    """3 iterations, N=3 mixed labels, 256x256: against the reference's own output."""
+    g = _g(golden_dir, 'refiner_full.npz')
+    inp = {k: v.to(DEV) for k, v in scflow_amd.make_inputs(int(g['n']), 256, 256,
+                                                           seed=int(g['input_seed'])).items()}
+    fr, fl, hf, cf = model.extract_feat(inp['render_images'], inp['real_images'])
+    close(fr[:, ::8], g['feat_render'], atol=2e-4, what='feat_render')
+    close(fl[:, ::8], g['feat_real'], atol=2e-4, what='feat_real')
+    close(hf[:, ::8], g['h_feat'], atol=2e-4, what='h_feat')
+    close(cf[:, ::8], g['cxt_feat'], atol=2e-4, what='cxt_feat')
+    model.decoder.iters = int(g['iters'])
+    outs = model.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'],
+                          inp['ref_translation'], inp['depth'], inp['internel_k'], inp['label'])
+    names = ['flow_from_pose', 'flow_from_pred', 'rotation', 'translation', 'mask',
+             'delta_rotation', 'delta_translation']
+    tol = dict(flow_from_pose=1e-3, flow_from_pred=2e-3, rotation=1e-5, translation=5e-3,
+               mask=2e-4, delta_rotation=2e-5, delta_translation=2e-5)
+    for nm, seq in zip(names, outs):
+        assert len(seq) == int(g['iters'])
+        st = torch.stack(list(seq))
+        if st.dim() == 5:
+            st = st[..., ::4, ::4]
+        close(st, g[nm], atol=tol[nm], what=nm)
+
+
+@pytest.mark.parametrize('n,iters', [(1, 8), (2, 8)])
+def test_full_refiner_vs_oracle_epe(golden_dir, model, n, iters):
+    """BASELINE configs 1/2 shape: 256x256, 8 GRU iterations.  EPE <= 1e-3 px."""
+    sd = scflow_amd.fill_state_dict(_shapes(golden_dir), seed=0)
+    inp = scflow_amd.make_inputs(n, 256, 256, seed=11 + n)
+    with torch.no_grad():
+        want = oracle.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'],
+                               inp['ref_translation'], inp['depth'], inp['internel_k'],
+                               inp['label'], sd, iters=iters)
+    model.decoder.iters = iters
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    got = model.get_pose(d['render_images'], d['real_images'], d['ref_rotation'],
+                         d['ref_translation'], d['depth'], d['internel_k'], d['label'])
+    valid = inp['depth'] > 0
+    for it in range(iters):
+        epe_pose = oracle.end_point_error(got[0][it].cpu(), want[0][it], valid)
+        epe_pred = oracle.end_point_error(got[1][it].cpu(), want[1][it])
+        assert epe_pose <= 1e-3, f'iter {it}: EPE(flow_from_pose) {epe_pose:.2e}'
+        assert epe_pred <= 1e-3, f'iter {it}: EPE(flow_from_pred) {epe_pred:.2e}'
+    close(got[2][-1], want[2][-1], atol=2e-5, what='final rotation')
+    close(got[3][-1], want[3][-1], atol=1e-2, rtol=2e-5, what='final translation (mm)')
+    assert float((got[0][-1].cpu()[:, :, ~valid[0]] if n == 1 else torch.zeros(1)).abs().max()) == 0.0
+
+
+def test_forward_single_pass_api(golden_dir, model):
+    inp = {k: v.to(DEV) for k, v in scflow_amd.make_inputs(3, 256, 256, seed=2).items()}
+    data = dict(labels=inp['label'], ref_rotations=inp['ref_rotation'],
+                ref_translations=inp['ref_translation'], real_images=inp['real_images'],
+                rendered_images=inp['render_images'], internel_k=inp['internel_k'],
+                rendered_depths=inp['depth'], per_img_patch_num=[2, 1])
+    model.decoder.iters = 2
+    model.test_iter_num = 3
+    out = model(data, return_loss=False)
+    assert model.decoder.iters == 2                     # restored (scflow_refiner.py:154-162)
+    assert [len(r) for r in out['rotations']] == [2, 1]
+    assert out['rotations'][0].shape == (2, 3, 3) and out['translations'][1].shape == (1, 3)
+    model.test_iter_num = 8

@@ -1,0 +1,98 @@
+"""CPU: the host-side mirror of the reference interface -- registries, config
+compatibility, state_dict key layout, cache invalidation, weight packing."""
+import json
+import os
+import runpy
+
+import pytest
+import torch
+
+import scflow_amd
+from scflow_amd import ops
+from scflow_amd.registry import DECODERS, ENCODERS, HEAD, REFINERS, build_from_cfg
+
+
+def test_registries_hold_the_reference_class_names():
+    assert 'SCFlowRefiner' in REFINERS
+    assert 'RAFTEncoder' in ENCODERS
+    assert 'SCFlowDecoder' in DECODERS
+    assert 'MultiClassPoseHead' in HEAD
+    with pytest.raises(KeyError):
+        build_from_cfg(dict(type='Nope'), REFINERS)
+    with pytest.raises(KeyError):
+        build_from_cfg(dict(foo=1), REFINERS)
+
+
+def test_state_dict_layout_matches_reference(golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, 'state_dict_keys.json')))
+    model = scflow_amd.build_refiner(scflow_amd.scflow_model_cfg())
+    sd = model.state_dict()
+    assert len(sd) == ref['num_tensors'] == 226
+    assert {k: list(v.shape) for k, v in sd.items()} == ref['shapes']
+    uniq = sum(v.numel() for k, v in sd.items() if not k.startswith('real_encoder.'))
+    assert uniq == ref['num_params_unique']
+    # shared encoder: one module under two names (base_refiner.py:36-39)
+    assert model.real_encoder is model.render_encoder
+    sd2 = scflow_amd.fill_state_dict({k: v.shape for k, v in sd.items()}, seed=0)
+    model.load_state_dict(sd2, strict=True)
+
+
+def test_reference_config_file_builds_unchanged():
+    path = '/root/reference/configs/refine_models/scflow.py'
+    if not os.path.exists(path):
+        pytest.skip('reference checkout not present (GPU box)')
+    cfg = runpy.run_path(path)['model']
+    model = scflow_amd.build_refiner(cfg)
+    assert model.decoder.iters == 8 and model.test_iter_num == 8
+    assert model.decoder.corr_lookup.r == 4 and model.decoder.num_levels == 4
+    ours = scflow_amd.scflow_model_cfg()
+    for key in ('cxt_channels', 'h_channels', 'seperate_encoder', 'max_flow'):
+        assert ours[key] == cfg[key]
+    for key in ('net_type', 'num_levels', 'radius', 'iters', 'mask_flow', 'mask_corr',
+                'gru_type', 'pose_head_cfg'):
+        assert ours['decoder'][key] == cfg['decoder'][key], key
+
+
+def test_pose_head_zero_init_like_reference():
+    head = build_from_cfg(scflow_amd.scflow_model_cfg()['decoder']['pose_head_cfg'], HEAD)
+    assert float(head.translation_pred.weight.abs().max()) == 0.0
+    assert float(head.rotation_pred.weight.abs().max()) == 0.0
+    assert head.rotation_pred.bias[:6].tolist() == [1., 0., 0., 0., 1., 0.]
+
+
+def test_pack_conv_weight_layout():
+    w = torch.arange(5 * 3 * 2 * 2, dtype=torch.float32).reshape(5, 3, 2, 2)
+    wp, mld = ops.pack_conv_weight(w, kc=2)
+    assert mld == 32 and wp.shape == (2 * 4 * 2, 32)         # 2 chunks x 4 taps x KC=2
+    for co in range(5):
+        for ci in range(3):
+            for t in range(4):
+                row = ((ci // 2) * 4 + t) * 2 + ci % 2
+                assert wp[row, co] == w[co, ci, t // 2, t % 2]
+    assert float(wp[:, 5:].abs().max()) == 0.0
+    pad_rows = [((1 * 4 + t) * 2 + 1) for t in range(4)]      # channel 3 does not exist
+    assert float(wp[pad_rows].abs().max()) == 0.0
+    assert ops.choose_kc(3, 7, 7) == 2 and ops.choose_kc(64, 3, 3) == 8 and ops.choose_kc(2, 7, 7) == 2
+
+
+def test_packed_cache_invalidation():
+    enc = build_from_cfg(scflow_amd.scflow_model_cfg()['encoder'], ENCODERS)
+    p1 = enc.packed
+    assert enc.packed is p1
+    enc.load_state_dict(enc.state_dict())
+    assert enc.__dict__['_packed'] is None
+    blk = enc.res_layer1[0]
+    _ = blk.packed
+    enc.float()                                  # any _apply drops caches of all submodules
+    assert blk.__dict__['_packed'] is None
+
+
+def test_unsupported_options_fail_loudly():
+    cfg = scflow_amd.scflow_model_cfg()
+    cfg['decoder']['mask_corr'] = True
+    with pytest.raises(NotImplementedError):
+        scflow_amd.build_refiner(cfg)
+    model = scflow_amd.build_refiner(scflow_amd.scflow_model_cfg())
+    x = torch.zeros(1, 3, 64, 64)
+    with pytest.raises(scflow_amd._lib.ScflowHipError):
+        model.extract_feat(x, x)               # CPU tensors: no fallback
