@@ -24,6 +24,7 @@
 #include "scf_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvK {
   const float* in0; const float* in1;
@@ -71,11 +72,17 @@ __device__ __forceinline__ void mfma_taps(f32x16 (&acc)[WM][WN], const float* wl
   }
 }
 
+// per-thread prefetch registers by channel-chunk size: PU patch floats, WU weight float4
+__host__ __device__ constexpr int pu_max(int kc) { return kc == 32 ? 16 : kc == 8 ? 20 : 12; }
+__host__ __device__ constexpr int wu_max(int kc) { return kc == 32 ? 4 : kc == 8 ? 9 : 13; }
+
 template <int WM, int WN, int KC>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = WM * 32;
+  constexpr int B4 = BM / 4;
   constexpr int NFRAG = WN * 4;
+  constexpr int PU_MAX = pu_max(KC), WU_MAX = wu_max(KC);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l32 = lane & 31, half = lane >> 5;
@@ -112,51 +119,93 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const long long HWin = (long long)p.H * p.W;
+  const int HWin = p.H * p.W;
   const float* in0n = p.in0 + (long long)n * p.in0_ns;
   const float* in1n = p.in1 ? p.in1 + (long long)n * p.in1_ns : nullptr;
   const float* wpn = p.wp + (long long)n * p.w_ns;
   const int rows = KC * T;
+  const int PE = KC * PHW;      // patch elements per chunk
+  const int WE = rows * B4;     // weight float4 per chunk
 
-  for (int chunk = 0; chunk < p.nchunk; ++chunk) {
-    __syncthreads();
-    // ---- stage the input window (zero padded) ----
-    const int c0 = chunk * KC;
-    for (int row = wave; row < KC * PH; row += 4) {
-      const int cl = row / PH, py = row - cl * PH;
-      const int cg = c0 + cl, iy = iy0 + py;
-      const bool rok = cg < p.Cin && iy >= 0 && iy < p.H;
-      const float* src = nullptr;
-      if (rok) src = (cg < p.C0 ? in0n + cg * HWin : in1n + (cg - p.C0) * HWin) + (long long)iy * p.W;
-      float* dst = pl + row * PW;
-      for (int px = lane; px < PW; px += 64) {
-        const int ix = ix0 + px;
+  // Gather table: element e = tid + 256*u of the staged window [KC][PH][PW] lives at offset
+  // toff[u] (floats) from the chunk's first channel plane, or is zero padding (-1).  The
+  // mapping is chunk-invariant, so the two integer divisions are paid once per block.
+  int toff[PU_MAX];
+#pragma unroll
+  for (int u = 0; u < PU_MAX; ++u) {
+    const int e = tid + u * 256;
+    int o = -1;
+    if (e < PE) {
+      const int cl = e / PHW, r = e - cl * PHW;
+      const int py = r / PW, px = r - py * PW;
+      const int iy = iy0 + py, ix = ix0 + px;
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) o = cl * HWin + iy * p.W + ix;
+    }
+    toff[u] = o;
+  }
+
+  // Software pipeline (issue-early / write-late): the global loads of chunk c+1 are issued
+  // into registers BEFORE the MFMA phase of chunk c and written to LDS after it, so HBM/L2
+  // latency hides under ~KC*T/2*WM*WN MFMAs even when only one block is resident per CU.
+  float preg[PU_MAX];
+  f32x4 wreg[WU_MAX];
+  bool wfast = false;
+  const float* wsrc = nullptr;
+  long long krow0 = 0;
+
+  for (int chunk = -1; chunk < p.nchunk; ++chunk) {
+    if (chunk >= 0) {
+      __syncthreads();                     // every wave is done reading the previous chunk
+#pragma unroll
+      for (int u = 0; u < PU_MAX; ++u) {
+        const int e = tid + u * 256;
+        if (e < PE) pl[e] = preg[u];
+      }
+      if (wfast) {
+#pragma unroll
+        for (int u = 0; u < WU_MAX; ++u) {
+          const int e = tid + u * 256;
+          if (e < WE) *reinterpret_cast<f32x4*>(wl + e * 4) = wreg[u];
+        }
+      } else {                              // ragged edge (partial M block / K tail / unaligned)
+        for (int e = tid; e < rows * BM; e += 256) {
+          const int r = e / BM, c = e - r * BM;
+          float v = 0.f;
+          if (m0 + c < p.Mld && krow0 + r < p.Krows) v = wsrc[(long long)r * p.Mld + c];
+          wl[e] = v;
+        }
+      }
+      __syncthreads();
+    }
+    if (chunk + 1 < p.nchunk) {            // issue the next chunk's loads (registers)
+      const int c0 = (chunk + 1) * KC;
+      const float* base;
+      int nvalid;
+      if (c0 < p.C0) { base = in0n + (long long)c0 * HWin; nvalid = p.C0 - c0; }
+      else { base = in1n + (long long)(c0 - p.C0) * HWin; nvalid = p.Cin - c0; }
+      const unsigned limit = (unsigned)(nvalid < KC ? nvalid : KC) * (unsigned)HWin;
+#pragma unroll
+      for (int u = 0; u < PU_MAX; ++u) {
         float v = 0.f;
-        if (rok && ix >= 0 && ix < p.W) v = src[ix];
-        dst[px] = v;
+        if ((unsigned)toff[u] < limit) v = base[toff[u]];
+        preg[u] = v;
+      }
+      krow0 = (long long)(chunk + 1) * rows;
+      wsrc = wpn + krow0 * p.Mld + m0;
+      wfast = p.wvec && (m0 + BM <= p.Mld) && (krow0 + rows <= p.Krows);
+      if (wfast) {
+#pragma unroll
+        for (int u = 0; u < WU_MAX; ++u) {
+          const int e = tid + u * 256;
+          if (e < WE) {
+            const int r = e / B4, c4 = e - r * B4;
+            wreg[u] = *reinterpret_cast<const f32x4*>(wsrc + (long long)r * p.Mld + c4 * 4);
+          }
+        }
       }
     }
-    // ---- stage the weight rows of this chunk ----
-    const long long krow0 = (long long)chunk * rows;
-    const float* wsrc = wpn + krow0 * p.Mld + m0;
-    if (p.wvec && m0 + BM <= p.Mld && krow0 + rows <= p.Krows) {
-      constexpr int B4 = BM / 4;
-      for (int e = tid; e < rows * B4; e += 256) {
-        const int r = e / B4, c4 = e - r * B4;
-        *reinterpret_cast<float4*>(wl + r * BM + c4 * 4) =
-            *reinterpret_cast<const float4*>(wsrc + (long long)r * p.Mld + c4 * 4);
-      }
-    } else {
-      for (int e = tid; e < rows * BM; e += 256) {
-        const int r = e / BM, c = e - r * BM;
-        float v = 0.f;
-        if (m0 + c < p.Mld && krow0 + r < p.Krows) v = wsrc[(long long)r * p.Mld + c];
-        wl[e] = v;
-      }
-    }
-    __syncthreads();
-    // ---- MFMA phase ----
-    mfma_taps<WM, WN, KC / 2>(acc, wl, pl, boff, T, p.KW, KC, BM, PW, PHW, half, l32);
+    if (chunk >= 0)
+      mfma_taps<WM, WN, KC / 2>(acc, wl, pl, boff, T, p.KW, KC, BM, PW, PHW, half, l32);
   }
 
   // ---- epilogue: C/D layout col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*half ----
@@ -205,7 +254,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
 
 template <int WM, int WN>
 static int launch_conv(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
-  if (k.KC == 8)
+  if (k.KC == 32)
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, 32>), dim3(nblk), dim3(256), lds_bytes, st, k);
+  else if (k.KC == 8)
     hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, 8>), dim3(nblk), dim3(256), lds_bytes, st, k);
   else
     hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, 2>), dim3(nblk), dim3(256), lds_bytes, st, k);
@@ -223,7 +274,8 @@ extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
   if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C0 <= 0 || d->C1 < 0 || d->Cout <= 0) return SCF_EINVAL;
   if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->pad_h < 0 || d->pad_w < 0) return SCF_EINVAL;
   if (d->C1 > 0 && !d->in1) return SCF_EINVAL;
-  if (d->KC != 2 && d->KC != 8) return SCF_EUNSUPPORTED;
+  if (d->KC != 2 && d->KC != 8 && d->KC != 32) return SCF_EUNSUPPORTED;
+  if (d->C1 > 0 && (d->C0 % d->KC) != 0) return SCF_EUNSUPPORTED;  // a chunk never straddles segments
   if (d->Mld < d->Cout) return SCF_EINVAL;
   if (d->mode == SCF_CONV_GRU_ZR && (!d->gru_h || !d->gru_aux || (d->Cout & 1))) return SCF_EINVAL;
   if (d->mode == SCF_CONV_GRU_Q && (!d->gru_h || !d->gru_z)) return SCF_EINVAL;
@@ -260,32 +312,40 @@ extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
   k.fc_log2 = fl;
   const int FR = 32 / FC;
 
-  // tile shape selection
+  // ---- tile shape selection -------------------------------------------------------------
+  // WM channel fragments x WN pixel fragments per wave (<= 4 accumulators = 64 VGPRs).  Start
+  // from the largest tile and shrink WM while the grid would leave CUs idle (< 2 blocks per
+  // CU); use the double-width pixel tile only when the grid is large anyway.  Every choice
+  // must fit the per-thread prefetch registers and 64 KiB of LDS.
   const int frags_m = (k.Cout + 31) / 32;
-  int WM;
-  if (frags_m <= 4) WM = frags_m;
-  else if (frags_m % 4 == 0) WM = 4;
-  else if (frags_m % 3 == 0) WM = 3;
-  else WM = 4;
-  k.mblocks = (frags_m + WM - 1) / WM;
-  auto ntiles = [&](int WN) {
+  auto tiles = [&](int WN) {
     const int TR = WN * 4 * FR;
     return (long long)d->N * ((k.Ho + TR - 1) / TR) * ((k.Wo + FC - 1) / FC);
   };
-  // at most 4 accumulator fragments (64 VGPRs) per wave: WN = 2 only for WM <= 2
-  int WN = (WM <= 2 && ntiles(2) * k.mblocks >= 512) ? 2 : 1;
+  auto fits = [&](int WM, int WN, size_t* lds_out) {
+    const int TR = WN * 4 * FR;
+    const int PH = (TR - 1) * k.stride + k.KH, PW = (FC - 1) * k.stride + k.KW;
+    const long long PE = (long long)k.KC * PH * PW, WE = (long long)k.KC * k.T * WM * 8;
+    const size_t lds = ((size_t)k.KC * k.T * WM * 32 + (size_t)PE) * sizeof(float);
+    if (lds_out) *lds_out = lds;
+    return (PE + 255) / 256 <= pu_max(k.KC) && (WE + 255) / 256 <= wu_max(k.KC) && lds <= 64 * 1024;
+  };
+  int WM = frags_m >= 4 ? ((frags_m % 4 == 0 || frags_m % 3 != 0) ? 4 : 3) : frags_m;
+  int WN = 1;
+  auto nblocks = [&](int wm, int wn) { return tiles(wn) * ((frags_m + wm - 1) / wm); };
+  while (WM > 1 && (nblocks(WM, 1) < 512 || !fits(WM, 1, nullptr))) {
+    int next = WM - 1;
+    while (next > 1 && frags_m % next != 0) --next;
+    WM = next;
+  }
+  if (WM <= 2 && nblocks(WM, 2) >= 2048 && fits(WM, 2, nullptr)) WN = 2;
   size_t lds_bytes = 0;
-  for (;;) {
+  if (!fits(WM, WN, &lds_bytes)) return SCF_EUNSUPPORTED;
+  k.mblocks = (frags_m + WM - 1) / WM;
+  {
     const int TR = WN * 4 * FR;
     k.PH = (TR - 1) * k.stride + k.KH;
     k.PW = (FC - 1) * k.stride + k.KW;
-    lds_bytes = ((size_t)k.KC * k.T * WM * 32 + (size_t)k.KC * k.PH * k.PW) * sizeof(float);
-    if (lds_bytes <= 64 * 1024 || WN == 1) break;
-    WN = 1;
-  }
-  if (lds_bytes > 64 * 1024) return SCF_EUNSUPPORTED;
-  {
-    const int TR = WN * 4 * FR;
     k.tiles_y = (k.Ho + TR - 1) / TR;
     k.tiles_x = (k.Wo + FC - 1) / FC;
   }
@@ -316,7 +376,7 @@ extern "C" int scf_corr_build(const float* feat1, const float* feat2, float* con
   d.N = N; d.H = h; d.W = w;
   d.wp = feat1; d.w_nstride = (int64_t)C * hw; d.Mld = hw; d.Cout = hw;
   d.KH = d.KW = 1; d.stride = 1; d.pad_h = d.pad_w = 0;
-  d.KC = (C % 8 == 0) ? 8 : 2;
+  d.KC = (C % 32 == 0) ? 32 : (C % 8 == 0) ? 8 : 2;
   d.out = levels[0]; d.out_nstride = (int64_t)hw * hw;
   d.out_div = sqrtf((float)C);
   d.act = SCF_ACT_NONE; d.mode = SCF_CONV_PLAIN;

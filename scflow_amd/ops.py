@@ -70,9 +70,15 @@ def _opt(t: Optional[Tensor], name: str) -> Optional[int]:
 
 
 # ------------------------------------------------------------------ conv
-def choose_kc(cin: int, kh: int, kw: int) -> int:
-    """channel chunk staged per LDS round: 8, or 2 for thin inputs / wide kernels."""
-    return 2 if (cin < 8 or kh * kw >= 25) else 8
+def choose_kc(cin: int, kh: int, kw: int, stride: int = 1) -> int:
+    """channels staged per LDS round (scf_conv2d accepts 2, 8, 32): 32 for dense 1x1
+    (a chunk must carry enough MFMA work to amortise its barriers), 2 for thin inputs or
+    wide kernels (LDS / prefetch-register budget), else 8."""
+    if cin < 8 or kh * kw >= 25:
+        return 2
+    if kh * kw == 1 and stride == 1 and cin >= 32:
+        return 32
+    return 8
 
 
 def pack_conv_weight(weight: Tensor, kc: int) -> Tuple[Tensor, int]:
@@ -115,7 +121,7 @@ class PackedConv:
         """``bn`` = (gamma, beta, running_mean, running_var): eval-mode BatchNorm
         folded into a per-channel scale/shift applied after the bias."""
         cout, cin, kh, kw = weight.shape
-        kc = choose_kc(cin, kh, kw)
+        kc = choose_kc(cin, kh, kw, stride)
         wp, mld = pack_conv_weight(weight, kc)
         ph, pw = (padding, padding) if isinstance(padding, int) else padding
         scale = shift = None
@@ -218,9 +224,32 @@ def corr_lookup(pyramid: Sequence[Tensor], flow: Tensor, radius: int = 4,
     if out is None:
         out = torch.empty((n, k, h, w), dtype=torch.float32, device=flow.device)
     arr = (C.c_void_p * L)(*[_dense(t, 'level') for t in pyramid])
+    ev = None
+    if _LOOKUP_EVENTS is not None:      # bench.py: per-launch HIP events on the launch stream
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     _lib.check(_lib.load().scf_corr_lookup(arr, pf, _dense(out, 'out'), n, h, w, radius, L,
                                            _stream()), 'scf_corr_lookup')
+    if ev is not None:
+        ev[1].record()
+        _LOOKUP_EVENTS.append(ev)
     return out
+
+
+_LOOKUP_EVENTS = None
+
+
+def lookup_timing(enable: bool):
+    """enable=True: start bracketing every corr-lookup launch with a pair of events recorded
+    on the stream it is launched on.  enable=False: stop, synchronise and return the
+    per-launch durations in microseconds."""
+    global _LOOKUP_EVENTS
+    if enable:
+        _LOOKUP_EVENTS = []
+        return None
+    evs, _LOOKUP_EVENTS = _LOOKUP_EVENTS or [], None
+    torch.cuda.synchronize()
+    return [a.elapsed_time(b) * 1e3 for a, b in evs]
 
 
 # ------------------------------------------------------------- norms etc.

@@ -73,6 +73,7 @@ def test_pack_conv_weight_layout():
     pad_rows = [((1 * 4 + t) * 2 + 1) for t in range(4)]      # channel 3 does not exist
     assert float(wp[pad_rows].abs().max()) == 0.0
     assert ops.choose_kc(3, 7, 7) == 2 and ops.choose_kc(64, 3, 3) == 8 and ops.choose_kc(2, 7, 7) == 2
+    assert ops.choose_kc(324, 1, 1) == 32 and ops.choose_kc(64, 1, 1, 2) == 8
 
 
 def test_packed_cache_invalidation():
