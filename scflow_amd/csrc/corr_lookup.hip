@@ -39,9 +39,11 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(LookupParams p) {
   constexpr int FSP = FS | 1;         // odd LDS stride per query
   constexpr int D = 2 * R + 1;        // window width
   constexpr int QB = 32;              // queries per block
+  constexpr int NSET = (FS + 63) / 64;  // wave-loads per query footprint
   __shared__ float fp[4][QB * FSP];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
   const int l32 = lane & 31, half = lane >> 5;
   const long long gq0 = (long long)blockIdx.x * QB;
   const int hw = p.h * p.w;
@@ -62,10 +64,19 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(LookupParams p) {
   }
   float* myfp = fp[wave];
 
+  // footprint element(s) this lane fetches for EVERY query: e = lane + 64*s
+  int erow[NSET], ecol[NSET];
+#pragma unroll
+  for (int s = 0; s < NSET; ++s) {
+    const int e = lane + 64 * s;
+    erow[s] = e / FW;
+    ecol[s] = e - erow[s] * FW;
+  }
+  const int nq = (int)((p.total_q - gq0) < QB ? (p.total_q - gq0) : QB);   // block-uniform
+
   for (int lvl = wave; lvl < p.L; lvl += 4) {
     const int lh = p.lh[lvl], lw = p.lw[lvl];
     const long long msz = (long long)lh * lw;
-    const float* base = p.lvl[lvl];
     // Reference quirk at degenerate sizes: coordinates are normalised with max(size-1, 1) and
     // grid_sample(align_corners=True) de-normalises with (size-1), so along a size-1 axis
     // EVERY tap lands exactly on index 0 (corr_lookup.py:64-67).
@@ -79,28 +90,47 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(LookupParams p) {
     if (!(cy == cy)) cy = -30000.f;
     const float x0f = floorf(cx), y0f = floorf(cy);
     const int x0 = (int)x0f - R, y0 = (int)y0f - R;
-    const int packed = (x0 & 0xffff) | (y0 << 16);
 
-
-    // ---- load phase: 32*FS footprint elements, 64 per wave-instruction ----
-    constexpr int NIT = (QB * FS + 63) / 64;
-#pragma unroll 10
-    for (int it = 0; it < NIT; ++it) {
-      const int e = it * 64 + lane;
-      const int qq = e / FS;
-      const int rem = e - qq * FS;
-      const int row = rem / FW, col = rem - row * FW;
-      const int pk = __shfl(packed, qq & 31);
-      const int xx = flat_x ? 0 : (int)(short)(pk & 0xffff) + col;
-      const int yy = flat_y ? 0 : (pk >> 16) + row;
-      const bool ok = (qq < QB) && (gq0 + qq < p.total_q) && xx >= 0 && xx < lw && yy >= 0 && yy < lh;
-      float v = 0.f;
-      if (ok) v = base[(gq0 + qq) * msz + (long long)yy * lw + xx];
-      if (qq < QB) myfp[qq * FSP + rem] = v;
+    // ---- load phase: one query per step, lanes <-> footprint elements.  x0/y0 and the map
+    //      base are wave-uniform per step (scalar registers); per lane only a bounds test and
+    //      a 32-bit offset remain.  8 queries (8*NSET loads) are in flight per wave.
+    const float* lbase = p.lvl[lvl] + gq0 * msz;
+    constexpr int QU = 8;             // queries whose loads are in flight together
+    for (int qb = 0; qb < QB; qb += QU) {
+      float v[QU][NSET];
+      unsigned okmask = 0;
+      // branch-free: out-of-map / out-of-range taps read element 0 of a valid map and are
+      // zeroed afterwards, so all QU*NSET loads issue back to back.
+#pragma unroll
+      for (int u = 0; u < QU; ++u) {
+        const int qq = qb + u;
+        const int sx0 = flat_x ? 0 : __builtin_amdgcn_readlane(x0, qq);
+        const int sy0 = flat_y ? 0 : __builtin_amdgcn_readlane(y0, qq);
+        const bool qok = qq < nq;
+        const float* mb = lbase + (qok ? (long long)qq * msz : 0);
+#pragma unroll
+        for (int s = 0; s < NSET; ++s) {
+          const int xx = flat_x ? 0 : sx0 + ecol[s];
+          const int yy = flat_y ? 0 : sy0 + erow[s];
+          const bool ok = qok && (unsigned)xx < (unsigned)lw && (unsigned)yy < (unsigned)lh &&
+                          (NSET * 64 == FS || lane + 64 * s < FS);
+          const int idx = ok ? yy * lw + xx : 0;
+          v[u][s] = mb[idx];
+          okmask |= (ok ? 1u : 0u) << (u * NSET + s);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < QU; ++u) {
+#pragma unroll
+        for (int s = 0; s < NSET; ++s) {
+          const float val = ((okmask >> (u * NSET + s)) & 1u) ? v[u][s] : 0.f;
+          if (NSET * 64 == FS || lane + 64 * s < FS) myfp[(qb + u) * FSP + lane + 64 * s] = val;
+        }
+      }
     }
     __builtin_amdgcn_wave_barrier();  // same-wave LDS ops complete in order
 
-    // ---- compute + store ----
+    // ---- compute + store: lane = (query, half); halves split the x-offsets ----
     const float tx = cx - x0f, ty = cy - y0f;
     const float wx0 = (x0f + 1.f) - cx, wy0 = (y0f + 1.f) - cy;   // grid_sample: (x_se - x)
     const float nw = wx0 * wy0, ne = tx * wy0, sw = wx0 * ty, se = tx * ty;
@@ -110,15 +140,17 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(LookupParams p) {
     float colA[FW], colB[FW];
 #pragma unroll
     for (int r = 0; r < FW; ++r) colA[r] = f[r * FW + i0];
-    float* o = p.out + ((long long)n * ktot + (long long)lvl * D * D) * hw + q;
+    // uniform channel base + per-lane query offset: the compiler keeps the base in SGPRs
+    float* obase = p.out + ((long long)n * ktot + (long long)lvl * D * D) * hw + q;
     for (int i = i0; i < i1; ++i) {
 #pragma unroll
       for (int r = 0; r < FW; ++r) colB[r] = f[r * FW + i + 1];
       if (qvalid) {
+        float* oc = obase + (long long)(i * D) * hw;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
           const float v = colA[j] * nw + colB[j] * ne + colA[j + 1] * sw + colB[j + 1] * se;
-          o[(long long)(i * D + j) * hw] = v;
+          oc[(long long)j * hw] = v;
         }
       }
 #pragma unroll
