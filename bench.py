@@ -180,6 +180,7 @@ def main():
 
     # ---- config[1]: single pair latency (rank 0, informational) ----
     if rank == 0 and world == 1 and not args.no_batch1:
+        from scflow_amd.graph import GraphedRefiner
         b1 = make_batch(1, seed=5, device=device)
         for _ in range(3):
             run_step(model, b1)
@@ -189,9 +190,21 @@ def main():
         for _ in range(n1):
             run_step(model, b1)
         torch.cuda.synchronize()
+        ms_eager = (time.perf_counter() - t1) / n1 * 1e3
+        graphed = GraphedRefiner(model, b1)          # whole pass as one hipGraph
+        for _ in range(3):
+            graphed(b1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n1 = 30
+        for _ in range(n1):
+            graphed(b1)
+        torch.cuda.synchronize()
         ms = (time.perf_counter() - t1) / n1 * 1e3
         result['batch1'] = {'workload': 'BASELINE configs[1]: batch=1, 256x256, 8 iters',
-                            'ms_per_pair': round(ms, 3), 'pairs_per_s': round(1e3 / ms, 2)}
+                            'ms_per_pair_hipgraph': round(ms, 3),
+                            'pairs_per_s_hipgraph': round(1e3 / ms, 2),
+                            'ms_per_pair_eager': round(ms_eager, 3)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(sd, args.iters)

@@ -150,3 +150,21 @@ def test_forward_single_pass_api(golden_dir, model):
     assert [len(r) for r in out['rotations']] == [2, 1]
     assert out['rotations'][0].shape == (2, 3, 3) and out['translations'][1].shape == (1, 3)
     model.test_iter_num = 8
+
+
+def test_hipgraph_replay_matches_eager(golden_dir, model):
+    """the captured pass must reproduce eager results bit for bit, also on new inputs."""
+    from scflow_amd.graph import GraphedRefiner
+    model.decoder.iters = 3
+    a = {k: v.to(DEV) for k, v in scflow_amd.make_inputs(2, 256, 256, seed=21).items()}
+    b = {k: v.to(DEV) for k, v in scflow_amd.make_inputs(2, 256, 256, seed=22).items()}
+    g = GraphedRefiner(model, a)
+    for inp in (a, b, a):
+        want = model.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'],
+                              inp['ref_translation'], inp['depth'], inp['internel_k'], inp['label'])
+        got = g(inp)
+        torch.cuda.synchronize()
+        for ws, gs in zip(want, got):
+            for wt, gt in zip(ws, gs):
+                assert torch.equal(wt, gt)
+    model.decoder.iters = 8
