@@ -105,12 +105,16 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=32, help='image pairs per GPU per step')
     ap.add_argument('--iters', type=int, default=8)
+    ap.add_argument('--precision', choices=['f32', 'f16x3'], default='f32',
+                    help='convolution arithmetic: exact fp32 MFMA, or split-fp16 3xMFMA '
+                         '(fp32 accumulate, ~22 mantissa bits; see DESIGN.md)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-batch1', action='store_true')
     args = ap.parse_args()
 
     from scflow_amd import ops
     from scflow_amd.dist import gather_poses, init_from_env
+    ops.set_conv_precision(args.precision)
     rank, world, local = init_from_env()
     if world != args.gpus:
         if rank == 0:

@@ -95,7 +95,7 @@ typedef struct scf_conv_desc {
   int32_t Mld;                          /* packed row stride                           */
   int32_t Cout;
   int32_t KH, KW, stride, pad_h, pad_w;
-  int32_t KC;                           /* channel chunk used at packing time (2 or 8)  */
+  int32_t KC;                           /* channel chunk used at packing time (2, 8, 32) */
   float* out; int64_t out_nstride;
   const float* bias;                    /* [Cout] or NULL                              */
   const float* scale; const float* shift; /* [Cout] each or both NULL (BN eval)        */
@@ -107,9 +107,16 @@ typedef struct scf_conv_desc {
   const float* gru_h; int64_t gru_h_nstride; /* hidden state (ZR, Q)                   */
   float* gru_aux; int64_t gru_aux_nstride;   /* ZR: r*h destination                    */
   const float* gru_z; int64_t gru_z_nstride; /* Q: z                                   */
+  const void* wp_f16;                   /* optional split-fp16 packing of the same weights:
+                                           [(chunk16*T + tap)*2 + k8][plane hi|lo][Mld][8] halves;
+                                           non-NULL selects the 3xMFMA fp16 kernel where the
+                                           shape fits (fp32-class accuracy)   */
 } scf_conv_desc;
 
 int scf_conv2d(const scf_conv_desc* desc, scf_stream_t stream);
+/* dry run of scf_conv2d's tile selection: info[4] = {WM, WN, grid blocks, MFMAs per wave per
+ * staged chunk}; SCF_EUNSUPPORTED when the packing's KC does not fit this shape.         */
+int scf_conv2d_query(const scf_conv_desc* desc, int32_t* info);
 
 /* ---------------------------------------------------------------------------------
  * InstanceNorm2d(eps, affine=False) [+ residual] [+ ReLU] over N*C planes of HW floats.

@@ -5,7 +5,8 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['capi.hip', 'corr_lookup.hip', 'conv_mfma.hip', 'resample.hip', 'pose.hip', 'norm.hip']
+SOURCES = ['capi.hip', 'corr_lookup.hip', 'conv_mfma.hip', 'conv_f16x3.hip', 'resample.hip', 'pose.hip',
+           'norm.hip']
 OUT = os.path.join(HERE, 'libscflow_hip.so')
 
 
@@ -14,7 +15,7 @@ def needs_build() -> bool:
         return True
     t = os.path.getmtime(OUT)
     deps = [os.path.join(HERE, s) for s in SOURCES] + [
-        os.path.join(HERE, 'scf_common.h'),
+        os.path.join(HERE, 'scf_common.h'), os.path.join(HERE, 'conv_kernels.h'),
         os.path.join(HERE, '..', '..', 'include', 'scflow_hip.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 

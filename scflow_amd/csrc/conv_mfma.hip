@@ -26,25 +26,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct ConvK {
-  const float* in0; const float* in1;
-  int C0, Cin;
-  long long in0_ns, in1_ns;
-  int H, W, Ho, Wo;
-  const float* wp; long long w_ns;
-  int Mld, Cout, Krows;
-  int KH, KW, T, stride, pad_h, pad_w, KC, nchunk;
-  int fc_log2, tiles_x, tiles_y, mblocks, PH, PW;
-  int wvec;
-  float* out; long long out_ns;
-  const float* bias; const float* scale; const float* shift;
-  const float* res; long long res_ns;
-  float out_div;
-  int act, act2, act_split, mode;
-  const float* gru_h; long long gru_h_ns;
-  float* gru_aux; long long gru_aux_ns;
-  const float* gru_z; long long gru_z_ns;
-};
+#include "conv_kernels.h"
 
 // all taps of one staged channel chunk: NCP = KC/2 k-steps (channel pairs) per tap
 template <int WM, int WN, int NCP>
@@ -73,8 +55,8 @@ __device__ __forceinline__ void mfma_taps(f32x16 (&acc)[WM][WN], const float* wl
 }
 
 // per-thread prefetch registers by channel-chunk size: PU patch floats, WU weight float4
-__host__ __device__ constexpr int pu_max(int kc) { return kc == 32 ? 16 : kc == 8 ? 20 : 12; }
-__host__ __device__ constexpr int wu_max(int kc) { return kc == 32 ? 4 : kc == 8 ? 9 : 13; }
+__host__ __device__ constexpr int pu_max(int kc, int wm) { return kc == 32 ? (wm * 1 >= 2 ? 16 : 26) : kc == 8 ? 20 : 12; }
+__host__ __device__ constexpr int wu_max(int kc) { return kc == 32 ? 10 : kc == 8 ? 9 : 13; }
 
 template <int WM, int WN, int KC>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
@@ -82,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
   constexpr int BM = WM * 32;
   constexpr int B4 = BM / 4;
   constexpr int NFRAG = WN * 4;
-  constexpr int PU_MAX = pu_max(KC), WU_MAX = wu_max(KC);
+  constexpr int PU_MAX = pu_max(KC, WM * WN), WU_MAX = wu_max(KC);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l32 = lane & 31, half = lane >> 5;
@@ -209,45 +191,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
   }
 
   // ---- epilogue: C/D layout col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*half ----
-  const long long HWo = (long long)p.Ho * p.Wo;
+  const ConvEpi epi = scf_conv_epi(p, n);
   const bool use_div = p.out_div != 1.0f;
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int oy = ty0 + (wave * WN + j) * FR + fr, ox = tx0 + fc;
     const bool pok = oy < p.Ho && ox < p.Wo;
-    const long long pix = (long long)oy * p.Wo + ox;
+    const int pix = oy * p.Wo + ox;
+    if (pok) {
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (pok && co < p.Cout) {
-        float v = acc[i][j][r];
-        if (use_div) v = v / p.out_div;
-        if (p.bias) v += p.bias[co];
-        if (p.mode == SCF_CONV_PLAIN) {
-          if (p.scale) v = v * p.scale[co] + p.shift[co];
-          if (p.res) v += p.res[(long long)n * p.res_ns + co * HWo + pix];
-          const int a = (p.act_split > 0 && co >= p.act_split) ? p.act2 : p.act;
-          p.out[(long long)n * p.out_ns + co * HWo + pix] = scf_apply_act(v, a);
-        } else if (p.mode == SCF_CONV_GRU_ZR) {
-          const float sg = 1.f / (1.f + expf(-v));
-          const int hc = p.Cout >> 1;
-          if (co < hc) {
-            p.out[(long long)n * p.out_ns + co * HWo + pix] = sg;
-          } else {
-            const int c2 = co - hc;
-            const float hv = p.gru_h[(long long)n * p.gru_h_ns + c2 * HWo + pix];
-            p.gru_aux[(long long)n * p.gru_aux_ns + c2 * HWo + pix] = sg * hv;
-          }
-        } else {  // SCF_CONV_GRU_Q
-          const float q = tanhf(v);
-          const float z = p.gru_z[(long long)n * p.gru_z_ns + co * HWo + pix];
-          const float hv = p.gru_h[(long long)n * p.gru_h_ns + co * HWo + pix];
-          p.out[(long long)n * p.out_ns + co * HWo + pix] = (1.f - z) * hv + z * q;
-        }
-        }
-      }
+      for (int i = 0; i < WM; ++i)
+        scf_conv_epilogue_frag(p, epi, acc[i][j], m0 + i * 32, half, pix, use_div);
     }
   }
 }
@@ -269,7 +223,14 @@ static int next_pow2(int v) {
   return p;
 }
 
-extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
+struct ConvPlan {
+  ConvK k;
+  int WM, WN;
+  long long nblk;
+  size_t lds_bytes;
+};
+
+static int conv_plan(const scf_conv_desc* d, ConvPlan* plan) {
   if (!d || !d->in0 || !d->wp || !d->out) return SCF_EINVAL;
   if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C0 <= 0 || d->C1 < 0 || d->Cout <= 0) return SCF_EINVAL;
   if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->pad_h < 0 || d->pad_w < 0) return SCF_EINVAL;
@@ -281,7 +242,7 @@ extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
   if (d->mode == SCF_CONV_GRU_Q && (!d->gru_h || !d->gru_z)) return SCF_EINVAL;
   if ((d->scale == nullptr) != (d->shift == nullptr)) return SCF_EINVAL;
 
-  ConvK k;
+  ConvK& k = plan->k;
   k.in0 = d->in0; k.in1 = d->C1 > 0 ? d->in1 : nullptr;
   k.C0 = d->C0; k.Cin = d->C0 + d->C1;
   k.in0_ns = d->in0_nstride; k.in1_ns = d->in1_nstride;
@@ -290,6 +251,7 @@ extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
   k.Wo = (d->W + 2 * d->pad_w - d->KW) / d->stride + 1;
   if (k.Ho <= 0 || k.Wo <= 0) return SCF_EINVAL;
   k.wp = d->wp; k.w_ns = d->w_nstride; k.Mld = d->Mld; k.Cout = d->Cout;
+  k.wp16 = d->wp_f16;
   k.KH = d->KH; k.KW = d->KW; k.T = d->KH * d->KW; k.stride = d->stride;
   k.pad_h = d->pad_h; k.pad_w = d->pad_w; k.KC = d->KC;
   k.nchunk = (k.Cin + k.KC - 1) / k.KC;
@@ -328,7 +290,7 @@ extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
     const long long PE = (long long)k.KC * PH * PW, WE = (long long)k.KC * k.T * WM * 8;
     const size_t lds = ((size_t)k.KC * k.T * WM * 32 + (size_t)PE) * sizeof(float);
     if (lds_out) *lds_out = lds;
-    return (PE + 255) / 256 <= pu_max(k.KC) && (WE + 255) / 256 <= wu_max(k.KC) && lds <= 64 * 1024;
+    return (PE + 255) / 256 <= pu_max(k.KC, WM * WN) && (WE + 255) / 256 <= wu_max(k.KC) && lds <= 64 * 1024;
   };
   int WM = frags_m >= 4 ? ((frags_m % 4 == 0 || frags_m % 3 != 0) ? 4 : 3) : frags_m;
   int WN = 1;
@@ -349,14 +311,55 @@ extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
     k.tiles_y = (k.Ho + TR - 1) / TR;
     k.tiles_x = (k.Wo + FC - 1) / FC;
   }
-  const long long nblk = (long long)d->N * k.tiles_y * k.tiles_x * k.mblocks;
-  if (nblk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
+  plan->nblk = (long long)d->N * k.tiles_y * k.tiles_x * k.mblocks;
+  if (plan->nblk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
+  plan->WM = WM; plan->WN = WN; plan->lds_bytes = lds_bytes;
+  return SCF_OK;
+}
+
+// split-fp16 eligibility: shared weights, >= 16 input channels, spatial kernel (dense 1x1
+// layers stay on the fp32 KC=32 kernel), shape fits the fp16 kernel's staging budget.
+static bool want_f16x3(const scf_conv_desc* d) {
+  return d->wp_f16 != nullptr && d->w_nstride == 0 && d->KH * d->KW > 1 && d->C0 + d->C1 >= 16;
+}
+
+extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
+  ConvPlan pl;
+  const int rc = conv_plan(d, &pl);
+  if (rc != SCF_OK) return rc;
+  if (want_f16x3(d)) {
+    const int r16 = scf_conv_f16x3_dispatch(pl.k, d->N, false, nullptr, scf_stream(stream));
+    if (r16 != SCF_EUNSUPPORTED) return r16;
+  }
+  const ConvK& k = pl.k;
+  const int WM = pl.WM, WN = pl.WN;
+  const long long nblk = pl.nblk;
+  const size_t lds_bytes = pl.lds_bytes;
   hipStream_t st = scf_stream(stream);
 #define SCF_CASE(M, Nn) if (WM == M && WN == Nn) return launch_conv<M, Nn>(k, (int)nblk, lds_bytes, st);
   SCF_CASE(1, 1) SCF_CASE(1, 2) SCF_CASE(2, 1) SCF_CASE(2, 2)
   SCF_CASE(3, 1) SCF_CASE(4, 1)
 #undef SCF_CASE
   return SCF_EUNSUPPORTED;
+}
+
+// Dry run of the tile selection for a descriptor: info[0..3] = WM, WN, grid blocks, MFMA
+// instructions per wave per staged channel chunk.  Lets the host side choose between weight
+// packings (KC = 8 vs 32) without launching.
+extern "C" int scf_conv2d_query(const scf_conv_desc* d, int32_t* info) {
+  if (!info) return SCF_EINVAL;
+  ConvPlan pl;
+  const int rc = conv_plan(d, &pl);
+  if (rc != SCF_OK) return rc;
+  if (want_f16x3(d) && scf_conv_f16x3_dispatch(pl.k, d->N, true, info, nullptr) == SCF_OK) {
+    info[3] = -info[3];      // negative: the split-fp16 kernel will run
+    return SCF_OK;
+  }
+  info[0] = pl.WM;
+  info[1] = pl.WN;
+  info[2] = (int32_t)pl.nblk;
+  info[3] = pl.k.T * (pl.k.KC / 2) * pl.WM * pl.WN;
+  return SCF_OK;
 }
 
 // ---------------------------------------------------------------------------------

@@ -24,7 +24,8 @@ from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_GRU_Q, CONV_G
 
 Tensor = torch.Tensor
 
-__all__ = ['PackedConv', 'pack_conv_weight', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
+__all__ = ['PackedConv', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision',
+           'get_conv_precision', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
            'instance_norm', 'group_norm_relu', 'linear', 'pose_update', 'reproject_flow',
            'unproject_depth', 'resize_bilinear', 'avgpool2x2', 'copy_channels',
            'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_TANH', 'CONV_PLAIN', 'CONV_GRU_ZR',
@@ -97,6 +98,44 @@ def pack_conv_weight(weight: Tensor, kc: int) -> Tuple[Tensor, int]:
     return out.contiguous(), mld
 
 
+def pack_conv_weight_f16x3(weight: Tensor) -> Tensor:
+    """(Cout, Cin, KH, KW) fp32 -> split-fp16 packing for conv_f16x3.hip:
+    w = hi + lo' * 2**-11 with hi = fp16(w), lo' = fp16((w - hi) * 2**11); cells of 8 channels,
+    shape ((chunk16*T + tap)*2 + k8, plane hi|lo, Mld, 8) float16."""
+    cout, cin, kh, kw = weight.shape
+    t = kh * kw
+    nchunk = (cin + 31) // 32 * 2       # 16-channel chunks, padded to a multiple of 32 channels
+    mld = (cout + 31) // 32 * 32
+    w = torch.zeros((cout, nchunk * 16, t), dtype=torch.float32, device=weight.device)
+    w[:, :cin] = weight.reshape(cout, cin, t).float()
+    hi = w.half()
+    lo = ((w - hi.float()) * 2048.0).half()
+    out = torch.zeros((nchunk, t, 2, 2, mld, 8), dtype=torch.float16, device=weight.device)
+    for plane, x in enumerate((hi, lo)):
+        out[:, :, :, plane, :cout] = x.reshape(cout, nchunk, 2, 8, t).permute(1, 4, 2, 0, 3)
+    return out.reshape(nchunk * t * 2, 2, mld, 8).contiguous()
+
+
+_CONV_PRECISION = 'f32'
+
+
+def set_conv_precision(mode: str) -> str:
+    """'f32'   : v_mfma_f32_32x32x2_f32 everywhere (bit-for-bit fp32 fma chains);
+    'f16x3' : spatial convolutions with >= 16 input channels run on the fp16 matrix cores as
+              three MFMAs over an exact hi/lo split of both operands (fp32 accumulate, ~22
+              mantissa bits; flow EPE ~1e-4 px vs fp32 on this path), everything else fp32.
+    Returns the previous mode."""
+    global _CONV_PRECISION
+    if mode not in ('f32', 'f16x3'):
+        raise ValueError(mode)
+    prev, _CONV_PRECISION = _CONV_PRECISION, mode
+    return prev
+
+
+def get_conv_precision() -> str:
+    return _CONV_PRECISION
+
+
 @dataclass
 class PackedConv:
     """a convolution's parameters in kernel layout (device resident)."""
@@ -113,6 +152,9 @@ class PackedConv:
     pad_w: int
     kc: int
     mld: int
+    wp_alt: Optional[Tensor] = None   # KC=32 packing of the same weights (short-chunk regime)
+    plans: Optional[dict] = None      # (N, H, W, C0, C1) -> use the KC=32 packing?
+    wp16: Optional[Tensor] = None     # split-fp16 packing (spatial kernels, Cin >= 16)
 
     @staticmethod
     def from_weight(weight: Tensor, bias: Optional[Tensor], stride: int = 1,
@@ -123,6 +165,8 @@ class PackedConv:
         cout, cin, kh, kw = weight.shape
         kc = choose_kc(cin, kh, kw, stride)
         wp, mld = pack_conv_weight(weight, kc)
+        wp_alt = pack_conv_weight(weight, 32)[0] if (kc == 8 and cin >= 32) else None
+        wp16 = pack_conv_weight_f16x3(weight) if (cin >= 16 and kh * kw > 1) else None
         ph, pw = (padding, padding) if isinstance(padding, int) else padding
         scale = shift = None
         if bn is not None:
@@ -130,7 +174,7 @@ class PackedConv:
             scale = (gamma / torch.sqrt(var + eps)).contiguous()
             shift = (beta - mean * scale).contiguous()
         return PackedConv(wp, None if bias is None else bias.float().contiguous(), scale, shift,
-                          cin, cout, kh, kw, stride, ph, pw, kc, mld)
+                          cin, cout, kh, kw, stride, ph, pw, kc, mld, wp_alt, {}, wp16)
 
     def out_hw(self, h: int, w: int) -> Tuple[int, int]:
         return ((h + 2 * self.pad_h - self.kh) // self.stride + 1,
@@ -186,6 +230,25 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
     if gru_z is not None:
         pz_, _, _, _, _, sz_ = _nchw(gru_z, 'gru_z')
         d.gru_z, d.gru_z_nstride = pz_, sz_
+    # Short-chunk regime (few blocks -> smallest tile): with KC=8 the MFMA phase of a chunk
+    # (T*4*WM*WN MFMAs of 64 cycles) is shorter than the L2 round trip its prefetch has to
+    # hide.  Stage 32 channels per chunk instead when that packing fits (decided once per shape).
+    if _CONV_PRECISION == 'f16x3' and pc.wp16 is not None:
+        d.wp_f16 = pc.wp16.data_ptr()
+    if pc.wp_alt is not None and (c1 == 0 or c0 % 32 == 0):
+        key = (n, h, w, c0, c1, d.wp_f16 is not None)
+        use_alt = pc.plans.get(key)
+        if use_alt is None:
+            lib = _lib.load()
+            info = (C.c_int32 * 4)()
+            use_alt = False
+            if lib.scf_conv2d_query(C.byref(d), info) == 0 and 0 <= info[3] * 64 < 6000:
+                d.wp, d.KC = pc.wp_alt.data_ptr(), 32
+                use_alt = lib.scf_conv2d_query(C.byref(d), info) == 0
+                d.wp, d.KC = pc.wp.data_ptr(), pc.kc
+            pc.plans[key] = use_alt
+        if use_alt:
+            d.wp, d.KC = pc.wp_alt.data_ptr(), 32
     _lib.check(_lib.load().scf_conv2d(C.byref(d), _stream()), 'scf_conv2d')
     return out
 

@@ -270,3 +270,55 @@ def test_avgpool_and_copy():
     dst = torch.zeros((3, 9, 12, 20), device=DEV)
     ops.copy_channels(x.to(DEV), dst[:, 2:7])
     close(dst[:, 2:7], x, atol=0, what='copy')
+
+
+# ------------------------------------------------------- split-fp16 (3 x MFMA) convolution
+F16_CASES = [c for c in CONV_CASES if c[1] >= 16 and c[3] != (1, 1)]
+
+
+@pytest.mark.parametrize('case', F16_CASES)
+def test_conv2d_f16x3(case):
+    """fp32-class accuracy of the split-fp16 kernel: error vs fp64 must stay within a small
+    multiple of the fp32 kernel's own error (both ~1e-6 relative to the output scale)."""
+    n, cin, cout, k, s, p, H, W = case
+    x = rnd((n, cin, H, W), 10)
+    wt = rnd((cout, cin, *k), 11, (1.0 / (cin * k[0] * k[1])) ** 0.5)
+    b = rnd((cout,), 12, 0.1)
+    ref64 = torch.relu(F.conv2d(x.double(), wt.double(), b.double(), stride=s, padding=p))
+    pc = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), stride=s, padding=p)
+    got32 = ops.conv2d(pc, x.to(DEV), act=ops.ACT_RELU).cpu().double()
+    prev = ops.set_conv_precision('f16x3')
+    try:
+        got16 = ops.conv2d(pc, x.to(DEV), act=ops.ACT_RELU).cpu().double()
+    finally:
+        ops.set_conv_precision(prev)
+    e32 = float((got32 - ref64).abs().max())
+    e16 = float((got16 - ref64).abs().max())
+    scale = float(ref64.abs().max())
+    assert e16 <= 4e-6 * scale + 1e-6, f'{case}: f16x3 err {e16:.2e} (fp32 kernel {e32:.2e}, scale {scale:.2f})'
+
+
+def test_conv2d_f16x3_gru_and_segments():
+    n, h, w = 2, 16, 16
+    hx = rnd((n, 384, h, w), 40)
+    hx[:, :128] = torch.tanh(hx[:, :128])
+    wz, wr, wq = (rnd((128, 384, 1, 5), s, 0.03) for s in (41, 42, 43))
+    bz, br, bq = (rnd((128,), s, 0.1) for s in (44, 45, 46))
+    hcur, x = hx[:, :128], hx[:, 128:]
+    z = torch.sigmoid(F.conv2d(hx, wz, bz, padding=(0, 2)))
+    r = torch.sigmoid(F.conv2d(hx, wr, br, padding=(0, 2)))
+    q = torch.tanh(F.conv2d(torch.cat([r * hcur, x], 1), wq, bq, padding=(0, 2)))
+    want = (1 - z) * hcur + z * q
+    pzr = ops.PackedConv.from_weight(torch.cat([wz, wr]).to(DEV), torch.cat([bz, br]).to(DEV), padding=(0, 2))
+    pq = ops.PackedConv.from_weight(wq.to(DEV), bq.to(DEV), padding=(0, 2))
+    hxd = hx.to(DEV)
+    zb = torch.empty((n, 128, h, w), device=DEV)
+    rh = torch.empty((n, 128, h, w), device=DEV)
+    prev = ops.set_conv_precision('f16x3')
+    try:
+        ops.conv2d(pzr, hxd, out=zb, mode=ops.CONV_GRU_ZR, gru_h=hxd[:, :128], gru_aux=rh)
+        ops.conv2d(pq, rh, hxd[:, 128:], out=hxd[:, :128], mode=ops.CONV_GRU_Q, gru_h=hxd[:, :128], gru_z=zb)
+    finally:
+        ops.set_conv_precision(prev)
+    close(zb, z, atol=2e-5, what='z')
+    close(hxd[:, :128], want, atol=3e-5, what='h_new f16x3')

@@ -168,3 +168,32 @@ def test_hipgraph_replay_matches_eager(golden_dir, model):
             for wt, gt in zip(ws, gs):
                 assert torch.equal(wt, gt)
     model.decoder.iters = 8
+
+
+def test_full_refiner_f16x3_epe(golden_dir, model):
+    """split-fp16 convolutions: the stated tolerance (flow EPE <= 1e-3 px vs the fp32 CPU path)
+    must hold with margin over 8 iterations."""
+    from scflow_amd import ops
+    sd = scflow_amd.fill_state_dict(_shapes(golden_dir), seed=0)
+    inp = scflow_amd.make_inputs(2, 256, 256, seed=13)
+    with torch.no_grad():
+        want = oracle.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'],
+                               inp['ref_translation'], inp['depth'], inp['internel_k'],
+                               inp['label'], sd, iters=8)
+    model.decoder.iters = 8
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    prev = ops.set_conv_precision('f16x3')
+    try:
+        got = model.get_pose(d['render_images'], d['real_images'], d['ref_rotation'],
+                             d['ref_translation'], d['depth'], d['internel_k'], d['label'])
+    finally:
+        ops.set_conv_precision(prev)
+    valid = inp['depth'] > 0
+    worst = 0.0
+    for it in range(8):
+        worst = max(worst, oracle.end_point_error(got[0][it].cpu(), want[0][it], valid),
+                    oracle.end_point_error(got[1][it].cpu(), want[1][it]))
+    print(f'f16x3 worst EPE over 8 iters: {worst:.2e}')
+    assert worst <= 5e-4, f'EPE {worst:.2e}'
+    close(got[2][-1], want[2][-1], atol=1e-5, what='final rotation')
+    close(got[3][-1], want[3][-1], atol=2e-2, rtol=5e-5, what='final translation (mm)')

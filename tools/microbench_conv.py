@@ -1,0 +1,44 @@
+"""Micro-benchmark of single convolution layers of the SCFlow path (HIP events, median)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from scflow_amd import ops
+dev = 'cuda:0'
+N = int(os.environ.get('N', 32))
+LAYERS = [  # name, cin, cout, (kh,kw), stride, pad, H, W, batch multiplier
+    ('heads 3x3 128>512', 128, 512, (3, 3), 1, (1, 1), 32, 32, 1),
+    ('corr_net.1 3x3 256>192', 256, 192, (3, 3), 1, (1, 1), 32, 32, 1),
+    ('gru zr 1x5 384>256', 384, 256, (1, 5), 1, (0, 2), 32, 32, 1),
+    ('gru q 5x1 384>128', 384, 128, (5, 1), 1, (2, 0), 32, 32, 1),
+    ('enc l1 3x3 64>64 @128', 64, 64, (3, 3), 1, (1, 1), 128, 128, 2),
+    ('enc l2 3x3 96>96 @64', 96, 96, (3, 3), 1, (1, 1), 64, 64, 2),
+    ('1x1 324>256', 324, 256, (1, 1), 1, (0, 0), 32, 32, 1),
+    ('pose c0 3x3s2 224>128', 224, 128, (3, 3), 2, (1, 1), 32, 32, 1),
+    ('flow_pred 3x3 256>2', 256, 2, (3, 3), 1, (1, 1), 32, 32, 1),
+]
+sel = sys.argv[1:] 
+for name, cin, cout, k, s, p, H, W, bm in LAYERS:
+    if sel and not any(x in name for x in sel):
+        continue
+    n = N * bm
+    x = torch.randn(n, cin, H, W, device=dev)
+    w = torch.randn(cout, cin, *k, device=dev) * 0.05
+    b = torch.randn(cout, device=dev)
+    pc = ops.PackedConv.from_weight(w, b, stride=s, padding=p)
+    out = ops.conv2d(pc, x, act=ops.ACT_RELU)
+    flops = 2.0 * cin * k[0] * k[1] * cout * out.shape[2] * out.shape[3] * n
+    res = []
+    for prec in ('f32', 'f16x3'):
+        ops.set_conv_precision(prec)
+        for _ in range(3):
+            ops.conv2d(pc, x, out=out, act=ops.ACT_RELU)
+        evs = []
+        for _ in range(15):
+            a = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+            a.record(); ops.conv2d(pc, x, out=out, act=ops.ACT_RELU); e.record(); evs.append((a, e))
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(e) for a, e in evs)
+        us = ts[len(ts) // 2] * 1e3
+        res.append(f'{prec}: {us:7.1f} us {flops / us / 1e6:6.1f} TF/s')
+    ops.set_conv_precision('f32')
+    print(f'{name:26s} N={n:3d}  ' + '   '.join(res))
