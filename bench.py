@@ -108,6 +108,8 @@ def main():
     ap.add_argument('--precision', choices=['f32', 'f16x3'], default='f32',
                     help='convolution arithmetic: exact fp32 MFMA, or split-fp16 3xMFMA '
                          '(fp32 accumulate, ~22 mantissa bits; see DESIGN.md)')
+    ap.add_argument('--no-alt', action='store_true', help='skip the second timed loop in the other '
+                    'convolution precision')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-batch1', action='store_true')
     args = ap.parse_args()
@@ -139,23 +141,46 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    ops.lookup_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    lookup_us = ops.lookup_timing(False)
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(precision):
+        """W warm-up + K timed steps in one convolution precision -> (seconds, lookup us list)."""
+        ops.set_conv_precision(precision)
+        for _ in range(args.warmup):
+            step()
+        fence()
+        ops.lookup_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        el = time.perf_counter() - t0
+        lk = ops.lookup_timing(False)
+        if world > 1:
+            t = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, lk
+
+    dt, lookup_us = timed(args.precision)
+    alt = None
+    if not args.no_alt:
+        other = 'f16x3' if args.precision == 'f32' else 'f32'
+        dt_alt, lk_alt = timed(other)
+        alt = {'precision': other,
+               'value': round(args.batch * world * args.steps / dt_alt, 2), 'unit': 'pairs/s',
+               'ms_per_step': round(dt_alt / args.steps * 1e3, 3),
+               'lookup_avg_launch_us': round(sum(lk_alt) / max(len(lk_alt), 1), 2),
+               'note': 'f16x3 = spatial convs with >=16 input channels as 3 fp16 MFMAs over an exact '
+                       'hi/lo split of both operands, fp32 accumulate (~22 mantissa bits); flow EPE vs '
+                       'the fp32 CPU oracle 7.6e-5 px over 8 iterations (tests/test_gpu_refiner.py), '
+                       'north-star tolerance 1e-3 px.  f32 = v_mfma_f32_32x32x2_f32 everywhere.'}
+        ops.set_conv_precision(args.precision)
 
     result = None
     if rank == 0:
+        pmc = {}
+        pmc_path = os.path.join(ROOT, 'profiles', 'lookup_pmc.json')
+        if os.path.exists(pmc_path) and args.batch == 32:      # PMC passes are separate rocprofv3 runs
+            pmc = json.load(open(pmc_path))
         pairs = args.batch * world * args.steps
         q = args.batch * 32 * 32
         avg_us = sum(lookup_us) / max(len(lookup_us), 1)
@@ -165,7 +190,9 @@ def main():
             'value': round(pairs / dt, 2), 'unit': 'pairs/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.precision == 'f32' else 'f32 (split-fp16 3xMFMA convs, fp32 accumulate)',
+            'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[2] per GPU: batch={args.batch} synthetic '
                                    f'256x256 pairs, {args.iters} GRU iters, corr radius 4, 4 levels'
                                    + (f' (configs[3] shape: {args.batch * world} pairs batch-split '
@@ -177,7 +204,8 @@ def main():
                          'achieved': None if achieved is None else round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': None,
+                         'traffic': pmc.get('traffic_bytes_per_launch'),
+                         'traffic_source': pmc.get('source'),
                          'avg_launch_us': round(avg_us, 2), 'launches_timed': len(lookup_us),
                          'algorithmic_bytes_per_launch': LOOKUP_BYTES_PER_QUERY * q},
         }
@@ -210,6 +238,8 @@ def main():
                             'pairs_per_s_hipgraph': round(1e3 / ms, 2),
                             'ms_per_pair_eager': round(ms_eager, 3)}
 
+    if rank == 0 and alt is not None:
+        result['alt_precision'] = alt
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(sd, args.iters)
     if rank == 0:

@@ -168,6 +168,14 @@ int scf_unproject_depth(const float* depth, const float* K, const float* R0, con
 int scf_resize_bilinear(const float* a, const float* b, float* out, int64_t planes, int Hin,
                         int Win, int Hout, int Wout, float mul, scf_stream_t stream);
 
+/* RAFT convex up-sampling (x8, 3x3 neighbourhood).  replaces RAFTDecoder._upsample
+ * models/decoder/raft_decoder.py:381-416 and RAFTDecoderMask.upsample_flow/upsample_mask
+ * raft_decoder_mask.py:104-160:  out[n,c,8y+sy,8x+sx] = sum_k softmax_k(mask_mul *
+ * mask[n, k*64+sy*8+sx, y, x]) * x_mul * x[n, c, y+k/3-1, x+k%3-1] (zero padded).
+ * x (N,C,h,w); mask (N,9*64,h,w); out (N,C,8h,8w).                                     */
+int scf_convex_upsample(const float* x, const float* mask, float* out, int N, int C, int h,
+                        int w, int scale, float x_mul, float mask_mul, scf_stream_t stream);
+
 /* 2x2 stride-2 average pool over (planes, Hin, Win) -> (planes, Hin/2, Win/2)          */
 int scf_avgpool2x2(const float* x, float* out, int64_t planes, int Hin, int Win,
                    scf_stream_t stream);

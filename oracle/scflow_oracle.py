@@ -26,7 +26,8 @@ __all__ = [
     'motion_encoder', 'sepconv_gru', 'xhead', 'multiclass_pose_head',
     'rotation_from_ortho6d', 'pose_from_delta_pose', 'unproject_depth',
     'flow_from_pose_and_points', 'scflow_decoder', 'extract_feat',
-    'get_pose', 'end_point_error',
+    'get_pose', 'end_point_error', 'convex_upsample', 'raft_decoder', 'raft_decoder_mask',
+    'cal_epe',
 ]
 
 
@@ -360,3 +361,86 @@ def end_point_error(flow_a: Tensor, flow_b: Tensor, valid: Tensor | None = None)
     if valid is not None:
         d = d[valid]
     return float(d.mean()) if d.numel() else 0.0
+
+
+# --------------------------------------------------------------------------
+# "next" rows: pose-free RAFT decoders, EPE metric
+# --------------------------------------------------------------------------
+def convex_upsample(x: Tensor, mask: Tensor, scale: int = 8, grid_size: int = 9,
+                    x_mul: float = 1.0) -> Tensor:
+    """decoder/raft_decoder.py:381-416 ``RAFTDecoder._upsample`` with a mask (same arithmetic
+    in raft_decoder_mask.py:104-160): softmax over the ``grid_size`` logits of every
+    sub-pixel, unfold(x_mul * x, 3x3, padding=1), weighted sum, pixel-shuffle to scale*H.
+    (grid_size = 2*radius+1 = 9 only coincides with the 3x3 unfold because radius = 4.)"""
+    n, c, h, w = x.shape
+    side = int(math.sqrt(grid_size))
+    m = torch.softmax(mask.view(n, 1, grid_size, scale, scale, h, w), dim=2)
+    up = F.unfold(x_mul * x, [side, side], padding=1).view(n, c, grid_size, 1, 1, h, w)
+    up = torch.sum(m * up, dim=2).permute(0, 1, 4, 2, 5, 3)
+    return up.reshape(n, c, scale * h, scale * w)
+
+
+def _raft_iteration(pyramid, flow, h_feat, cxt_feat, sd, p, radius):
+    corr = corr_lookup(pyramid, flow, radius)
+    motion = motion_encoder(corr, flow, sd, p + 'encoder.')
+    h_feat = sepconv_gru(h_feat, torch.cat([cxt_feat, motion], dim=1), sd, p + 'gru.')
+    return h_feat, flow + xhead(h_feat, sd, p + 'flow_pred.', 'flow')
+
+
+def raft_decoder(feat1: Tensor, feat2: Tensor, flow: Tensor, h_feat: Tensor, cxt_feat: Tensor,
+                 sd: SD, *, prefix: str = 'decoder.', iters: int = 12, num_levels: int = 4,
+                 radius: int = 4) -> List[Tensor]:
+    """decoder/raft_decoder.py:418-457 ``RAFTDecoder.forward`` ('Basic': convex up-sampling
+    with mask = 0.25 * mask_pred(h))."""
+    pyramid = correlation_pyramid(feat1, feat2, num_levels)
+    scale = 2 ** (num_levels - 1)
+    outs = []
+    for _ in range(iters):
+        h_feat, flow = _raft_iteration(pyramid, flow, h_feat, cxt_feat, sd, prefix, radius)
+        mask = .25 * xhead(h_feat, sd, prefix + 'mask_pred.', 'mask')
+        outs.append(convex_upsample(flow, mask, scale, 2 * radius + 1, x_mul=float(scale)))
+    return outs
+
+
+def raft_decoder_mask(feat1: Tensor, feat2: Tensor, flow: Tensor, h_feat: Tensor,
+                      cxt_feat: Tensor, sd: SD, *, prefix: str = 'decoder.', iters: int = 12,
+                      num_levels: int = 4, radius: int = 4):
+    """decoder/raft_decoder_mask.py:163-208 ``RAFTDecoderMask.forward``: as RAFTDecoder plus an
+    occlusion head (sigmoid) that is convex-up-sampled with the same mask."""
+    pyramid = correlation_pyramid(feat1, feat2, num_levels)
+    scale = 2 ** (num_levels - 1)
+    flows, occs = [], []
+    for _ in range(iters):
+        h_feat, flow = _raft_iteration(pyramid, flow, h_feat, cxt_feat, sd, prefix, radius)
+        occ = torch.sigmoid(xhead(h_feat, sd, prefix + 'occlusion_pred.', 'mask'))
+        mask = .25 * xhead(h_feat, sd, prefix + 'mask_pred.', 'mask')
+        flows.append(convex_upsample(flow, mask, scale, 2 * radius + 1, x_mul=float(scale)))
+        occs.append(convex_upsample(occ, mask, scale, 2 * radius + 1))
+    return flows, occs
+
+
+def cal_epe(flow_tgt: Tensor, flow_pred: Tensor, mask, max_flow: float = 400,
+            reduction: str = 'mean', threshs=(1, 3, 5)):
+    """utils/flow.py:64-88 ``cal_epe`` restated AS-IS.  valid = |flow_tgt| < max_flow (and
+    mask >= 0.5).  Known quirk kept on purpose: in the 'mean' branch the error of the VALID
+    pixels is overwritten with 1e8 before the threshold ratios are taken (:79), so the
+    '<t>px' entries count INVALID pixels below the threshold ('total_mean' does it right)."""
+    mag = torch.sum(flow_tgt ** 2, dim=1).sqrt()
+    valid = (mag < max_flow) & (mask >= 0.5) if mask is not None else (mag < max_flow)
+    err = torch.sum((flow_tgt - flow_pred) ** 2, dim=1).sqrt()
+    if reduction == 'none':
+        return err * valid.to(err)
+    acc = {}
+    if reduction == 'mean':
+        total = valid.sum(dim=(-1, -2)) + 1e-10
+        acc['mean'] = (err * valid.to(err)).sum(dim=(-1, -2)) / total
+        err = err.clone()
+        err[valid] = 1e+8
+        for t in threshs:
+            acc[f'{t}px'] = (err < t).sum(dim=(-1, -2)) / total
+    elif reduction == 'total_mean':
+        total = valid.sum(dim=(-1, -2, -3)) + 1e-10
+        acc['mean'] = (err * valid.to(err.dtype)).sum(dim=(-1, -2, -3)) / total
+        for t in threshs:
+            acc[f'{t}px'] = (err[valid] < t).sum() / total
+    return acc

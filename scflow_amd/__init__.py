@@ -12,8 +12,10 @@ __version__ = '0.1.0'
 from .registry import (DECODERS, ENCODERS, HEAD, REFINERS, Registry, build_decoder,  # noqa: F401
                        build_encoder, build_from_cfg, build_head, build_refiner)
 from .modules import (ConvGRU, CorrelationPyramid, CorrLookup, MotionEncoder,  # noqa: F401
-                      MultiClassPoseHead, RAFTEncoder, SCFlowDecoder, XHead)
-from .refiner import SCFlowRefiner  # noqa: F401
+                      MultiClassPoseHead, RAFTDecoder, RAFTDecoderMask, RAFTEncoder,
+                      SCFlowDecoder, XHead)
+from .refiner import RAFTRefinerFlow, RAFTRefinerFlowMask, SCFlowRefiner  # noqa: F401
+from .metrics import cal_epe  # noqa: F401
 from .config import scflow_model_cfg  # noqa: F401
 from .weights import fill_state_dict  # noqa: F401
 from .synthetic import make_inputs  # noqa: F401

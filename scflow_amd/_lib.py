@@ -65,6 +65,8 @@ SIGNATURES = {
     'scf_unproject_depth': (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     'scf_resize_bilinear': (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_float, _fp]),
+    'scf_convex_upsample': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_float, C.c_float, _fp]),
     'scf_avgpool2x2': (C.c_int, [_fp, _fp, C.c_int64, C.c_int, C.c_int, _fp]),
     'scf_copy_strided': (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int, C.c_int64, _fp]),
 }

@@ -29,18 +29,19 @@ struct LookupParams {
   const float* flow;
   float* out;
   int N, h, w, L;
+  int woff[4];            // LDS offset (floats) of each wave's staging region
   long long total_q;
 };
 
 template <int R>
-__global__ __launch_bounds__(256) void corr_lookup_kernel(LookupParams p) {
+__global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
   constexpr int FW = 2 * R + 2;       // footprint width
   constexpr int FS = FW * FW;         // footprint size
   constexpr int FSP = FS | 1;         // odd LDS stride per query
   constexpr int D = 2 * R + 1;        // window width
   constexpr int QB = 32;              // queries per block
   constexpr int NSET = (FS + 63) / 64;  // wave-loads per query footprint
-  __shared__ float fp[4][QB * FSP];
+  extern __shared__ float lds_fp[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(LookupParams p) {
     qx = (float)x + fl[0];
     qy = (float)y + fl[hw];
   }
-  float* myfp = fp[wave];
+  float* myfp = lds_fp + p.woff[wave];
 
   // footprint element(s) this lane fetches for EVERY query: e = lane + 64*s
   int erow[NSET], ecol[NSET];
@@ -91,40 +92,67 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(LookupParams p) {
     const float x0f = floorf(cx), y0f = floorf(cy);
     const int x0 = (int)x0f - R, y0 = (int)y0f - R;
 
-    // ---- load phase: one query per step, lanes <-> footprint elements.  x0/y0 and the map
-    //      base are wave-uniform per step (scalar registers); per lane only a bounds test and
-    //      a 32-bit offset remain.  8 queries (8*NSET loads) are in flight per wave.
-    const float* lbase = p.lvl[lvl] + gq0 * msz;
-    constexpr int QU = 8;             // queries whose loads are in flight together
-    for (int qb = 0; qb < QB; qb += QU) {
-      float v[QU][NSET];
-      unsigned okmask = 0;
-      // branch-free: out-of-map / out-of-range taps read element 0 of a valid map and are
-      // zeroed afterwards, so all QU*NSET loads issue back to back.
+    // Small maps (coarse levels: the whole map is no larger than the window footprint) are
+    // staged whole instead of as a zero-padded footprint: fewer LDS bytes per query (which is
+    // what lets 4 blocks share a CU and the grid finish in ONE wave of blocks at batch 32) and
+    // the maps of the block's 32 queries are one contiguous, fully coalesced run in memory.
+    const bool small = (lh <= FW && lw <= FW);
+    const int S = small ? ((int)msz | 1) : FSP;       // odd per-query LDS stride
+    if (small) {
+      const float* lbase = p.lvl[lvl] + gq0 * msz;
+      const int tot = nq * (int)msz;
+      for (int f0 = 0; f0 < tot; f0 += 64 * 8) {
+        float v[8];
 #pragma unroll
-      for (int u = 0; u < QU; ++u) {
-        const int qq = qb + u;
-        const int sx0 = flat_x ? 0 : __builtin_amdgcn_readlane(x0, qq);
-        const int sy0 = flat_y ? 0 : __builtin_amdgcn_readlane(y0, qq);
-        const bool qok = qq < nq;
-        const float* mb = lbase + (qok ? (long long)qq * msz : 0);
+        for (int u = 0; u < 8; ++u) {
+          const int f = f0 + u * 64 + lane;
+          v[u] = __builtin_nontemporal_load(lbase + (f < tot ? f : 0));
+        }
 #pragma unroll
-        for (int s = 0; s < NSET; ++s) {
-          const int xx = flat_x ? 0 : sx0 + ecol[s];
-          const int yy = flat_y ? 0 : sy0 + erow[s];
-          const bool ok = qok && (unsigned)xx < (unsigned)lw && (unsigned)yy < (unsigned)lh &&
-                          (NSET * 64 == FS || lane + 64 * s < FS);
-          const int idx = ok ? yy * lw + xx : 0;
-          v[u][s] = mb[idx];
-          okmask |= (ok ? 1u : 0u) << (u * NSET + s);
+        for (int u = 0; u < 8; ++u) {
+          const int f = f0 + u * 64 + lane;
+          if (f < tot) {
+            const int qq = f / (int)msz;
+            myfp[qq * S + (f - qq * (int)msz)] = v[u];
+          }
         }
       }
+    } else {
+    // ---- load phase: one query per step, lanes <-> footprint elements.  x0/y0 and the map
+      //      base are wave-uniform per step (scalar registers); per lane only a bounds test and
+      //      a 32-bit offset remain.  8 queries (8*NSET loads) are in flight per wave.
+      const float* lbase = p.lvl[lvl] + gq0 * msz;
+      constexpr int QU = 8;             // queries whose loads are in flight together
+      for (int qb = 0; qb < QB; qb += QU) {
+        float v[QU][NSET];
+        unsigned okmask = 0;
+        // branch-free: out-of-map / out-of-range taps read element 0 of a valid map and are
+        // zeroed afterwards, so all QU*NSET loads issue back to back.
 #pragma unroll
-      for (int u = 0; u < QU; ++u) {
+        for (int u = 0; u < QU; ++u) {
+          const int qq = qb + u;
+          const int sx0 = flat_x ? 0 : __builtin_amdgcn_readlane(x0, qq);
+          const int sy0 = flat_y ? 0 : __builtin_amdgcn_readlane(y0, qq);
+          const bool qok = qq < nq;
+          const float* mb = lbase + (qok ? (long long)qq * msz : 0);
 #pragma unroll
-        for (int s = 0; s < NSET; ++s) {
-          const float val = ((okmask >> (u * NSET + s)) & 1u) ? v[u][s] : 0.f;
-          if (NSET * 64 == FS || lane + 64 * s < FS) myfp[(qb + u) * FSP + lane + 64 * s] = val;
+          for (int s = 0; s < NSET; ++s) {
+            const int xx = flat_x ? 0 : sx0 + ecol[s];
+            const int yy = flat_y ? 0 : sy0 + erow[s];
+            const bool ok = qok && (unsigned)xx < (unsigned)lw && (unsigned)yy < (unsigned)lh &&
+                            (NSET * 64 == FS || lane + 64 * s < FS);
+            const int idx = ok ? yy * lw + xx : 0;
+            v[u][s] = __builtin_nontemporal_load(mb + idx);
+            okmask |= (ok ? 1u : 0u) << (u * NSET + s);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < QU; ++u) {
+#pragma unroll
+          for (int s = 0; s < NSET; ++s) {
+            const float val = ((okmask >> (u * NSET + s)) & 1u) ? v[u][s] : 0.f;
+            if (NSET * 64 == FS || lane + 64 * s < FS) myfp[(qb + u) * FSP + lane + 64 * s] = val;
+          }
         }
       }
     }
@@ -134,17 +162,42 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(LookupParams p) {
     const float tx = cx - x0f, ty = cy - y0f;
     const float wx0 = (x0f + 1.f) - cx, wy0 = (y0f + 1.f) - cy;   // grid_sample: (x_se - x)
     const float nw = wx0 * wy0, ne = tx * wy0, sw = wx0 * ty, se = tx * ty;
-    const float* f = myfp + l32 * FSP;
+    const float* f = myfp + l32 * S;
     const int i0 = half ? (D + 1) / 2 : 0;
     const int i1 = half ? D : (D + 1) / 2;
-    float colA[FW], colB[FW];
+    // column c of the window (x = x0 + c), rows 0..FW-1
+    int rowoff[FW];
+    unsigned rowok = 0;
+    if (small) {
 #pragma unroll
-    for (int r = 0; r < FW; ++r) colA[r] = f[r * FW + i0];
+      for (int r = 0; r < FW; ++r) {
+        const int yy = flat_y ? 0 : y0 + r;
+        const bool ok = (unsigned)yy < (unsigned)lh;
+        rowoff[r] = ok ? yy * lw : 0;
+        rowok |= (ok ? 1u : 0u) << r;
+      }
+    }
+    auto column = [&](int c, float (&col)[FW]) {
+      if (small) {
+        const int xx = flat_x ? 0 : x0 + c;
+        const bool cok = (unsigned)xx < (unsigned)lw;
+        const int xo = cok ? xx : 0;
+#pragma unroll
+        for (int r = 0; r < FW; ++r) {
+          const float v = f[rowoff[r] + xo];
+          col[r] = (cok && ((rowok >> r) & 1u)) ? v : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < FW; ++r) col[r] = f[r * FW + c];
+      }
+    };
+    float colA[FW], colB[FW];
+    column(i0, colA);
     // uniform channel base + per-lane query offset: the compiler keeps the base in SGPRs
     float* obase = p.out + ((long long)n * ktot + (long long)lvl * D * D) * hw + q;
     for (int i = i0; i < i1; ++i) {
-#pragma unroll
-      for (int r = 0; r < FW; ++r) colB[r] = f[r * FW + i + 1];
+      column(i + 1, colB);
       if (qvalid) {
         float* oc = obase + (long long)(i * D) * hw;
 #pragma unroll
@@ -179,11 +232,26 @@ extern "C" int scf_corr_lookup(const float* const* levels, const float* flow, fl
   p.N = N; p.h = h; p.w = w; p.L = L;
   p.total_q = (long long)N * h * w;
   const int nblk = (int)scf_cdiv(p.total_q, 32);
+  // per-wave LDS region: wave w stages levels w, w+4, ...; a level whose whole map fits in the
+  // (2r+2)^2 footprint is staged whole (stride map|1), otherwise as a footprint (stride FS|1)
+  const int FWh = 2 * r + 2, FSPh = (FWh * FWh) | 1;
+  int off = 0;
+  for (int wv = 0; wv < 4; ++wv) {
+    int need = 0;
+    for (int l = wv; l < L; l += 4) {
+      const bool small = p.lh[l] <= FWh && p.lw[l] <= FWh;
+      const int S = small ? ((p.lh[l] * p.lw[l]) | 1) : FSPh;
+      need = need > 32 * S ? need : 32 * S;
+    }
+    p.woff[wv] = off;
+    off += need;
+  }
+  const size_t lds = (size_t)off * sizeof(float);
   switch (r) {
-    case 4: hipLaunchKernelGGL(corr_lookup_kernel<4>, dim3(nblk), dim3(256), 0, scf_stream(stream), p); break;
-    case 3: hipLaunchKernelGGL(corr_lookup_kernel<3>, dim3(nblk), dim3(256), 0, scf_stream(stream), p); break;
-    case 2: hipLaunchKernelGGL(corr_lookup_kernel<2>, dim3(nblk), dim3(256), 0, scf_stream(stream), p); break;
-    case 1: hipLaunchKernelGGL(corr_lookup_kernel<1>, dim3(nblk), dim3(256), 0, scf_stream(stream), p); break;
+    case 4: hipLaunchKernelGGL(corr_lookup_kernel<4>, dim3(nblk), dim3(256), lds, scf_stream(stream), p); break;
+    case 3: hipLaunchKernelGGL(corr_lookup_kernel<3>, dim3(nblk), dim3(256), lds, scf_stream(stream), p); break;
+    case 2: hipLaunchKernelGGL(corr_lookup_kernel<2>, dim3(nblk), dim3(256), lds, scf_stream(stream), p); break;
+    case 1: hipLaunchKernelGGL(corr_lookup_kernel<1>, dim3(nblk), dim3(256), lds, scf_stream(stream), p); break;
     default: return SCF_EUNSUPPORTED;
   }
   return scf_launch_status();

@@ -98,3 +98,76 @@ extern "C" int scf_copy_strided(const float* src, int64_t src_nstride, float* ds
                      (long long)src_nstride, dst, (long long)dst_nstride, N, (long long)count);
   return scf_launch_status();
 }
+
+// ---------------------------------------------------------------------------------
+// RAFT convex up-sampling (x`scale`, 3x3 neighbourhood): RAFTDecoder._upsample,
+// models/decoder/raft_decoder.py:381-416 (same arithmetic in RAFTDecoderMask.upsample_flow /
+// upsample_mask, raft_decoder_mask.py:104-160):
+//   w[k] = softmax_k(mask_mul * mask[n, k*s*s + sy*s + sx, y, x]),  k = ky*3 + kx
+//   out[n, c, s*y+sy, s*x+sx] = sum_k w[k] * x_mul * x[n, c, y+ky-1, x+kx-1]   (zero padded)
+// HBM-bound on the mask read (9*s*s*4 B per low-res pixel).  One block = one low-res row
+// segment of 32 pixels: lanes run along x (coalesced mask reads, one 128-B line per channel),
+// results are transposed through LDS so every (c, sy) output row is written as s*32
+// contiguous floats.
+// ---------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ mask,
+                                                              float* __restrict__ out, int C, int h,
+                                                              int w, float x_mul, float mask_mul) {
+  constexpr int SS = S * S;
+  extern __shared__ float tile[];              // [C][S(sy)][32*S] floats
+  const int xt = blockIdx.x, y = blockIdx.y, n = blockIdx.z;
+  const int xl = threadIdx.x & 31, sub0 = threadIdx.x >> 5;   // 8 sub-pixel rows of lanes
+  const int px = xt * 32 + xl;
+  const long long hw = (long long)h * w;
+  const bool ok = px < w;
+  for (int sub = sub0; sub < SS; sub += 8) {
+    const int sy = sub / S, sx = sub - sy * S;
+    float wk[9];
+    float mx = -3.4e38f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      wk[k] = ok ? mask_mul * mask[((long long)n * 9 * SS + k * SS + sub) * hw + (long long)y * w + px] : 0.f;
+      mx = fmaxf(mx, wk[k]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { wk[k] = expf(wk[k] - mx); den += wk[k]; }
+    const float inv = 1.f / den;
+    for (int c = 0; c < C; ++c) {
+      const float* xp = x + ((long long)n * C + c) * hw;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int yy = y + k / 3 - 1, xx = px + k % 3 - 1;
+        float v = 0.f;
+        if (ok && yy >= 0 && yy < h && xx >= 0 && xx < w) v = x_mul * xp[(long long)yy * w + xx];
+        acc += (wk[k] * inv) * v;
+      }
+      tile[(c * S + sy) * (32 * S) + xl * S + sx] = acc;
+    }
+  }
+  __syncthreads();
+  const int W8 = w * S;
+  const int rowlen = 32 * S;
+  for (int e = threadIdx.x; e < C * S * rowlen; e += 256) {
+    const int col = e % rowlen, r = e / rowlen;      // r = c*S + sy
+    const int c = r / S, sy = r - c * S;
+    const int ox = xt * rowlen + col;
+    if (ox < W8) out[(((long long)n * C + c) * h * S + (long long)y * S + sy) * W8 + ox] = tile[e];
+  }
+}
+
+extern "C" int scf_convex_upsample(const float* x, const float* mask, float* out, int N, int C,
+                                   int h, int w, int scale, float x_mul, float mask_mul,
+                                   scf_stream_t stream) {
+  if (!x || !mask || !out || N <= 0 || C <= 0 || h <= 0 || w <= 0) return SCF_EINVAL;
+  if (scale != 8 || N > 65535 || h > 65535) return SCF_EUNSUPPORTED;
+  const size_t lds = (size_t)C * 8 * 32 * 8 * sizeof(float);
+  if (lds > 64 * 1024) return SCF_EUNSUPPORTED;
+  const dim3 grid((w + 31) / 32, h, N);
+  hipLaunchKernelGGL(convex_upsample_kernel<8>, grid, dim3(256), lds, scf_stream(stream), x, mask,
+                     out, C, h, w, x_mul, mask_mul);
+  return scf_launch_status();
+}

@@ -486,6 +486,97 @@ class SCFlowDecoder(HipModule):
         return outs
 
 
+class _RAFTDecoderBase(HipModule):
+    """shared part of RAFTDecoder / RAFTDecoderMask ('Basic'): correlation pyramid, lookup,
+    motion encoder, SepConvGRU, flow head, 576-channel convex-up-sampling mask head."""
+    _h_channels = {'Basic': 128, 'Small': 96}
+    _cxt_channels = {'Basic': 128, 'Small': 64}
+
+    def __init__(self, net_type: str, num_levels: int, radius: int, iters: int,
+                 corr_lookup_cfg: dict = dict(type='CorrLookup', align_corners=True),
+                 gru_type: str = 'SeqConv', feat_channels: Union[int, Sequence[int]] = 256,
+                 mask_channels: int = 64, convex_unsample_flow: bool = True, conv_cfg=None,
+                 norm_cfg=None, act_cfg=None) -> None:
+        super().__init__()
+        if net_type != 'Basic':
+            raise NotImplementedError("RAFT decoders: net_type='Basic'")
+        self.net_type, self.num_levels, self.radius, self.iters = net_type, num_levels, radius, iters
+        self.h_channels = self._h_channels[net_type]
+        self.cxt_channels = self._cxt_channels[net_type]
+        self.mask_channels = mask_channels * (2 * radius + 1)      # raft_decoder.py:355
+        self.corr_block = CorrelationPyramid(num_levels)
+        cl = dict(corr_lookup_cfg)
+        cl.pop('type', None)
+        cl['radius'] = radius
+        self.corr_lookup = CorrLookup(**cl)
+        self.encoder = MotionEncoder(num_levels, radius, net_type, conv_cfg, norm_cfg, act_cfg)
+        self.gru = ConvGRU(self.h_channels, 126 + 2 + self.cxt_channels, gru_type)
+        self.flow_pred = XHead(self.h_channels, [256], 2, x='flow')
+        self.mask_pred = XHead(self.h_channels, [256], self.mask_channels, x='mask')
+        self.convex_upsample_flow = convex_unsample_flow
+        if self.mask_channels != 9 * (2 ** (num_levels - 1)) ** 2:
+            raise NotImplementedError('convex up-sampling kernel: 9 x 8 x 8 mask (radius 4, 4 levels)')
+
+    def _step(self, pyramid, flow, hx):
+        """one update: lookup, motion encoder, GRU (in place in hx), flow += delta."""
+        hc, cc = self.h_channels, self.cxt_channels
+        corr = self.corr_lookup(pyramid, flow)
+        self.encoder(corr, flow, out=hx[:, hc + cc:])
+        hv = self.gru.forward_inplace(hx)
+        d_flow = self.flow_pred(hv)
+        n, _, h, w = flow.shape
+        return hv, ops.resize_bilinear(flow, (h, w), b=d_flow)       # flow + delta (same size)
+
+    def _upsample(self, x: Tensor, mask: Optional[Tensor], mul: float) -> Tensor:
+        scale = 2 ** (self.num_levels - 1)
+        n, c, h, w = x.shape
+        if mask is None:                         # raft_decoder.py:397-400
+            return ops.resize_bilinear(x, (scale * h, scale * w), mul=mul)
+        return ops.convex_upsample(x, mask, scale, x_mul=mul, mask_mul=0.25)
+
+
+@DECODERS.register_module()
+class RAFTDecoder(_RAFTDecoderBase):
+    """decoder/raft_decoder.py:299-457."""
+
+    def forward(self, feat1: Tensor, feat2: Tensor, flow: Tensor, h_feat: Tensor,
+                cxt_feat: Tensor) -> List[Tensor]:
+        pyramid = self.corr_block(feat1, feat2)
+        hx = _as_gru_buffer(h_feat, cxt_feat, self.h_channels + self.cxt_channels + 128)
+        scale = float(2 ** (self.num_levels - 1))
+        flow = flow.contiguous()
+        outs = []
+        for _ in range(self.iters):
+            hv, flow = self._step(pyramid, flow, hx)
+            mask = self.mask_pred(hv) if self.convex_upsample_flow else None   # 0.25 folded in
+            outs.append(self._upsample(flow, mask, scale))
+        return outs
+
+
+@DECODERS.register_module()
+class RAFTDecoderMask(_RAFTDecoderBase):
+    """decoder/raft_decoder_mask.py:21-208: RAFTDecoder + occlusion head."""
+
+    def __init__(self, *args, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self.occlusion_pred = XHead(self.h_channels, [256], 1, x='mask')
+
+    def forward(self, feat1: Tensor, feat2: Tensor, flow: Tensor, h_feat: Tensor,
+                cxt_feat: Tensor):
+        pyramid = self.corr_block(feat1, feat2)
+        hx = _as_gru_buffer(h_feat, cxt_feat, self.h_channels + self.cxt_channels + 128)
+        scale = float(2 ** (self.num_levels - 1))
+        flow = flow.contiguous()
+        flows, occs = [], []
+        for _ in range(self.iters):
+            hv, flow = self._step(pyramid, flow, hx)
+            occ = self.occlusion_pred.predict(self.occlusion_pred.layers[0](hv), act=ACT_SIGMOID)
+            mask = self.mask_pred(hv) if self.convex_upsample_flow else None
+            flows.append(self._upsample(flow, mask, scale))
+            occs.append(self._upsample(occ, mask, 1.0))
+        return flows, occs
+
+
 def _as_gru_buffer(h_feat: Tensor, cxt_feat: Tensor, total: int) -> Tensor:
     """[h | cxt | ...] buffer of ``total`` channels: zero-copy when h_feat / cxt_feat already
     are adjacent channel slices of such a buffer (SCFlowRefiner.extract_feat makes them so)."""

@@ -27,7 +27,7 @@ Tensor = torch.Tensor
 __all__ = ['PackedConv', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision',
            'get_conv_precision', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
            'instance_norm', 'group_norm_relu', 'linear', 'pose_update', 'reproject_flow',
-           'unproject_depth', 'resize_bilinear', 'avgpool2x2', 'copy_channels',
+           'unproject_depth', 'resize_bilinear', 'convex_upsample', 'avgpool2x2', 'copy_channels',
            'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_TANH', 'CONV_PLAIN', 'CONV_GRU_ZR',
            'CONV_GRU_Q']
 
@@ -404,6 +404,22 @@ def resize_bilinear(a: Tensor, out_hw: Tuple[int, int], mul: float = 1.0,
     _lib.check(_lib.load().scf_resize_bilinear(pa, _opt(b, 'b'), _dense(out, 'out'), n * c, h, w,
                                                ho, wo, float(mul), _stream()),
                'scf_resize_bilinear')
+    return out
+
+
+def convex_upsample(x: Tensor, mask: Tensor, scale: int = 8, x_mul: float = 1.0,
+                    mask_mul: float = 1.0, out: Optional[Tensor] = None) -> Tensor:
+    """RAFT convex up-sampling (raft_decoder.py:381-416): x (N,C,h,w), mask (N,9*scale^2,h,w)
+    -> (N,C,scale*h,scale*w)."""
+    px = _dense(x, 'x')
+    n, c, h, w = x.shape
+    if tuple(mask.shape) != (n, 9 * scale * scale, h, w):
+        raise _lib.ScflowHipError(f'mask has shape {tuple(mask.shape)}')
+    if out is None:
+        out = torch.empty((n, c, scale * h, scale * w), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().scf_convex_upsample(px, _dense(mask, 'mask'), _dense(out, 'out'), n, c,
+                                               h, w, scale, float(x_mul), float(mask_mul),
+                                               _stream()), 'scf_convex_upsample')
     return out
 
 

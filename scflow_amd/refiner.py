@@ -121,3 +121,52 @@ class SCFlowRefiner(HipModule):
         if return_loss:
             raise NotImplementedError('training is outside the hot path (SURVEY.md section 2)')
         return self.forward_single_pass(data, data_batch)
+
+
+class _FlowRefinerBase(HipModule):
+    """feature extraction + ``get_flow`` of the pose-free RAFT refiners
+    (models/refiner/raft_refiner_flow_mask.py:88-133, raft_refiner_flow.py).  Their pose step
+    is cv2 RANSAC-PnP on the CPU (models/utils/pose.py:203-249): out of scope, raises."""
+
+    def __init__(self, seperate_encoder: bool, cxt_channels: int, h_channels: int,
+                 cxt_encoder: dict, encoder: dict, decoder: dict, test_cfg: Optional[dict] = None,
+                 **ignored) -> None:
+        super().__init__()
+        self.seperate_encoder = seperate_encoder
+        if seperate_encoder:
+            self.render_encoder = build_encoder(encoder)
+            self.real_encoder = build_encoder(encoder)
+        else:
+            enc = build_encoder(encoder)
+            self.render_encoder = enc
+            self.real_encoder = enc
+        self.decoder = build_decoder(decoder)
+        self.context = build_encoder(cxt_encoder)
+        self.h_channels, self.cxt_channels = h_channels, cxt_channels
+        self.test_cfg = test_cfg or {}
+        self.test_iter_num = self.test_cfg.get('iters', self.decoder.iters)
+        self.eval()
+
+    extract_feat = SCFlowRefiner.extract_feat
+
+    def get_flow(self, render_images: Tensor, real_images: Tensor,
+                 init_flow: Optional[Tensor] = None):
+        """raft_refiner_flow_mask.py:120-133: init_flow defaults to zeros at 1/8 resolution."""
+        feat_render, feat_real, h_feat, cxt_feat = self.extract_feat(render_images, real_images)
+        if init_flow is None:
+            b, _, h, w = feat_real.shape
+            init_flow = torch.zeros((b, 2, h, w), dtype=torch.float32, device=feat_real.device)
+        return self.decoder(feat_render, feat_real, init_flow, h_feat, cxt_feat)
+
+    def solve_pose(self, *a, **k):
+        raise NotImplementedError('RANSAC-PnP (cv2) pose solve is outside the HIP hot path')
+
+
+@REFINERS.register_module()
+class RAFTRefinerFlowMask(_FlowRefinerBase):
+    """configs/refine_models/raft.py: RAFTDecoderMask -> (flows, occlusions)."""
+
+
+@REFINERS.register_module()
+class RAFTRefinerFlow(_FlowRefinerBase):
+    """RAFTDecoder -> flows."""

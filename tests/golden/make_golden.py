@@ -204,5 +204,51 @@ def main():
          label=inp['label'], **arrays)
 
 
+@torch.no_grad()
+def main_next():
+    """fixtures of the SURVEY 8(f) rows: pose-free RAFT decoders, cal_epe."""
+    from models.decoder.raft_decoder import RAFTDecoder
+    from models.decoder.raft_decoder_mask import RAFTDecoderMask
+    from models.utils.flow import cal_epe
+    torch.manual_seed(0)
+    kw = dict(net_type='Basic', num_levels=4, radius=4, iters=2,
+              corr_lookup_cfg=dict(align_corners=True), gru_type='SeqConv',
+              act_cfg=dict(type='ReLU'))
+    f1, f2 = rnd((2, 256, 8, 8), 71), rnd((2, 256, 8, 8), 72)
+    h = torch.tanh(rnd((2, 128, 8, 8), 73)); cxt = torch.relu(rnd((2, 128, 8, 8), 74))
+    flow0 = rnd((2, 2, 8, 8), 75, 0.5)
+    shapes = {}
+    for name, cls in (('raft_decoder', RAFTDecoder), ('raft_decoder_mask', RAFTDecoderMask)):
+        dec = cls(**dict(kw, corr_lookup_cfg=dict(align_corners=True))).eval()
+        sh = {'decoder.' + k: tuple(v.shape) for k, v in dec.state_dict().items()}
+        shapes[name] = {k: list(v) for k, v in sh.items()}
+        sd = fill_state_dict(sh, seed=6)
+        dec.load_state_dict({k[len('decoder.'):]: v for k, v in sd.items()}, strict=True)
+        out = dec(f1, f2, flow0.clone(), h, cxt)
+        if name == 'raft_decoder':
+            save(name + '.npz', SHIM, feat1=f1, feat2=f2, flow0=flow0, h=h, cxt=cxt,
+                 flows=torch.stack(out))
+        else:
+            save(name + '.npz', SHIM, feat1=f1, feat2=f2, flow0=flow0, h=h, cxt=cxt,
+                 flows=torch.stack(out[0]), occs=torch.stack(out[1]))
+    with open(os.path.join(HERE, 'raft_decoder_keys.json'), 'w') as f:
+        json.dump({'pinned_under': SHIM, 'shapes': shapes}, f, indent=0)
+    # cal_epe (pure torch)
+    tgt, pred = rnd((3, 2, 16, 16), 81, 3.0), rnd((3, 2, 16, 16), 82, 3.0)
+    tgt[0, :, :4] = 500.
+    mask = (rnd((3, 16, 16), 83) > -0.5).float()
+    res = {}
+    for red in ('mean', 'total_mean'):
+        acc = cal_epe(tgt.clone(), pred.clone(), mask, reduction=red)
+        for k, v in acc.items():
+            res[f'{red}_{k}'] = v
+    res['none'] = cal_epe(tgt.clone(), pred.clone(), mask, reduction='none')
+    res['mean_nomask'] = cal_epe(tgt.clone(), pred.clone(), None, reduction='mean')['mean']
+    save('cal_epe.npz', STUBS, tgt=tgt, pred=pred, mask=mask, **res)
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'next':
+        main_next()
+    else:
+        main()

@@ -97,3 +97,24 @@ def test_unsupported_options_fail_loudly():
     x = torch.zeros(1, 3, 64, 64)
     with pytest.raises(scflow_amd._lib.ScflowHipError):
         model.extract_feat(x, x)               # CPU tensors: no fallback
+
+
+def test_checkpoint_ingestion(tmp_path, golden_dir):
+    """mmflow -> SCFlow key mapping (tools/mmflow_ckpt_converter.py:30-35) and mmcv-style files."""
+    from scflow_amd.checkpoint import convert_mmflow_state_dict, load_checkpoint
+    model = scflow_amd.build_refiner(scflow_amd.scflow_model_cfg())
+    sd = scflow_amd.fill_state_dict({k: v.shape for k, v in model.state_dict().items()}, seed=2)
+    # an "mmflow" checkpoint: one encoder.* copy, DDP prefix, mmcv file layout
+    mm = {('module.' + k.replace('render_encoder', 'encoder')): v for k, v in sd.items()
+          if not k.startswith('real_encoder.')}
+    conv = convert_mmflow_state_dict({'encoder.conv1.weight': 1, 'decoder.gru.x': 2, 'context.a': 3})
+    assert set(conv) == {'real_encoder.conv1.weight', 'render_encoder.conv1.weight',
+                         'decoder.gru.x', 'context.a'}
+    path = os.path.join(tmp_path, 'ckpt.pth')
+    torch.save({'state_dict': mm, 'meta': {}}, path)
+    _ = model.render_encoder.packed
+    res = load_checkpoint(model, path, strict=True, from_mmflow=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert model.render_encoder.__dict__['_packed'] is None       # kernel-layout cache dropped
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, sd[k]), k

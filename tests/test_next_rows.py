@@ -1,0 +1,148 @@
+"""SURVEY.md section 8(f) 'next' rows: pose-free RAFT decoders (convex up-sampling) and the
+``cal_epe`` metric.  CPU: oracle / host code vs golden vectors from the reference sources.
+GPU (-m gpu): HIP path vs oracle and golden."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+import scflow_amd
+from scflow_amd.metrics import cal_epe
+
+DEV = 'cuda:0'
+
+
+def _g(golden_dir, name):
+    d = np.load(os.path.join(golden_dir, name))
+    return {k: (torch.from_numpy(d[k]) if d[k].dtype.kind in 'fi' and d[k].shape != () else d[k])
+            for k in d.files}
+
+
+def _close(a, b, atol, rtol=1e-5, what=''):
+    a, b = torch.as_tensor(a).detach().cpu(), torch.as_tensor(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    assert bool((err <= atol + rtol * b.abs()).all()), f'{what}: max err {float(err.max()):.3e}'
+
+
+def _sd(golden_dir, name):
+    shapes = json.load(open(os.path.join(golden_dir, 'raft_decoder_keys.json')))['shapes'][name]
+    return scflow_amd.fill_state_dict(shapes, seed=6)
+
+
+# ------------------------------------------------------------------ CPU
+def test_cal_epe_matches_reference(golden_dir):
+    g = _g(golden_dir, 'cal_epe.npz')
+    for impl in (oracle.cal_epe, cal_epe):
+        for red in ('mean', 'total_mean'):
+            acc = impl(g['tgt'].clone(), g['pred'].clone(), g['mask'], reduction=red)
+            for k, v in acc.items():
+                _close(v.float(), torch.as_tensor(np.asarray(g[f'{red}_{k}'])).float(), atol=1e-6, what=f'{red}_{k}')
+        _close(impl(g['tgt'].clone(), g['pred'].clone(), g['mask'], reduction='none'), g['none'], 1e-6)
+        _close(impl(g['tgt'].clone(), g['pred'].clone(), None, reduction='mean')['mean'],
+               torch.as_tensor(np.asarray(g['mean_nomask'])), 1e-6)
+    fixed = cal_epe(g['tgt'], g['pred'], g['mask'], fix_threshold_quirk=True)
+    assert float(fixed['5px'].max()) <= 1.0 + 1e-6       # a ratio of valid pixels, as intended
+
+
+def test_oracle_raft_decoders_golden(golden_dir):
+    g = _g(golden_dir, 'raft_decoder.npz')
+    with torch.no_grad():
+        out = oracle.raft_decoder(g['feat1'], g['feat2'], g['flow0'].clone(), g['h'], g['cxt'],
+                                  _sd(golden_dir, 'raft_decoder'), iters=2)
+    _close(torch.stack(out), g['flows'], atol=2e-4, what='RAFTDecoder flows')
+    g = _g(golden_dir, 'raft_decoder_mask.npz')
+    with torch.no_grad():
+        fl, oc = oracle.raft_decoder_mask(g['feat1'], g['feat2'], g['flow0'].clone(), g['h'],
+                                          g['cxt'], _sd(golden_dir, 'raft_decoder_mask'), iters=2)
+    _close(torch.stack(fl), g['flows'], atol=2e-4, what='RAFTDecoderMask flows')
+    _close(torch.stack(oc), g['occs'], atol=2e-5, what='RAFTDecoderMask occlusions')
+
+
+def test_raft_decoder_state_dict_layout(golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, 'raft_decoder_keys.json')))['shapes']
+    kw = dict(net_type='Basic', num_levels=4, radius=4, iters=12,
+              corr_lookup_cfg=dict(align_corners=True), gru_type='SeqConv', act_cfg=dict(type='ReLU'))
+    for name in ('RAFTDecoder', 'RAFTDecoderMask'):
+        dec = scflow_amd.build_decoder(dict(type=name, **kw))
+        key = 'raft_decoder' if name == 'RAFTDecoder' else 'raft_decoder_mask'
+        got = {'decoder.' + k: list(v.shape) for k, v in dec.state_dict().items()}
+        assert got == ref[key]
+
+
+def test_raft_refiner_config_builds():
+    path = '/root/reference/configs/refine_models/raft.py'
+    if not os.path.exists(path):
+        pytest.skip('reference checkout not present (GPU box)')
+    import runpy
+    cfg = runpy.run_path(path)['model']
+    m = scflow_amd.build_refiner(cfg)
+    assert type(m).__name__ == 'RAFTRefinerFlowMask' and m.decoder.iters == 12
+    assert m.test_iter_num == 12
+    with pytest.raises(NotImplementedError):
+        m.solve_pose()
+
+
+# ------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,c,h,w', [(2, 2, 8, 8), (1, 1, 12, 20), (1, 2, 32, 32), (1, 2, 60, 80)])
+def test_convex_upsample(n, c, h, w):
+    from scflow_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((n, c, h, w), generator=g) * 3
+    mask = torch.randn((n, 576, h, w), generator=g) * 4
+    want = oracle.convex_upsample(x, 0.25 * mask, 8, 9, x_mul=8.0)
+    got = ops.convex_upsample(x.to(DEV), mask.to(DEV), 8, x_mul=8.0, mask_mul=0.25)
+    _close(got, want, atol=2e-5, what='convex upsample')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['RAFTDecoder', 'RAFTDecoderMask'])
+def test_raft_decoders_gpu_golden(golden_dir, name):
+    key = 'raft_decoder' if name == 'RAFTDecoder' else 'raft_decoder_mask'
+    g = _g(golden_dir, key + '.npz')
+    dec = scflow_amd.build_decoder(dict(type=name, net_type='Basic', num_levels=4, radius=4, iters=2,
+                                        corr_lookup_cfg=dict(align_corners=True), gru_type='SeqConv',
+                                        act_cfg=dict(type='ReLU')))
+    sd = _sd(golden_dir, key)
+    dec.load_state_dict({k[len('decoder.'):]: v for k, v in sd.items()}, strict=True)
+    dec = dec.to(DEV)
+    d = lambda k: g[k].to(DEV)
+    out = dec(d('feat1'), d('feat2'), d('flow0'), d('h'), d('cxt'))
+    if name == 'RAFTDecoder':
+        _close(torch.stack(out), g['flows'], atol=3e-4, what='flows')
+    else:
+        _close(torch.stack(out[0]), g['flows'], atol=3e-4, what='flows')
+        _close(torch.stack(out[1]), g['occs'], atol=3e-5, what='occlusions')
+
+
+@pytest.mark.gpu
+def test_raft_flow_refiner_480x640_config5(golden_dir):
+    """BASELINE configs[4] route: 480x640, 12 iters on the pose-free RAFTDecoderMask path
+    (the SCFlow pose head is hard-wired to 256x256).  N=1 here; parity vs oracle."""
+    cfg = dict(type='RAFTRefinerFlowMask', cxt_channels=128, h_channels=128, seperate_encoder=False,
+               encoder=dict(type='RAFTEncoder', in_channels=3, out_channels=256, net_type='Basic',
+                            norm_cfg=dict(type='IN')),
+               cxt_encoder=dict(type='RAFTEncoder', in_channels=3, out_channels=256, net_type='Basic',
+                                norm_cfg=dict(type='BN')),
+               decoder=dict(type='RAFTDecoderMask', net_type='Basic', num_levels=4, radius=4, iters=3,
+                            corr_lookup_cfg=dict(align_corners=True), gru_type='SeqConv',
+                            act_cfg=dict(type='ReLU')), test_cfg=dict(iters=3))
+    m = scflow_amd.build_refiner(cfg)
+    sd = scflow_amd.fill_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed=9)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(3)
+    rend, real = torch.rand((1, 3, 480, 640), generator=g), torch.rand((1, 3, 480, 640), generator=g)
+    flows, occs = m.get_flow(rend.to(DEV), real.to(DEV))
+    assert flows[-1].shape == (1, 2, 480, 640) and occs[-1].shape == (1, 1, 480, 640)
+    with torch.no_grad():
+        fr, fl, hf, cf = oracle.extract_feat(rend, real, sd)
+        wf, wo = oracle.raft_decoder_mask(fr, fl, torch.zeros((1, 2, 60, 80)), hf, cf, sd, iters=3)
+    epe = oracle.end_point_error(flows[-1].cpu(), wf[-1])
+    assert epe <= 1e-3, f'EPE {epe:.2e}'
+    _close(occs[-1], wo[-1], atol=1e-4, what='occlusion')
