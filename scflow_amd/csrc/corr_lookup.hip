@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
       //      base are wave-uniform per step (scalar registers); per lane only a bounds test and
       //      a 32-bit offset remain.  8 queries (8*NSET loads) are in flight per wave.
       const float* lbase = p.lvl[lvl] + gq0 * msz;
-      constexpr int QU = 8;             // queries whose loads are in flight together
+      constexpr int QU = 4;             // queries whose loads are in flight together (x16 waves/CU)
       for (int qb = 0; qb < QB; qb += QU) {
         float v[QU][NSET];
         unsigned okmask = 0;

@@ -230,7 +230,7 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
     if gru_z is not None:
         pz_, _, _, _, _, sz_ = _nchw(gru_z, 'gru_z')
         d.gru_z, d.gru_z_nstride = pz_, sz_
-    # Short-chunk regime (few blocks -> smallest tile): with KC=8 the MFMA phase of a chunk
+    # Short-chunk regime (smallest tile, WM = WN = 1): with KC=8 the MFMA phase of a chunk
     # (T*4*WM*WN MFMAs of 64 cycles) is shorter than the L2 round trip its prefetch has to
     # hide.  Stage 32 channels per chunk instead when that packing fits (decided once per shape).
     if _CONV_PRECISION == 'f16x3' and pc.wp16 is not None:
@@ -242,7 +242,8 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
             lib = _lib.load()
             info = (C.c_int32 * 4)()
             use_alt = False
-            if lib.scf_conv2d_query(C.byref(d), info) == 0 and 0 <= info[3] * 64 < 6000:
+            if (lib.scf_conv2d_query(C.byref(d), info) == 0 and info[0] * info[1] == 1
+                    and 0 <= info[3] * 64 < 6000):
                 d.wp, d.KC = pc.wp_alt.data_ptr(), 32
                 use_alt = lib.scf_conv2d_query(C.byref(d), info) == 0
                 d.wp, d.KC = pc.wp.data_ptr(), pc.kc
