@@ -13,6 +13,7 @@ struct ConvK {
   int KH, KW, T, stride, pad_h, pad_w, KC, nchunk;
   int fc_log2, tiles_x, tiles_y, mblocks, PH, PW;
   int wvec;
+  int ksplit;                // 32-pixel tile, the 4 waves split the k-steps (small grids)
   float* out; long long out_ns;
   const float* bias; const float* scale; const float* shift;
   const float* res; long long res_ns;
@@ -49,55 +50,62 @@ __device__ __forceinline__ ConvEpi scf_conv_epi(const ConvK& p, int n) {
 // Order: /div, +bias, BN scale/shift, +residual, activation, GRU gating.
 typedef float scf_f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ void scf_conv_epilogue_frag(const ConvK& p, const ConvEpi& e,
-                                                       const scf_f32x16 acc, int co0, int half,
-                                                       int pix, bool use_div) {
+// one group of 4 consecutive channel rows cb..cb+3 of one pixel
+__device__ __forceinline__ void scf_conv_epilogue_group(const ConvK& p, const ConvEpi& e,
+                                                        const float (&acc)[4], int cb, int pix,
+                                                        bool use_div) {
   const bool need_aux = (p.mode == SCF_CONV_PLAIN) ? (e.res != nullptr) : true;
   const int hc = p.Cout >> 1;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int cb = co0 + 8 * g + 4 * half;     // rows cb .. cb+3
-    float aux0[4] = {0.f, 0.f, 0.f, 0.f}, aux1[4] = {0.f, 0.f, 0.f, 0.f};
-    if (need_aux) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = cb + q;
-        if (co < p.Cout) {
-          const int off = co * e.HWo + pix;
-          if (p.mode == SCF_CONV_PLAIN) {
-            aux0[q] = e.res[off];
-          } else if (p.mode == SCF_CONV_GRU_ZR) {
-            if (co >= hc) aux0[q] = e.gru_h[off - hc * e.HWo];
-          } else {
-            aux0[q] = e.gru_h[off];
-            aux1[q] = e.gru_z[off];
-          }
-        }
-      }
-    }
+  float aux0[4] = {0.f, 0.f, 0.f, 0.f}, aux1[4] = {0.f, 0.f, 0.f, 0.f};
+  if (need_aux) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int co = cb + q;
       if (co < p.Cout) {
         const int off = co * e.HWo + pix;
-        float v = acc[4 * g + q];
-        if (use_div) v = v / p.out_div;
-        if (p.bias) v += p.bias[co];
         if (p.mode == SCF_CONV_PLAIN) {
-          if (p.scale) v = v * p.scale[co] + p.shift[co];
-          v += aux0[q];
-          const int a = (p.act_split > 0 && co >= p.act_split) ? p.act2 : p.act;
-          e.out[off] = scf_apply_act(v, a);
+          aux0[q] = e.res[off];
         } else if (p.mode == SCF_CONV_GRU_ZR) {
-          const float sg = 1.f / (1.f + expf(-v));
-          if (co < hc) e.out[off] = sg;
-          else e.gru_aux[off - hc * e.HWo] = sg * aux0[q];
+          if (co >= hc) aux0[q] = e.gru_h[off - hc * e.HWo];
         } else {
-          const float qv = tanhf(v);
-          e.out[off] = (1.f - aux1[q]) * aux0[q] + aux1[q] * qv;
+          aux0[q] = e.gru_h[off];
+          aux1[q] = e.gru_z[off];
         }
       }
     }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int co = cb + q;
+    if (co < p.Cout) {
+      const int off = co * e.HWo + pix;
+      float v = acc[q];
+      if (use_div) v = v / p.out_div;
+      if (p.bias) v += p.bias[co];
+      if (p.mode == SCF_CONV_PLAIN) {
+        if (p.scale) v = v * p.scale[co] + p.shift[co];
+        v += aux0[q];
+        const int a = (p.act_split > 0 && co >= p.act_split) ? p.act2 : p.act;
+        e.out[off] = scf_apply_act(v, a);
+      } else if (p.mode == SCF_CONV_GRU_ZR) {
+        const float sg = 1.f / (1.f + expf(-v));
+        if (co < hc) e.out[off] = sg;
+        else e.gru_aux[off - hc * e.HWo] = sg * aux0[q];
+      } else {
+        const float qv = tanhf(v);
+        e.out[off] = (1.f - aux1[q]) * aux0[q] + aux1[q] * qv;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void scf_conv_epilogue_frag(const ConvK& p, const ConvEpi& e,
+                                                       const scf_f32x16 acc, int co0, int half,
+                                                       int pix, bool use_div) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    scf_conv_epilogue_group(p, e, v, co0 + 8 * g + 4 * half, pix, use_div);
   }
 }
 

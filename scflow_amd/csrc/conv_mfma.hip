@@ -206,6 +206,168 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
   }
 }
 
+// ---------------------------------------------------------------------------------
+// K-split variant for small grids (pose-head layers with 16^2..4^2 outputs, thin layers,
+// batch 1): block tile = 32 channels x ONE 32-pixel fragment, and the four waves split the
+// k-steps of every staged chunk instead of the pixels.  4x more blocks than the smallest
+// pixel-split tile and 4x less serial MFMA work per wave; partial sums are combined through
+// LDS in a fixed order (deterministic), each wave finalising 4 of the 16 accumulator rows.
+// ---------------------------------------------------------------------------------
+template <int KC>
+__global__ __launch_bounds__(256, 2) void conv_mfma_ksplit_kernel(ConvK p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int BM = 32, B4 = 8;
+  constexpr int PU_MAX = pu_max(KC, 1), WU_MAX = wu_max(KC);
+  constexpr int NCP = KC / 2;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, half = lane >> 5;
+
+  const int lb = scf_xcd_remap(blockIdx.x, gridDim.x);
+  const int mblk = lb % p.mblocks;
+  const int tile = lb / p.mblocks;
+  const int m0 = mblk * BM;
+
+  const int FC = 1 << p.fc_log2, FR = 32 >> p.fc_log2;
+  const int txi = tile % p.tiles_x;
+  const int t2 = tile / p.tiles_x;
+  const int tyi = t2 % p.tiles_y;
+  const int n = t2 / p.tiles_y;
+  const int ty0 = tyi * FR, tx0 = txi * FC;
+  const int s = p.stride;
+  const int iy0 = ty0 * s - p.pad_h, ix0 = tx0 * s - p.pad_w;
+  const int PH = p.PH, PW = p.PW, PHW = PH * PW;
+  const int T = p.T;
+
+  float* wl = lds;
+  float* pl = lds + KC * T * BM;
+  const int fr = l32 >> p.fc_log2, fc = l32 & (FC - 1);
+  const int boff = (fr * s) * PW + fc * s + half * PHW;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  const int HWin = p.H * p.W;
+  const float* in0n = p.in0 + (long long)n * p.in0_ns;
+  const float* in1n = p.in1 ? p.in1 + (long long)n * p.in1_ns : nullptr;
+  const float* wpn = p.wp + (long long)n * p.w_ns;
+  const int rows = KC * T;
+  const int PE = KC * PHW;
+  const int WE = rows * B4;
+
+  int toff[PU_MAX];
+#pragma unroll
+  for (int u = 0; u < PU_MAX; ++u) {
+    const int e = tid + u * 256;
+    int o = -1;
+    if (e < PE) {
+      const int cl = e / PHW, r = e - cl * PHW;
+      const int py = r / PW, px = r - py * PW;
+      const int iy = iy0 + py, ix = ix0 + px;
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) o = cl * HWin + iy * p.W + ix;
+    }
+    toff[u] = o;
+  }
+  float preg[PU_MAX];
+  f32x4 wreg[WU_MAX];
+  bool wfast = false;
+  const float* wsrc = nullptr;
+  long long krow0 = 0;
+
+  for (int chunk = -1; chunk < p.nchunk; ++chunk) {
+    if (chunk >= 0) {
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < PU_MAX; ++u) {
+        const int e = tid + u * 256;
+        if (e < PE) pl[e] = preg[u];
+      }
+      if (wfast) {
+#pragma unroll
+        for (int u = 0; u < WU_MAX; ++u) {
+          const int e = tid + u * 256;
+          if (e < WE) *reinterpret_cast<f32x4*>(wl + e * 4) = wreg[u];
+        }
+      } else {
+        for (int e = tid; e < rows * BM; e += 256) {
+          const int r = e / BM, c = e - r * BM;
+          float v = 0.f;
+          if (m0 + c < p.Mld && krow0 + r < p.Krows) v = wsrc[(long long)r * p.Mld + c];
+          wl[e] = v;
+        }
+      }
+      __syncthreads();
+    }
+    if (chunk + 1 < p.nchunk) {
+      const int c0 = (chunk + 1) * KC;
+      const float* base;
+      int nvalid;
+      if (c0 < p.C0) { base = in0n + (long long)c0 * HWin; nvalid = p.C0 - c0; }
+      else { base = in1n + (long long)(c0 - p.C0) * HWin; nvalid = p.Cin - c0; }
+      const unsigned limit = (unsigned)(nvalid < KC ? nvalid : KC) * (unsigned)HWin;
+#pragma unroll
+      for (int u = 0; u < PU_MAX; ++u) {
+        float v = 0.f;
+        if ((unsigned)toff[u] < limit) v = base[toff[u]];
+        preg[u] = v;
+      }
+      krow0 = (long long)(chunk + 1) * rows;
+      wsrc = wpn + krow0 * p.Mld + m0;
+      wfast = p.wvec && (m0 + BM <= p.Mld) && (krow0 + rows <= p.Krows);
+      if (wfast) {
+#pragma unroll
+        for (int u = 0; u < WU_MAX; ++u) {
+          const int e = tid + u * 256;
+          if (e < WE) {
+            const int r = e / B4, c4 = e - r * B4;
+            wreg[u] = *reinterpret_cast<const f32x4*>(wsrc + (long long)r * p.Mld + c4 * 4);
+          }
+        }
+      }
+    }
+    if (chunk >= 0) {
+      // wave w takes the k-steps  (tap*NCP + c) % 4 == w
+      for (int t = 0; t < T; ++t) {
+        const int ky = t / p.KW, kx = t - ky * p.KW;
+        const float* wt = wl + (t * KC + half) * BM + l32;
+        const float* pt = pl + ky * PW + kx + boff;
+#pragma unroll
+        for (int c = 0; c < NCP; ++c) {
+          if (((t * NCP + c) & 3) == wave)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[2 * c * BM], pt[2 * c * PHW], acc, 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- cross-wave reduction (fixed order) + epilogue: wave w finalises rows 4w..4w+3 ----
+  __syncthreads();
+  float* red = lds;                         // [4 waves][16 regs][64 lanes]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  float v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = 4 * wave + q;
+    v[q] = ((red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) +
+            red[(2 * 16 + r) * 64 + lane]) + red[(3 * 16 + r) * 64 + lane];
+  }
+  const int oy = ty0 + fr, ox = tx0 + fc;
+  if (oy < p.Ho && ox < p.Wo) {
+    const ConvEpi epi = scf_conv_epi(p, n);
+    scf_conv_epilogue_group(p, epi, v, m0 + 8 * wave + 4 * half, oy * p.Wo + ox, p.out_div != 1.0f);
+  }
+}
+
+template <int KC>
+static int launch_ksplit(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
+  hipLaunchKernelGGL((conv_mfma_ksplit_kernel<KC>), dim3(nblk), dim3(256), lds_bytes, st, k);
+  return scf_launch_status();
+}
+
 template <int WM, int WN>
 static int launch_conv(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
   if (k.KC == 32)
@@ -302,7 +464,7 @@ static int conv_plan(const scf_conv_desc* d, ConvPlan* plan) {
   }
   if (WM <= 2 && nblocks(WM, 2) >= 2048 && fits(WM, 2, nullptr)) WN = 2;
   size_t lds_bytes = 0;
-  if (!fits(WM, WN, &lds_bytes)) return SCF_EUNSUPPORTED;
+  const bool normal_fits = fits(WM, WN, &lds_bytes);
   k.mblocks = (frags_m + WM - 1) / WM;
   {
     const int TR = WN * 4 * FR;
@@ -313,6 +475,29 @@ static int conv_plan(const scf_conv_desc* d, ConvPlan* plan) {
   }
   plan->nblk = (long long)d->N * k.tiles_y * k.tiles_x * k.mblocks;
   if (plan->nblk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
+  // Still a small grid with the smallest pixel-split tile: split K across the 4 waves instead
+  // (32-pixel tiles, 4x the blocks).
+  // (a) truly small grids (fewer blocks than half the CUs: batch 1), or (b) the pixel-split
+  // tile does not fit this chunk size at all (KC = 32 on a strided layer) while the 32-pixel
+  // tile does.  Not for grids that already fill the chip: 4x the blocks means 4x the staging.
+  k.ksplit = 0;
+  if (!normal_fits && !(WM == 1 && WN == 1)) return SCF_EUNSUPPORTED;
+  if (WM == 1 && WN == 1 && (plan->nblk < 128 || !normal_fits)) {
+    const int PHk = (FR - 1) * k.stride + k.KH, PWk = (FC - 1) * k.stride + k.KW;
+    const long long PEk = (long long)k.KC * PHk * PWk, WEk = (long long)k.KC * k.T * 8;
+    size_t ldsk = ((size_t)k.KC * k.T * 32 + (size_t)PEk) * sizeof(float);
+    if (ldsk < 4 * 16 * 64 * sizeof(float)) ldsk = 4 * 16 * 64 * sizeof(float);
+    if ((PEk + 255) / 256 <= pu_max(k.KC, 1) && (WEk + 255) / 256 <= wu_max(k.KC) && ldsk <= 64 * 1024) {
+      k.ksplit = 1;
+      k.PH = PHk; k.PW = PWk;
+      k.tiles_y = (k.Ho + FR - 1) / FR;
+      k.tiles_x = (k.Wo + FC - 1) / FC;
+      k.mblocks = frags_m;
+      lds_bytes = ldsk;
+      plan->nblk = (long long)d->N * k.tiles_y * k.tiles_x * k.mblocks;
+    }
+  }
+  if (!normal_fits && !k.ksplit) return SCF_EUNSUPPORTED;
   plan->WM = WM; plan->WN = WN; plan->lds_bytes = lds_bytes;
   return SCF_OK;
 }
@@ -336,6 +521,11 @@ extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
   const long long nblk = pl.nblk;
   const size_t lds_bytes = pl.lds_bytes;
   hipStream_t st = scf_stream(stream);
+  if (k.ksplit) {
+    if (k.KC == 32) return launch_ksplit<32>(k, (int)nblk, lds_bytes, st);
+    if (k.KC == 8) return launch_ksplit<8>(k, (int)nblk, lds_bytes, st);
+    return launch_ksplit<2>(k, (int)nblk, lds_bytes, st);
+  }
 #define SCF_CASE(M, Nn) if (WM == M && WN == Nn) return launch_conv<M, Nn>(k, (int)nblk, lds_bytes, st);
   SCF_CASE(1, 1) SCF_CASE(1, 2) SCF_CASE(2, 1) SCF_CASE(2, 2)
   SCF_CASE(3, 1) SCF_CASE(4, 1)
@@ -358,7 +548,7 @@ extern "C" int scf_conv2d_query(const scf_conv_desc* d, int32_t* info) {
   info[0] = pl.WM;
   info[1] = pl.WN;
   info[2] = (int32_t)pl.nblk;
-  info[3] = pl.k.T * (pl.k.KC / 2) * pl.WM * pl.WN;
+  info[3] = pl.k.T * (pl.k.KC / 2) * pl.WM * pl.WN / (pl.k.ksplit ? 4 : 1);
   return SCF_OK;
 }
 
