@@ -122,8 +122,9 @@ def main():
         if rank == 0:
             print(f'[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using {world}',
                   file=sys.stderr)
-    torch.cuda.set_device(local)
-    device = f'cuda:{local}'
+    dev_index = local % torch.cuda.device_count()   # one process per GPU (torchrun LOCAL_RANK)
+    torch.cuda.set_device(dev_index)
+    device = f'cuda:{dev_index}'
 
     model, sd = build_model(args.iters, device)
     batch = make_batch(args.batch, seed=1000 + rank, device=device)

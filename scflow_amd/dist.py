@@ -38,9 +38,9 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
-            torch.cuda.set_device(local)
+            backend = os.environ.get('SCF_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -61,11 +61,11 @@ def gather_poses(rotation: torch.Tensor, translation: torch.Tensor, total: Optio
     packed = torch.zeros((per, 12), dtype=torch.float32, device=rotation.device)
     packed[:n_r, :9] = rotation.reshape(n_r, 9)
     packed[:n_r, 9:] = translation
-    out = torch.empty((world * per, 12), dtype=torch.float32, device=rotation.device)
-    dist.all_gather_into_tensor(out, packed)
+    parts = [torch.empty_like(packed) for _ in range(world)]
+    dist.all_gather(parts, packed)
     rows = []
     for r in range(world):
         lo, hi = shard_range(total, r, world)
-        rows.append(out[r * per:r * per + (hi - lo)])
+        rows.append(parts[r][:hi - lo])
     allp = torch.cat(rows, 0)
     return allp[:, :9].reshape(-1, 3, 3), allp[:, 9:]
