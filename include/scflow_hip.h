@@ -73,6 +73,15 @@ int scf_corr_build(const float* feat1, const float* feat2, float* const* levels,
 int scf_corr_lookup(const float* const* levels, const float* flow, float* out,
                     int N, int h, int w, int r, int L, scf_stream_t stream);
 
+/* Same pair with a lookup-friendly LEVEL-0 layout (level0_tiled = 1): every query's level-0
+ * map is stored in 8x4-float tiles of one 128-byte line each (needs w % 8 == 0, h % 4 == 0), so
+ * a (2r+2)^2 window touches ~6.9 lines instead of 2r+2 = 10 full rows.  Levels >= 1 keep the
+ * reference layout.  level0_tiled = 0 is exactly scf_corr_build / scf_corr_lookup.        */
+int scf_corr_build_ex(const float* feat1, const float* feat2, float* const* levels, int N, int C,
+                      int h, int w, int L, int level0_tiled, scf_stream_t stream);
+int scf_corr_lookup_ex(const float* const* levels, const float* flow, float* out, int N, int h,
+                       int w, int r, int L, int level0_tiled, scf_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * Direct convolution as implicit GEMM on MFMA with fused epilogue.
  * replaces every torch conv2d (+bias +BN(eval) +residual +activation +GRU gating) on
@@ -111,6 +120,9 @@ typedef struct scf_conv_desc {
                                            [(chunk16*T + tap)*2 + k8][plane hi|lo][Mld][8] halves;
                                            non-NULL selects the 3xMFMA fp16 kernel where the
                                            shape fits (fp32-class accuracy)   */
+  int32_t out_tile8x4;                  /* 1: store every output plane in 8(x) x 4(y)-float tiles
+                                           of 128 B (tile-major, row-major inside) instead of
+                                           row-major; needs Wo % 8 == 0 and Ho % 4 == 0          */
 } scf_conv_desc;
 
 int scf_conv2d(const scf_conv_desc* desc, scf_stream_t stream);

@@ -40,6 +40,7 @@ class ConvDesc(C.Structure):
         ('gru_aux', _fp), ('gru_aux_nstride', C.c_int64),
         ('gru_z', _fp), ('gru_z_nstride', C.c_int64),
         ('wp_f16', _fp),
+        ('out_tile8x4', C.c_int32),
     ]
 
 
@@ -52,6 +53,10 @@ SIGNATURES = {
                                  C.c_int, _fp]),
     'scf_corr_lookup': (C.c_int, [C.POINTER(_fp), _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, _fp]),
+    'scf_corr_build_ex': (C.c_int, [_fp, _fp, C.POINTER(_fp), C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, _fp]),
+    'scf_corr_lookup_ex': (C.c_int, [C.POINTER(_fp), _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, _fp]),
     'scf_conv2d': (C.c_int, [C.POINTER(ConvDesc), _fp]),
     'scf_conv2d_query': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int32)]),
     'scf_instance_norm': (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int, C.c_float, C.c_int, _fp]),

@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
   for (int j = 0; j < WN; ++j) {
     const int oy = ty0 + (wave * WN + j) * FR + fr, ox = tx0 + fc;
     const bool pok = oy < p.Ho && ox < p.Wo;
-    const int pix = oy * p.Wo + ox;
+    const int pix = p.out_tile ? (((oy >> 2) * (p.Wo >> 3) + (ox >> 3)) * 32 + (oy & 3) * 8 + (ox & 7))
+                               : oy * p.Wo + ox;
     if (pok) {
 #pragma unroll
       for (int i = 0; i < WM; ++i)
@@ -358,7 +359,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_ksplit_kernel(ConvK p) {
   const int oy = ty0 + fr, ox = tx0 + fc;
   if (oy < p.Ho && ox < p.Wo) {
     const ConvEpi epi = scf_conv_epi(p, n);
-    scf_conv_epilogue_group(p, epi, v, m0 + 8 * wave + 4 * half, oy * p.Wo + ox, p.out_div != 1.0f);
+    const int pixk = p.out_tile ? (((oy >> 2) * (p.Wo >> 3) + (ox >> 3)) * 32 + (oy & 3) * 8 + (ox & 7))
+                                : oy * p.Wo + ox;
+    scf_conv_epilogue_group(p, epi, v, m0 + 8 * wave + 4 * half, pixk, p.out_div != 1.0f);
   }
 }
 
@@ -403,6 +406,7 @@ static int conv_plan(const scf_conv_desc* d, ConvPlan* plan) {
   if (d->mode == SCF_CONV_GRU_ZR && (!d->gru_h || !d->gru_aux || (d->Cout & 1))) return SCF_EINVAL;
   if (d->mode == SCF_CONV_GRU_Q && (!d->gru_h || !d->gru_z)) return SCF_EINVAL;
   if ((d->scale == nullptr) != (d->shift == nullptr)) return SCF_EINVAL;
+  if (d->out_tile8x4 && (d->mode != SCF_CONV_PLAIN || d->res)) return SCF_EUNSUPPORTED;
 
   ConvK& k = plan->k;
   k.in0 = d->in0; k.in1 = d->C1 > 0 ? d->in1 : nullptr;
@@ -414,6 +418,7 @@ static int conv_plan(const scf_conv_desc* d, ConvPlan* plan) {
   if (k.Ho <= 0 || k.Wo <= 0) return SCF_EINVAL;
   k.wp = d->wp; k.w_ns = d->w_nstride; k.Mld = d->Mld; k.Cout = d->Cout;
   k.wp16 = d->wp_f16;
+  k.out_tile = d->out_tile8x4;
   k.KH = d->KH; k.KW = d->KW; k.T = d->KH * d->KW; k.stride = d->stride;
   k.pad_h = d->pad_h; k.pad_w = d->pad_w; k.KC = d->KC;
   k.nchunk = (k.Cin + k.KC - 1) / k.KC;
@@ -505,7 +510,7 @@ static int conv_plan(const scf_conv_desc* d, ConvPlan* plan) {
 // split-fp16 eligibility: shared weights, >= 16 input channels, spatial kernel (dense 1x1
 // layers stay on the fp32 KC=32 kernel), shape fits the fp16 kernel's staging budget.
 static bool want_f16x3(const scf_conv_desc* d) {
-  return d->wp_f16 != nullptr && d->w_nstride == 0 && d->KH * d->KW > 1 && d->C0 + d->C1 >= 16;
+  return d->wp_f16 != nullptr && !d->out_tile8x4 && d->w_nstride == 0 && d->KH * d->KW > 1 && d->C0 + d->C1 >= 16;
 }
 
 extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
@@ -557,10 +562,14 @@ extern "C" int scf_conv2d_query(const scf_conv_desc* d, int32_t* info) {
 // level0 = conv2d(1x1) with per-sample weights feat1[n] ([C][hw] is already the packed
 // [K][M] layout), divided by sqrt(C); levels 1.. = cascaded 2x2 average pools.
 // ---------------------------------------------------------------------------------
-extern "C" int scf_corr_build(const float* feat1, const float* feat2, float* const* levels, int N,
-                              int C, int h, int w, int L, scf_stream_t stream) {
+extern "C" int scf_avgpool2x2_tiled_in(const float* x, float* out, int64_t planes, int Hin, int Win,
+                                       scf_stream_t stream);
+
+extern "C" int scf_corr_build_ex(const float* feat1, const float* feat2, float* const* levels, int N,
+                                 int C, int h, int w, int L, int level0_tiled, scf_stream_t stream) {
   if (!feat1 || !feat2 || !levels || N <= 0 || C <= 0 || h <= 0 || w <= 0 || L <= 0) return SCF_EINVAL;
   if (L > SCF_MAX_LEVELS) return SCF_EUNSUPPORTED;
+  if (level0_tiled && ((w & 7) || (h & 3))) return SCF_EUNSUPPORTED;
   for (int l = 0; l < L; ++l)
     if (!levels[l]) return SCF_EINVAL;
   const int hw = h * w;
@@ -573,15 +582,23 @@ extern "C" int scf_corr_build(const float* feat1, const float* feat2, float* con
   d.out = levels[0]; d.out_nstride = (int64_t)hw * hw;
   d.out_div = sqrtf((float)C);
   d.act = SCF_ACT_NONE; d.mode = SCF_CONV_PLAIN;
+  d.out_tile8x4 = level0_tiled ? 1 : 0;
   int rc = scf_conv2d(&d, stream);
   if (rc != SCF_OK) return rc;
   int lh = h, lw = w;
   for (int l = 1; l < L; ++l) {
     if (lh < 2 || lw < 2) return SCF_EINVAL;
-    rc = scf_avgpool2x2(levels[l - 1], levels[l], (int64_t)N * hw, lh, lw, stream);
+    rc = (l == 1 && level0_tiled)
+             ? scf_avgpool2x2_tiled_in(levels[0], levels[1], (int64_t)N * hw, lh, lw, stream)
+             : scf_avgpool2x2(levels[l - 1], levels[l], (int64_t)N * hw, lh, lw, stream);
     if (rc != SCF_OK) return rc;
     lh /= 2;
     lw /= 2;
   }
   return SCF_OK;
+}
+
+extern "C" int scf_corr_build(const float* feat1, const float* feat2, float* const* levels, int N,
+                              int C, int h, int w, int L, scf_stream_t stream) {
+  return scf_corr_build_ex(feat1, feat2, levels, N, C, h, w, L, 0, stream);
 }

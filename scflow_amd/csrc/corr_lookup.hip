@@ -10,12 +10,13 @@
 // Work decomposition (wave64):
 //   block = 256 threads = 4 waves handling the same 32 consecutive queries;
 //   wave w owns pyramid level w (levels w, w+4, ... when L > 4).
-//   load phase : the wave's 64 lanes sweep the 32 x (2r+2)^2 footprint elements in
-//                element order -> every wave-load covers contiguous rows of one or two
-//                queries' maps (coalesced 40-B runs), exactly the algorithmic bytes are
-//                requested, out-of-map taps become 0 (zero padding);
-//                values are parked in LDS at an ODD per-query stride (bank-conflict
-//                free for the transposed read that follows).
+//   load phase : per query, the wave's 64 lanes fetch the (2r+2)^2 footprint elements in
+//                element order with global_load_lds (memory -> LDS, no VGPR staging, so all
+//                64 gathers of a wave are in flight at once); exactly the algorithmic bytes
+//                are requested; each query's window lands contiguously in LDS at an ODD
+//                per-query stride (bank-conflict free for the transposed read that follows);
+//                out-of-map taps: the staging area is zero-filled first and their lanes are
+//                switched off (zero padding without fetching anything).
 //   compute    : lane = (query, half); the two half-waves split the x-offsets; bilinear
 //                weights are per (query, level) constants because offsets are integers.
 //   store      : out[n, k, y, x]; each half-wave writes 32 consecutive queries of one
@@ -30,8 +31,65 @@ struct LookupParams {
   float* out;
   int N, h, w, L;
   int woff[4];            // LDS offset (floats) of each wave's staging region
+  int l0_tiled;           // level 0 stored in 8x4-float tiles (scf_corr_build_ex)
   long long total_q;
 };
+
+// window read-back + bilinear blend + store for one (wave, level).  SMALL: the level's whole
+// map is staged (stride S) and out-of-map taps are masked here; otherwise the zero-padded
+// (2r+2)^2 footprint is staged and read unmasked.
+template <int R, bool SMALL>
+__device__ __forceinline__ void lookup_emit(const float* f, int lw, int lh, int x0, int y0,
+                                            bool flat_x, bool flat_y, float nw, float ne, float sw,
+                                            float se, int half, char* obase, unsigned lane_off,
+                                            size_t cs, bool qvalid) {
+  constexpr int FW = 2 * R + 2, D = 2 * R + 1;
+  const int i0 = half ? (D + 1) / 2 : 0;
+  const int i1 = half ? D : (D + 1) / 2;
+  int rowoff[FW];
+  unsigned rowok = 0;
+  if constexpr (SMALL) {
+#pragma unroll
+    for (int r = 0; r < FW; ++r) {
+      const int yy = flat_y ? 0 : y0 + r;
+      const bool ok = (unsigned)yy < (unsigned)lh;
+      rowoff[r] = ok ? yy * lw : 0;
+      rowok |= (ok ? 1u : 0u) << r;
+    }
+  }
+  auto column = [&](int c, float (&col)[FW]) {
+    if constexpr (SMALL) {
+      const int xx = flat_x ? 0 : x0 + c;
+      const bool cok = (unsigned)xx < (unsigned)lw;
+      const float* fc = f + (cok ? xx : 0);
+#pragma unroll
+      for (int r = 0; r < FW; ++r) {
+        float v = fc[rowoff[r]];
+        asm volatile("" : "+v"(v));      // keep the (always in-range) read unconditional
+        col[r] = (cok && ((rowok >> r) & 1u)) ? v : 0.f;
+      }
+    } else {
+      const float* fc = f + c;
+#pragma unroll
+      for (int r = 0; r < FW; ++r) col[r] = fc[r * FW];
+    }
+  };
+  float colA[FW], colB[FW];
+  column(i0, colA);
+  for (int i = i0; i < i1; ++i) {
+    column(i + 1, colB);
+    if (qvalid) {
+      char* oc = obase + (size_t)(i * D) * cs;      // wave-uniform channel base (SGPRs)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const float v = colA[j] * nw + colB[j] * ne + colA[j + 1] * sw + colB[j + 1] * se;
+        *(float*)(oc + (size_t)j * cs + lane_off) = v;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < FW; ++r) colA[r] = colB[r];
+  }
+}
 
 template <int R>
 __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
@@ -41,7 +99,10 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
   constexpr int D = 2 * R + 1;        // window width
   constexpr int QB = 32;              // queries per block
   constexpr int NSET = (FS + 63) / 64;  // wave-loads per query footprint
-  extern __shared__ float lds_fp[];
+  constexpr int AUX_NT = 2;           // nt: every footprint byte is read exactly once
+  extern __shared__ __attribute__((aligned(16))) float lds_fp[];
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
@@ -49,11 +110,12 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
   const long long gq0 = (long long)blockIdx.x * QB;
   const int hw = p.h * p.w;
   const int ktot = p.L * D * D;
+  const int n0 = (int)(gq0 / hw);     // sample of the block's first query (block-uniform)
 
   // this lane's query (both half-waves hold the same 32 queries)
   const long long gq = gq0 + l32;
   const bool qvalid = gq < p.total_q;
-  int n = 0, q = 0;
+  int n = n0, q = 0;
   float qx = 0.f, qy = 0.f;
   if (qvalid) {
     n = (int)(gq / hw);
@@ -63,6 +125,9 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
     qx = (float)x + fl[0];
     qy = (float)y + fl[hw];
   }
+  // byte offset of this lane's query from the block-uniform base out[n0, k, 0, 0]
+  const unsigned lane_off = (unsigned)(((long long)(n - n0) * ktot * hw + q) * 4);
+  const size_t cs = (size_t)hw * 4;   // channel stride in bytes
   float* myfp = lds_fp + p.woff[wave];
 
   // footprint element(s) this lane fetches for EVERY query: e = lane + 64*s
@@ -77,7 +142,7 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
 
   for (int lvl = wave; lvl < p.L; lvl += 4) {
     const int lh = p.lh[lvl], lw = p.lw[lvl];
-    const long long msz = (long long)lh * lw;
+    const int msz = lh * lw;
     // Reference quirk at degenerate sizes: coordinates are normalised with max(size-1, 1) and
     // grid_sample(align_corners=True) de-normalises with (size-1), so along a size-1 axis
     // EVERY tap lands exactly on index 0 (corr_lookup.py:64-67).
@@ -91,130 +156,78 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
     if (!(cy == cy)) cy = -30000.f;
     const float x0f = floorf(cx), y0f = floorf(cy);
     const int x0 = (int)x0f - R, y0 = (int)y0f - R;
+    const char* lbase = (const char*)(p.lvl[lvl] + gq0 * msz);
 
+    // Staging is LDS-DMA (global_load_lds_dword): memory -> LDS without passing through VGPRs,
+    // so ALL of a wave's gathers are in flight together (a register-staged version was
+    // latency-bound at 4 queries in flight per wave).  One query per step: the map base and the
+    // window origin are wave-uniform (readlane -> SGPRs), each lane adds a 32-bit offset.
+    //
     // Small maps (coarse levels: the whole map is no larger than the window footprint) are
     // staged whole instead of as a zero-padded footprint: fewer LDS bytes per query (which is
-    // what lets 4 blocks share a CU and the grid finish in ONE wave of blocks at batch 32) and
-    // the maps of the block's 32 queries are one contiguous, fully coalesced run in memory.
+    // what lets 4 blocks share a CU and the grid finish in ONE wave of blocks at batch 32).
     const bool small = (lh <= FW && lw <= FW);
-    const int S = small ? ((int)msz | 1) : FSP;       // odd per-query LDS stride
+    const bool tiled = lvl == 0 && p.l0_tiled;
+    const int S = small ? (msz | 1) : FSP;            // odd per-query LDS stride
     if (small) {
-      const float* lbase = p.lvl[lvl] + gq0 * msz;
-      const int tot = nq * (int)msz;
-      for (int f0 = 0; f0 < tot; f0 += 64 * 8) {
-        float v[8];
+#pragma unroll 4
+      for (int qq = 0; qq < QB; ++qq) {
+        if (qq < nq) {
+          const char* mb = lbase + (size_t)qq * msz * 4;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int f = f0 + u * 64 + lane;
-          v[u] = __builtin_nontemporal_load(lbase + (f < tot ? f : 0));
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int f = f0 + u * 64 + lane;
-          if (f < tot) {
-            const int qq = f / (int)msz;
-            myfp[qq * S + (f - qq * (int)msz)] = v[u];
-          }
+          for (int s = 0; s < NSET; ++s)
+            if (lane + 64 * s < msz)
+              __builtin_amdgcn_global_load_lds((gptr_t)(mb + (unsigned)(lane + 64 * s) * 4u),
+                                               (lptr_t)(myfp + qq * S + 64 * s), 4, 0, AUX_NT);
         }
       }
     } else {
-    // ---- load phase: one query per step, lanes <-> footprint elements.  x0/y0 and the map
-      //      base are wave-uniform per step (scalar registers); per lane only a bounds test and
-      //      a 32-bit offset remain.  8 queries (8*NSET loads) are in flight per wave.
-      const float* lbase = p.lvl[lvl] + gq0 * msz;
-      constexpr int QU = 4;             // queries whose loads are in flight together (x16 waves/CU)
-      for (int qb = 0; qb < QB; qb += QU) {
-        float v[QU][NSET];
-        unsigned okmask = 0;
-        // branch-free: out-of-map / out-of-range taps read element 0 of a valid map and are
-        // zeroed afterwards, so all QU*NSET loads issue back to back.
-#pragma unroll
-        for (int u = 0; u < QU; ++u) {
-          const int qq = qb + u;
+      // zero padding = zero-filled staging area + lanes of out-of-map taps switched off
+      for (int i = lane; i < QB * FSP / 4; i += 64)
+        ((float __attribute__((ext_vector_type(4)))*)myfp)[i] = 0.f;
+      __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): zeros land before the DMA data
+#pragma unroll 4
+      for (int qq = 0; qq < QB; ++qq) {
+        if (qq < nq) {
           const int sx0 = flat_x ? 0 : __builtin_amdgcn_readlane(x0, qq);
           const int sy0 = flat_y ? 0 : __builtin_amdgcn_readlane(y0, qq);
-          const bool qok = qq < nq;
-          const float* mb = lbase + (qok ? (long long)qq * msz : 0);
+          const char* mb = lbase + (size_t)qq * msz * 4;
 #pragma unroll
           for (int s = 0; s < NSET; ++s) {
             const int xx = flat_x ? 0 : sx0 + ecol[s];
             const int yy = flat_y ? 0 : sy0 + erow[s];
-            const bool ok = qok && (unsigned)xx < (unsigned)lw && (unsigned)yy < (unsigned)lh &&
+            const bool ok = (unsigned)xx < (unsigned)lw && (unsigned)yy < (unsigned)lh &&
                             (NSET * 64 == FS || lane + 64 * s < FS);
-            const int idx = ok ? yy * lw + xx : 0;
-            v[u][s] = __builtin_nontemporal_load(mb + idx);
-            okmask |= (ok ? 1u : 0u) << (u * NSET + s);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < QU; ++u) {
-#pragma unroll
-          for (int s = 0; s < NSET; ++s) {
-            const float val = ((okmask >> (u * NSET + s)) & 1u) ? v[u][s] : 0.f;
-            if (NSET * 64 == FS || lane + 64 * s < FS) myfp[(qb + u) * FSP + lane + 64 * s] = val;
+            // 24-bit multiplies (full rate); lanes with out-of-range xx/yy are switched off
+            const int lin = tiled ? __mul24(yy >> 2, lw * 4) + ((xx >> 3) << 5) + ((yy & 3) << 3) + (xx & 7)
+                                  : __mul24(yy, lw) + xx;
+            if (ok)
+              __builtin_amdgcn_global_load_lds((gptr_t)(mb + (unsigned)lin * 4u),
+                                               (lptr_t)(myfp + qq * FSP + 64 * s), 4, 0, AUX_NT);
           }
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();  // same-wave LDS ops complete in order
+    __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the DMA data is in LDS
+    __builtin_amdgcn_wave_barrier();
 
-    // ---- compute + store: lane = (query, half); halves split the x-offsets ----
+    // ---- read back + blend + store: lane = (query, half); halves split the x-offsets ----
     const float tx = cx - x0f, ty = cy - y0f;
     const float wx0 = (x0f + 1.f) - cx, wy0 = (y0f + 1.f) - cy;   // grid_sample: (x_se - x)
     const float nw = wx0 * wy0, ne = tx * wy0, sw = wx0 * ty, se = tx * ty;
     const float* f = myfp + l32 * S;
-    const int i0 = half ? (D + 1) / 2 : 0;
-    const int i1 = half ? D : (D + 1) / 2;
-    // column c of the window (x = x0 + c), rows 0..FW-1
-    int rowoff[FW];
-    unsigned rowok = 0;
-    if (small) {
-#pragma unroll
-      for (int r = 0; r < FW; ++r) {
-        const int yy = flat_y ? 0 : y0 + r;
-        const bool ok = (unsigned)yy < (unsigned)lh;
-        rowoff[r] = ok ? yy * lw : 0;
-        rowok |= (ok ? 1u : 0u) << r;
-      }
-    }
-    auto column = [&](int c, float (&col)[FW]) {
-      if (small) {
-        const int xx = flat_x ? 0 : x0 + c;
-        const bool cok = (unsigned)xx < (unsigned)lw;
-        const int xo = cok ? xx : 0;
-#pragma unroll
-        for (int r = 0; r < FW; ++r) {
-          const float v = f[rowoff[r] + xo];
-          col[r] = (cok && ((rowok >> r) & 1u)) ? v : 0.f;
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < FW; ++r) col[r] = f[r * FW + c];
-      }
-    };
-    float colA[FW], colB[FW];
-    column(i0, colA);
-    // uniform channel base + per-lane query offset: the compiler keeps the base in SGPRs
-    float* obase = p.out + ((long long)n * ktot + (long long)lvl * D * D) * hw + q;
-    for (int i = i0; i < i1; ++i) {
-      column(i + 1, colB);
-      if (qvalid) {
-        float* oc = obase + (long long)(i * D) * hw;
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-          const float v = colA[j] * nw + colB[j] * ne + colA[j + 1] * sw + colB[j + 1] * se;
-          oc[(long long)j * hw] = v;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < FW; ++r) colA[r] = colB[r];
-    }
+    char* obase = (char*)p.out + ((size_t)n0 * ktot + (size_t)lvl * D * D) * cs;
+    if (small)
+      lookup_emit<R, true>(f, lw, lh, x0, y0, flat_x, flat_y, nw, ne, sw, se, half, obase, lane_off, cs, qvalid);
+    else
+      lookup_emit<R, false>(f, lw, lh, x0, y0, flat_x, flat_y, nw, ne, sw, se, half, obase, lane_off, cs, qvalid);
     __builtin_amdgcn_wave_barrier();
   }
 }
 
-extern "C" int scf_corr_lookup(const float* const* levels, const float* flow, float* out, int N,
-                               int h, int w, int r, int L, scf_stream_t stream) {
+extern "C" int scf_corr_lookup_ex(const float* const* levels, const float* flow, float* out, int N,
+                                  int h, int w, int r, int L, int level0_tiled, scf_stream_t stream) {
+  if (level0_tiled && ((w & 7) || (h & 3) || h <= 2 * r + 2 || w <= 2 * r + 2)) return SCF_EUNSUPPORTED;
   if (!levels || !flow || !out || N <= 0 || h <= 0 || w <= 0 || L <= 0) return SCF_EINVAL;
   if (L > SCF_MAX_LEVELS) return SCF_EUNSUPPORTED;
   LookupParams p;
@@ -231,6 +244,7 @@ extern "C" int scf_corr_lookup(const float* const* levels, const float* flow, fl
   p.out = out;
   p.N = N; p.h = h; p.w = w; p.L = L;
   p.total_q = (long long)N * h * w;
+  p.l0_tiled = level0_tiled ? 1 : 0;
   const int nblk = (int)scf_cdiv(p.total_q, 32);
   // per-wave LDS region: wave w stages levels w, w+4, ...; a level whose whole map fits in the
   // (2r+2)^2 footprint is staged whole (stride map|1), otherwise as a footprint (stride FS|1)
@@ -244,7 +258,7 @@ extern "C" int scf_corr_lookup(const float* const* levels, const float* flow, fl
       need = need > 32 * S ? need : 32 * S;
     }
     p.woff[wv] = off;
-    off += need;
+    off += (need + 3) & ~3;                            // 16-byte aligned regions (b128 zero fill)
   }
   const size_t lds = (size_t)off * sizeof(float);
   switch (r) {
@@ -255,4 +269,9 @@ extern "C" int scf_corr_lookup(const float* const* levels, const float* flow, fl
     default: return SCF_EUNSUPPORTED;
   }
   return scf_launch_status();
+}
+
+extern "C" int scf_corr_lookup(const float* const* levels, const float* flow, float* out, int N,
+                               int h, int w, int r, int L, scf_stream_t stream) {
+  return scf_corr_lookup_ex(levels, flow, out, N, h, w, r, L, 0, stream);
 }

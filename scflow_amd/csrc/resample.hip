@@ -78,6 +78,37 @@ extern "C" int scf_avgpool2x2(const float* x, float* out, int64_t planes, int Hi
   return scf_launch_status();
 }
 
+// level 1 from a level 0 stored in 8x4-float tiles (scf_corr_build_ex): same arithmetic, the
+// four taps of a window always lie in one tile row pair.
+__global__ __launch_bounds__(256) void avgpool2x2_tiled_in_kernel(const float* __restrict__ x,
+                                                                  float* __restrict__ out,
+                                                                  long long planes, int Hin, int Win,
+                                                                  int Ho, int Wo) {
+  const long long total = planes * Ho * Wo;
+  const int tw = Win >> 3;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(idx % Wo);
+    const long long t = idx / Wo;
+    const int oy = (int)(t % Ho);
+    const long long pl = t / Ho;
+    const int y = 2 * oy, xx = 2 * ox;
+    const float* s = x + pl * Hin * Win + ((y >> 2) * tw + (xx >> 3)) * 32 + (y & 3) * 8 + (xx & 7);
+    out[idx] = (((s[0] + s[1]) + s[8]) + s[9]) * 0.25f;
+  }
+}
+
+extern "C" int scf_avgpool2x2_tiled_in(const float* x, float* out, int64_t planes, int Hin, int Win,
+                                       scf_stream_t stream) {
+  if (!x || !out || planes <= 0 || Hin < 4 || Win < 8 || (Win & 7) || (Hin & 3)) return SCF_EINVAL;
+  const int Ho = Hin / 2, Wo = Win / 2;
+  const long long total = (long long)planes * Ho * Wo;
+  const int grid = (int)(scf_cdiv(total, 256) < 16384 ? scf_cdiv(total, 256) : 16384);
+  hipLaunchKernelGGL(avgpool2x2_tiled_in_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), x, out,
+                     (long long)planes, Hin, Win, Ho, Wo);
+  return scf_launch_status();
+}
+
 __global__ __launch_bounds__(256) void copy_strided_kernel(const float* __restrict__ src,
                                                            long long sns, float* __restrict__ dst,
                                                            long long dns, int N, long long count) {

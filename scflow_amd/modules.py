@@ -217,8 +217,10 @@ class CorrelationPyramid(HipModule):
         super().__init__()
         self.num_levels = num_levels
 
-    def forward(self, feat1: Tensor, feat2: Tensor) -> List[Tensor]:
-        return ops.corr_build(feat1, feat2, self.num_levels)
+    def forward(self, feat1: Tensor, feat2: Tensor, level0_tiled: bool = False) -> List[Tensor]:
+        """``level0_tiled`` (decoder-internal): level 0 in the lookup's 8x4-tile layout; the
+        default is the reference's row-major pyramid."""
+        return ops.corr_build(feat1, feat2, self.num_levels, level0_tiled=level0_tiled)
 
 
 class CorrLookup(HipModule):
@@ -231,8 +233,18 @@ class CorrLookup(HipModule):
             raise NotImplementedError('HIP CorrLookup: bilinear / zeros / align_corners=True')
         self.r = radius
 
-    def forward(self, corr_pyramid: Sequence[Tensor], flow: Tensor) -> Tensor:
-        return ops.corr_lookup(corr_pyramid, flow, self.r)
+    def forward(self, corr_pyramid: Sequence[Tensor], flow: Tensor,
+                level0_tiled: bool = False) -> Tensor:
+        return ops.corr_lookup(corr_pyramid, flow, self.r, level0_tiled=level0_tiled)
+
+
+def _use_tiled_level0(feat: Tensor, radius: int) -> bool:
+    """the decoders keep the pyramid to themselves, so they are free to pick the tiled level-0
+    layout whenever the map shape allows it (SCF_LOOKUP_TILED=0 forces the reference layout)."""
+    import os
+    if os.environ.get('SCF_LOOKUP_TILED', '1') == '0':
+        return False
+    return ops.tiled_level0_ok(feat.shape[-2], feat.shape[-1], radius)
 
 
 class MotionEncoder(HipModule):
@@ -452,7 +464,8 @@ class SCFlowDecoder(HipModule):
         dev = depth.device
         f32 = dict(dtype=torch.float32, device=dev)
 
-        pyramid = self.corr_block(feat_render, feat_real)                          # :172
+        tiled = _use_tiled_level0(feat_render, self.radius)
+        pyramid = self.corr_block(feat_render, feat_real, level0_tiled=tiled)      # :172
         # GRU buffer [h | cxt | motion(126) | flow(2)]; reuse the caller's if it already is one
         hx = _as_gru_buffer(h_feat, cxt_feat, hc + cc + 128)
         rot, trans = ref_rotation.contiguous(), ref_translation.contiguous()
@@ -463,7 +476,7 @@ class SCFlowDecoder(HipModule):
         heads = torch.empty((n, 512, h, w), **f32)
         for _ in range(self.iters):
             flow_lr = ops.resize_bilinear(flow, (h, w), mul=1.0 / scale)           # :196-197
-            corr = self.corr_lookup(pyramid, flow_lr)                              # :198
+            corr = self.corr_lookup(pyramid, flow_lr, level0_tiled=tiled)          # :198
             self.encoder(corr, flow_lr, out=hx[:, hc + cc:])                       # :206
             hv = self.gru.forward_inplace(hx)                                      # :207-208
             ops.conv2d(self.packed, hv, out=heads, act=ACT_RELU)
@@ -517,10 +530,10 @@ class _RAFTDecoderBase(HipModule):
         if self.mask_channels != 9 * (2 ** (num_levels - 1)) ** 2:
             raise NotImplementedError('convex up-sampling kernel: 9 x 8 x 8 mask (radius 4, 4 levels)')
 
-    def _step(self, pyramid, flow, hx):
+    def _step(self, pyramid, flow, hx, tiled=False):
         """one update: lookup, motion encoder, GRU (in place in hx), flow += delta."""
         hc, cc = self.h_channels, self.cxt_channels
-        corr = self.corr_lookup(pyramid, flow)
+        corr = self.corr_lookup(pyramid, flow, level0_tiled=tiled)
         self.encoder(corr, flow, out=hx[:, hc + cc:])
         hv = self.gru.forward_inplace(hx)
         d_flow = self.flow_pred(hv)
@@ -541,13 +554,14 @@ class RAFTDecoder(_RAFTDecoderBase):
 
     def forward(self, feat1: Tensor, feat2: Tensor, flow: Tensor, h_feat: Tensor,
                 cxt_feat: Tensor) -> List[Tensor]:
-        pyramid = self.corr_block(feat1, feat2)
+        tiled = _use_tiled_level0(feat1, self.radius)
+        pyramid = self.corr_block(feat1, feat2, level0_tiled=tiled)
         hx = _as_gru_buffer(h_feat, cxt_feat, self.h_channels + self.cxt_channels + 128)
         scale = float(2 ** (self.num_levels - 1))
         flow = flow.contiguous()
         outs = []
         for _ in range(self.iters):
-            hv, flow = self._step(pyramid, flow, hx)
+            hv, flow = self._step(pyramid, flow, hx, tiled)
             mask = self.mask_pred(hv) if self.convex_upsample_flow else None   # 0.25 folded in
             outs.append(self._upsample(flow, mask, scale))
         return outs
@@ -563,13 +577,14 @@ class RAFTDecoderMask(_RAFTDecoderBase):
 
     def forward(self, feat1: Tensor, feat2: Tensor, flow: Tensor, h_feat: Tensor,
                 cxt_feat: Tensor):
-        pyramid = self.corr_block(feat1, feat2)
+        tiled = _use_tiled_level0(feat1, self.radius)
+        pyramid = self.corr_block(feat1, feat2, level0_tiled=tiled)
         hx = _as_gru_buffer(h_feat, cxt_feat, self.h_channels + self.cxt_channels + 128)
         scale = float(2 ** (self.num_levels - 1))
         flow = flow.contiguous()
         flows, occs = [], []
         for _ in range(self.iters):
-            hv, flow = self._step(pyramid, flow, hx)
+            hv, flow = self._step(pyramid, flow, hx, tiled)
             occ = self.occlusion_pred.predict(self.occlusion_pred.layers[0](hv), act=ACT_SIGMOID)
             mask = self.mask_pred(hv) if self.convex_upsample_flow else None
             flows.append(self._upsample(flow, mask, scale))

@@ -255,10 +255,25 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
 
 
 # ----------------------------------------------------- correlation volume
+def tiled_level0_ok(h: int, w: int, radius: int = 4) -> bool:
+    """whether the 8x4-tiled level-0 layout (scf_corr_build_ex) applies to an h x w map."""
+    return w % 8 == 0 and h % 4 == 0 and h > 2 * radius + 2 and w > 2 * radius + 2
+
+
+def untile_level0(level0: Tensor) -> Tensor:
+    """torch view-shuffle of a tiled level 0 back to the reference's row-major layout (tests /
+    debugging only; the hot path never untiles)."""
+    q, _, h, w = level0.shape
+    return (level0.reshape(q, h // 4, w // 8, 4, 8).permute(0, 1, 3, 2, 4).reshape(q, 1, h, w)
+            .contiguous())
+
+
 def corr_build(feat1: Tensor, feat2: Tensor, num_levels: int = 4,
-               out: Optional[List[Tensor]] = None) -> List[Tensor]:
+               out: Optional[List[Tensor]] = None, level0_tiled: bool = False) -> List[Tensor]:
     """CorrelationPyramid.forward (raft_decoder.py:35-58) -> list of
-    (N*h*w, 1, h>>l, w>>l)."""
+    (N*h*w, 1, h>>l, w>>l).  ``level0_tiled`` stores level 0 in 128-byte 8x4 tiles for the
+    lookup (same values, permuted inside each query's map; pass the same flag to
+    ``corr_lookup``)."""
     p1 = _dense(feat1, 'feat1')
     p2 = _dense(feat2, 'feat2')
     if feat1.shape != feat2.shape or feat1.dim() != 4:
@@ -268,13 +283,14 @@ def corr_build(feat1: Tensor, feat2: Tensor, num_levels: int = 4,
         out = [torch.empty((n * h * w, 1, h >> l, w >> l), dtype=torch.float32,
                            device=feat1.device) for l in range(num_levels)]
     arr = (C.c_void_p * num_levels)(*[_dense(t, 'level') for t in out])
-    _lib.check(_lib.load().scf_corr_build(p1, p2, arr, n, c, h, w, num_levels, _stream()),
+    _lib.check(_lib.load().scf_corr_build_ex(p1, p2, arr, n, c, h, w, num_levels,
+                                             1 if level0_tiled else 0, _stream()),
                'scf_corr_build')
     return out
 
 
 def corr_lookup(pyramid: Sequence[Tensor], flow: Tensor, radius: int = 4,
-                out: Optional[Tensor] = None) -> Tensor:
+                out: Optional[Tensor] = None, level0_tiled: bool = False) -> Tensor:
     """CorrLookup.forward (corr_lookup.py:102-136) -> (N, L*(2r+1)^2, h, w)."""
     pf = _dense(flow, 'flow')
     n, two, h, w = flow.shape
@@ -292,8 +308,9 @@ def corr_lookup(pyramid: Sequence[Tensor], flow: Tensor, radius: int = 4,
     if _LOOKUP_EVENTS is not None:      # bench.py: per-launch HIP events on the launch stream
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    _lib.check(_lib.load().scf_corr_lookup(arr, pf, _dense(out, 'out'), n, h, w, radius, L,
-                                           _stream()), 'scf_corr_lookup')
+    _lib.check(_lib.load().scf_corr_lookup_ex(arr, pf, _dense(out, 'out'), n, h, w, radius, L,
+                                              1 if level0_tiled else 0, _stream()),
+               'scf_corr_lookup')
     if ev is not None:
         ev[1].record()
         _LOOKUP_EVENTS.append(ev)

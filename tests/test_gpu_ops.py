@@ -72,6 +72,37 @@ def test_corr_lookup_golden_and_channel_order(golden_dir):
     assert int(got[0, :81, 8, 8].argmax()) == 9 * 1 + 6      # x_off=-3 -> a=1, y_off=+2 -> b=6
 
 
+@pytest.mark.parametrize('n,c,h,w', [(2, 32, 16, 16), (1, 64, 12, 24), (2, 256, 32, 32), (1, 20, 20, 40)])
+def test_corr_tiled_level0_is_a_permutation_and_looks_up_identically(n, c, h, w):
+    """scf_corr_build_ex / scf_corr_lookup_ex with level0_tiled=1: level 0 is the reference map
+    bit-for-bit after untiling, levels >= 1 are bit-identical, and the lookup output is
+    bit-identical to the reference-layout lookup (same loads, same arithmetic order)."""
+    assert ops.tiled_level0_ok(h, w, 4)
+    f1, f2 = rnd((n, c, h, w), 11).to(DEV), rnd((n, c, h, w), 12).to(DEV)
+    ref = ops.corr_build(f1, f2, 4)
+    til = ops.corr_build(f1, f2, 4, level0_tiled=True)
+    assert torch.equal(ops.untile_level0(til[0]), ref[0])
+    for a, b in zip(til[1:], ref[1:]):
+        assert torch.equal(a, b)
+    flow = rnd((n, 2, h, w), 13, 4.0)
+    flow[0, :, 0, 0] = torch.tensor([-40., 3.])
+    flow[0, :, 1, 1] = torch.tensor([float(w), float(h)])
+    flow[0, :, 2, 2] = torch.tensor([1e9, -1e9])
+    flow[0, :, 3, 3] = torch.tensor([-3.5, -2.25])
+    flow = flow.to(DEV)
+    want = ops.corr_lookup(ref, flow, 4)
+    got = ops.corr_lookup(til, flow, 4, level0_tiled=True)
+    assert torch.equal(got, want)
+    close(got, oracle.corr_lookup([p.cpu() for p in ref], flow.cpu().clone(), 4), atol=5e-5,
+          what='tiled lookup vs oracle')
+
+
+def test_corr_tiled_rejects_unaligned_maps():
+    f = rnd((1, 8, 10, 12), 1).to(DEV)
+    with pytest.raises(Exception):
+        ops.corr_build(f, f, 2, level0_tiled=True)
+
+
 def test_lookup_of_constant_volume_is_partition_of_unity():
     """size-independent property: a constant map sampled bilinearly gives the constant for
     fully in-range windows and 0 far outside."""

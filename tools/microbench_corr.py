@@ -32,6 +32,12 @@ for N in (1, 8, 32, 64):
     medc, mnc = timeit(lambda: ops.corr_lookup(pyr, flow, 4, out=out), n=20, flush=flush)
     gb = 2904 * N * h * w / 1e3
     print(f'N={N:3d} lookup warm {med:7.1f} us ({gb / med:7.1f} GB/s)  cold {medc:7.1f} us ({gb / medc:7.1f} GB/s)')
+    pyt = ops.corr_build(f1, f2, 4, level0_tiled=True)
+    medt, _ = timeit(lambda: ops.corr_lookup(pyt, flow, 4, out=out, level0_tiled=True))
+    medtc, _ = timeit(lambda: ops.corr_lookup(pyt, flow, 4, out=out, level0_tiled=True), n=20, flush=flush)
+    print(f'N={N:3d} tiled  warm {medt:7.1f} us ({gb / medt:7.1f} GB/s)  cold {medtc:7.1f} us ({gb / medtc:7.1f} GB/s)')
+    med, mn = timeit(lambda: ops.corr_build(f1, f2, 4, out=pyt, level0_tiled=True), n=20)
+    print(f'N={N:3d} build tiled {med:7.1f} us')
     med, mn = timeit(lambda: ops.corr_build(f1, f2, 4, out=pyr), n=20)
     print(f'N={N:3d} build  {med:7.1f} us  {2 * 256 * (h * w) ** 2 * N / med / 1e6:6.2f} TFLOP/s')
     del flush
