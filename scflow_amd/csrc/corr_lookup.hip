@@ -44,8 +44,12 @@ __device__ __forceinline__ void lookup_emit(const float* f, int lw, int lh, int 
                                             float se, int half, char* obase, unsigned lane_off,
                                             size_t cs, bool qvalid) {
   constexpr int FW = 2 * R + 2, D = 2 * R + 1;
-  const int i0 = half ? (D + 1) / 2 : 0;
-  const int i1 = half ? D : (D + 1) / 2;
+  // halves split the D x-offsets: half 0 takes columns [0, NI), half 1 [NI, D); the loop itself
+  // is wave-uniform (half 1's last step is masked when D is odd) so that store bases stay in
+  // SGPRs and only a 32-bit per-lane offset goes into the address VGPR.
+  constexpr int NI = (D + 1) / 2;
+  const int i0 = half ? NI : 0;
+  const unsigned lane_off2 = lane_off + (unsigned)((size_t)i0 * D * cs);
   int rowoff[FW];
   unsigned rowok = 0;
   if constexpr (SMALL) {
@@ -57,11 +61,12 @@ __device__ __forceinline__ void lookup_emit(const float* f, int lw, int lh, int 
       rowok |= (ok ? 1u : 0u) << r;
     }
   }
-  auto column = [&](int c, float (&col)[FW]) {
+  const float* fbase = f + (SMALL ? 0 : i0);
+  auto column = [&](int it, float (&col)[FW]) {
     if constexpr (SMALL) {
-      const int xx = flat_x ? 0 : x0 + c;
+      const int xx = flat_x ? 0 : x0 + i0 + it;
       const bool cok = (unsigned)xx < (unsigned)lw;
-      const float* fc = f + (cok ? xx : 0);
+      const float* fc = fbase + (cok ? xx : 0);
 #pragma unroll
       for (int r = 0; r < FW; ++r) {
         float v = fc[rowoff[r]];
@@ -69,29 +74,29 @@ __device__ __forceinline__ void lookup_emit(const float* f, int lw, int lh, int 
         col[r] = (cok && ((rowok >> r) & 1u)) ? v : 0.f;
       }
     } else {
-      const float* fc = f + c;
 #pragma unroll
-      for (int r = 0; r < FW; ++r) col[r] = fc[r * FW];
+      for (int r = 0; r < FW; ++r) col[r] = fbase[r * FW + it];      // immediate offsets
     }
   };
-  float colA[FW], colB[FW];
-  column(i0, colA);
-  for (int i = i0; i < i1; ++i) {
-    column(i + 1, colB);
-    if (qvalid) {
-      char* oc = obase + (size_t)(i * D) * cs;      // wave-uniform channel base (SGPRs)
+  float col[2][FW];
+  column(0, col[0]);
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    float (&cA)[FW] = col[it & 1];
+    float (&cB)[FW] = col[(it & 1) ^ 1];
+    column(it + 1, cB);
+    if (qvalid && (2 * NI == D || it < NI - 1 || !half)) {
+      char* oc = obase + (size_t)(it * D) * cs;      // wave-uniform channel base (SGPRs)
 #pragma unroll
       for (int j = 0; j < D; ++j) {
-        const float v = colA[j] * nw + colB[j] * ne + colA[j + 1] * sw + colB[j + 1] * se;
-        *(float*)(oc + (size_t)j * cs + lane_off) = v;
+        const float v = cA[j] * nw + cB[j] * ne + cA[j + 1] * sw + cB[j + 1] * se;
+        *(float*)(oc + (size_t)j * cs + lane_off2) = v;
       }
     }
-#pragma unroll
-    for (int r = 0; r < FW; ++r) colA[r] = colB[r];
   }
 }
 
-template <int R>
+template <int R, bool TILED0>
 __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
   constexpr int FW = 2 * R + 2;       // footprint width
   constexpr int FS = FW * FW;         // footprint size
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
     // staged whole instead of as a zero-padded footprint: fewer LDS bytes per query (which is
     // what lets 4 blocks share a CU and the grid finish in ONE wave of blocks at batch 32).
     const bool small = (lh <= FW && lw <= FW);
-    const bool tiled = lvl == 0 && p.l0_tiled;
+    const bool tiled = TILED0 && lvl == 0;
     const int S = small ? (msz | 1) : FSP;            // odd per-query LDS stride
     if (small) {
 #pragma unroll 4
@@ -185,25 +190,50 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
       // zero padding = zero-filled staging area + lanes of out-of-map taps switched off
       for (int i = lane; i < QB * FSP / 4; i += 64)
         ((float __attribute__((ext_vector_type(4)))*)myfp)[i] = 0.f;
+      // Per query (computed once, vectorised over the 32 queries in lanes): a bit mask of the
+      // in-map window columns (bits 0..FW-1) and rows (bits 16..16+FW-1), and the element
+      // offset of the window origin.  Per (lane, set) constants: that element's column/row bit
+      // pair and its offset from the origin.  A tap is fetched iff both of its bits are set, and
+      // (row-major maps) its address is scalar origin + per-lane constant: 2 VALU per gather.
+      auto span = [&](int o, int n) -> unsigned {      // window positions c with 0 <= o + c < n
+        const int lo = min(max(-o, 0), FW), hi = max(min(n - o, FW), 0);
+        return hi > lo ? (1u << hi) - (1u << lo) : 0u;
+      };
+      const unsigned qmask = (flat_x ? (1u << FW) - 1u : span(x0, lw)) |
+                             ((flat_y ? (1u << FW) - 1u : span(y0, lh)) << 16);
+      const int qorg = (flat_y ? 0 : y0 * lw) + (flat_x ? 0 : x0);
+      unsigned ebits[NSET], eoff[NSET];
+#pragma unroll
+      for (int s = 0; s < NSET; ++s) {
+        const bool live = NSET * 64 == FS || lane + 64 * s < FS;
+        ebits[s] = live ? (1u << ecol[s]) | (1u << (16 + erow[s])) : 0x80000000u;
+        eoff[s] = (unsigned)(((flat_y ? 0 : erow[s] * lw) + (flat_x ? 0 : ecol[s])) * 4);
+      }
       __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): zeros land before the DMA data
 #pragma unroll 4
       for (int qq = 0; qq < QB; ++qq) {
         if (qq < nq) {
-          const int sx0 = flat_x ? 0 : __builtin_amdgcn_readlane(x0, qq);
-          const int sy0 = flat_y ? 0 : __builtin_amdgcn_readlane(y0, qq);
+          const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)qmask, qq);
           const char* mb = lbase + (size_t)qq * msz * 4;
+          if (!TILED0 || !tiled) {
+            const char* org = mb + (long long)__builtin_amdgcn_readlane(qorg, qq) * 4;
 #pragma unroll
-          for (int s = 0; s < NSET; ++s) {
-            const int xx = flat_x ? 0 : sx0 + ecol[s];
-            const int yy = flat_y ? 0 : sy0 + erow[s];
-            const bool ok = (unsigned)xx < (unsigned)lw && (unsigned)yy < (unsigned)lh &&
-                            (NSET * 64 == FS || lane + 64 * s < FS);
-            // 24-bit multiplies (full rate); lanes with out-of-range xx/yy are switched off
-            const int lin = tiled ? __mul24(yy >> 2, lw * 4) + ((xx >> 3) << 5) + ((yy & 3) << 3) + (xx & 7)
-                                  : __mul24(yy, lw) + xx;
-            if (ok)
-              __builtin_amdgcn_global_load_lds((gptr_t)(mb + (unsigned)lin * 4u),
-                                               (lptr_t)(myfp + qq * FSP + 64 * s), 4, 0, AUX_NT);
+            for (int s = 0; s < NSET; ++s)
+              if ((ebits[s] & m) == ebits[s])
+                __builtin_amdgcn_global_load_lds((gptr_t)(org + eoff[s]),
+                                                 (lptr_t)(myfp + qq * FSP + 64 * s), 4, 0, AUX_NT);
+          } else {
+            const int sx0 = __builtin_amdgcn_readlane(x0, qq);
+            const int sy0 = __builtin_amdgcn_readlane(y0, qq);
+#pragma unroll
+            for (int s = 0; s < NSET; ++s) {
+              const int xx = sx0 + ecol[s], yy = sy0 + erow[s];
+              // 24-bit multiply (full rate); lanes with out-of-range xx/yy are switched off
+              const int lin = __mul24(yy >> 2, lw * 4) + ((xx >> 3) << 5) + ((yy & 3) << 3) + (xx & 7);
+              if ((ebits[s] & m) == ebits[s])
+                __builtin_amdgcn_global_load_lds((gptr_t)(mb + (unsigned)lin * 4u),
+                                                 (lptr_t)(myfp + qq * FSP + 64 * s), 4, 0, AUX_NT);
+            }
           }
         }
       }
@@ -261,13 +291,18 @@ extern "C" int scf_corr_lookup_ex(const float* const* levels, const float* flow,
     off += (need + 3) & ~3;                            // 16-byte aligned regions (b128 zero fill)
   }
   const size_t lds = (size_t)off * sizeof(float);
+#define SCF_LK(R_)                                                                                 \
+  case R_:                                                                                         \
+    if (level0_tiled)                                                                              \
+      hipLaunchKernelGGL((corr_lookup_kernel<R_, true>), dim3(nblk), dim3(256), lds, scf_stream(stream), p);  \
+    else                                                                                           \
+      hipLaunchKernelGGL((corr_lookup_kernel<R_, false>), dim3(nblk), dim3(256), lds, scf_stream(stream), p); \
+    break;
   switch (r) {
-    case 4: hipLaunchKernelGGL(corr_lookup_kernel<4>, dim3(nblk), dim3(256), lds, scf_stream(stream), p); break;
-    case 3: hipLaunchKernelGGL(corr_lookup_kernel<3>, dim3(nblk), dim3(256), lds, scf_stream(stream), p); break;
-    case 2: hipLaunchKernelGGL(corr_lookup_kernel<2>, dim3(nblk), dim3(256), lds, scf_stream(stream), p); break;
-    case 1: hipLaunchKernelGGL(corr_lookup_kernel<1>, dim3(nblk), dim3(256), lds, scf_stream(stream), p); break;
+    SCF_LK(4) SCF_LK(3) SCF_LK(2) SCF_LK(1)
     default: return SCF_EUNSUPPORTED;
   }
+#undef SCF_LK
   return scf_launch_status();
 }
 
