@@ -120,6 +120,11 @@ typedef struct scf_conv_desc {
                                            [(chunk16*T + tap)*2 + k8][plane hi|lo][Mld][8] halves;
                                            non-NULL selects the 3xMFMA fp16 kernel where the
                                            shape fits (fp32-class accuracy)   */
+  const float* wp_a4;                   /* optional second packing of the same weights for the
+                                           LDS-DMA kernel (stride 1): [chunk][tap][g][h][Mld_a4][4]
+                                           floats, channel = chunk*8G + 8g + 2s + h at float s      */
+  int32_t a4_groups;                    /* G in {1,2,4}: 8G channels per staged chunk              */
+  int32_t a4_mld;                       /* Cout rounded up to 32                                    */
   int32_t out_tile8x4;                  /* 1: store every output plane in 8(x) x 4(y)-float tiles
                                            of 128 B (tile-major, row-major inside) instead of
                                            row-major; needs Wo % 8 == 0 and Ho % 4 == 0          */

@@ -40,6 +40,9 @@ class ConvDesc(C.Structure):
         ('gru_aux', _fp), ('gru_aux_nstride', C.c_int64),
         ('gru_z', _fp), ('gru_z_nstride', C.c_int64),
         ('wp_f16', _fp),
+        ('wp_a4', _fp),
+        ('a4_groups', C.c_int32),
+        ('a4_mld', C.c_int32),
         ('out_tile8x4', C.c_int32),
     ]
 

@@ -1,0 +1,257 @@
+// Stride-1 fp32 convolution, second generation of the implicit-GEMM kernel in conv_mfma.hip
+// (same GEMM view, same v_mfma_f32_32x32x2_f32 arithmetic and k order, same fused epilogue):
+//
+//   * operands are staged by LDS-DMA (global_load_lds): memory -> LDS without passing through
+//     VGPRs, into a DOUBLE-BUFFERED chunk area -- chunk c+1 streams in while chunk c is on the
+//     matrix cores, one workgroup barrier per chunk, no staging registers;
+//   * the k dimension inside a chunk is interleaved four-deep: channel c = 8g + 2s + h sits at
+//     float s of cell (g, h), for the weights   [tap][g][h][cout][4]
+//                              and for the patch [g][h][PH][PW][4],
+//     so ONE ds_read_b128 per fragment feeds four consecutive MFMA k-steps (lane half h takes
+//     channel 2s+h at step s, exactly the A[l&31][l>>5] / B[l>>5][l&31] operand layout);
+//   * those reads are software-pipelined one (tap, group) step ahead of the MFMAs.
+// The MFMA phase alone runs at 138-147 TFLOP/s from LDS (tools/probes/mfma_loop_probe.hip) vs
+// 122-131 for the b32 / read-then-use loop.
+//
+// Zero padding: the patch areas are zero-filled once per block and out-of-image positions are
+// never written afterwards (the gather table is chunk-invariant).
+#include "scf_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#include "conv_kernels.h"
+
+#define SCF_DMA_PU 16   // patch gathers per thread per chunk (256 * 16 floats)
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+// LDS-DMA, 16 / 4 bytes per lane: lane l's data lands at lds_base + l*16 (l*4).  M0 carries
+// the wave-uniform LDS base; it is compiler-reserved, so it is saved and restored in the same
+// statement.  The compiler does not count these loads: the caller waits (vmcnt) itself.
+__device__ __forceinline__ void dma_b128(const void* g, unsigned lds_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void dma_b32(const void* g, unsigned lds_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(lds_base) : "memory");
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int BM = WM * 32;
+  constexpr int NFRAG = WN * 4;
+  constexpr int PU = SCF_DMA_PU;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, half = lane >> 5;
+
+  const int lb = scf_xcd_remap(blockIdx.x, gridDim.x);
+  const int mblk = lb % p.mblocks;
+  const int tile = lb / p.mblocks;
+  const int m0 = mblk * BM;
+
+  const int FC = 1 << p.fc_log2, FR = 32 >> p.fc_log2, TR = NFRAG * FR;
+  const int txi = tile % p.tiles_x;
+  const int t2 = tile / p.tiles_x;
+  const int tyi = t2 % p.tiles_y;
+  const int n = t2 / p.tiles_y;
+  const int ty0 = tyi * TR, tx0 = txi * FC;
+  const int iy0 = ty0 - p.pad_h, ix0 = tx0 - p.pad_w;
+  const int PW = p.PW, PHW = p.PH * p.PW;
+  const int T = p.T, G = p.G4, KC = 8 * G;
+  const int NIT = T * G;               // (tap, group) steps per chunk, 4 k-steps each
+  const int WF4 = NIT * 2 * BM;        // weight float4 per chunk
+  const int PE = KC * PHW;             // patch floats per chunk
+  const int bufsz = WF4 * 4 + PE;      // floats per buffer (multiple of 4)
+
+  // ---- zero both patch areas (padding positions stay zero for the whole kernel) ----
+  for (int b = 0; b < 2; ++b) {
+    f32x4* z = reinterpret_cast<f32x4*>(lds + b * bufsz + WF4 * 4);
+    for (int i = tid; i < PE / 4; i += 256) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // ---- gather table: LDS patch float e = tid + 256u <-> (group g, half h, py, px, s) ----
+  const int HWin = p.H * p.W;
+  int toff[PU];
+#pragma unroll
+  for (int u = 0; u < PU; ++u) {
+    const int e = tid + u * 256;
+    int o = -1;
+    if (e < PE) {
+      const int s = e & 3, q = e >> 2;
+      const int gh = q / PHW, r = q - gh * PHW;
+      const int py = r / PW, px = r - py * PW;
+      const int c = 8 * (gh >> 1) + 2 * s + (gh & 1);
+      const int iy = iy0 + py, ix = ix0 + px;
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) o = c * HWin + iy * p.W + ix;
+    }
+    toff[u] = o;
+  }
+
+  const int fr = l32 >> p.fc_log2, fc = l32 & (FC - 1);
+  int boff[WN];                        // float4 index of this lane's pixel, fragment j, tap (0,0)
+#pragma unroll
+  for (int j = 0; j < WN; ++j) boff[j] = ((wave * WN + j) * FR + fr) * PW + fc + half * PHW;
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const float* in0n = p.in0 + (long long)n * p.in0_ns;
+  const float* in1n = p.in1 ? p.in1 + (long long)n * p.in1_ns : nullptr;
+  const long long wrow = (long long)p.Mld4 * 4;      // floats per (chunk, tap, g, h) weight row
+
+  auto stage = [&](int chunk, int b) {
+    float* wb = lds + b * bufsz;
+    float* pb = wb + WF4 * 4;
+    // patch: one dword per lane, lane-linear in LDS
+    const int c0 = chunk * KC;
+    const float* base;
+    int nvalid;
+    if (c0 < p.C0) { base = in0n + (long long)c0 * HWin; nvalid = p.C0 - c0; }
+    else { base = in1n + (long long)(c0 - p.C0) * HWin; nvalid = p.Cin - c0; }
+    const bool tail = nvalid < KC;
+    const unsigned limit = (unsigned)(tail ? nvalid : KC) * (unsigned)HWin;
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      if (u * 256 < PE) {
+        if ((unsigned)toff[u] < limit && !(p.dbg & 1)) dma_b32(base + toff[u], lds_addr(pb + u * 256 + wave * 64));
+        else if (tail && toff[u] >= 0) pb[u * 256 + tid] = 0.f;      // channels past the end
+      }
+    }
+    // weights: straight copy of [NIT*2 rows][BM float4] out of [rows][Mld4 float4]
+    const float* wsrc = p.wp4 + (long long)chunk * NIT * 2 * wrow + (long long)m0 * 4;
+    for (int e0 = wave * 64; e0 < WF4; e0 += 256) {
+      const int e = e0 + lane;
+      const int row = e / BM, m = e - row * BM;
+      if (e < WF4 && m0 + m < p.Mld4 && !(p.dbg & 2)) dma_b128(wsrc + row * wrow + m * 4, lds_addr(wb + e0 * 4));
+    }
+  };
+
+  __syncthreads();                     // zero fill complete before any DMA data can land
+  stage(0, 0);
+
+  for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's DMA has landed
+    __syncthreads();                                   // everyone's has; previous MFMA phase done
+    if (chunk + 1 < p.nchunk) stage(chunk + 1, (chunk + 1) & 1);
+
+    const f32x4* wl = reinterpret_cast<const f32x4*>(lds + (chunk & 1) * bufsz) + half * BM + l32;
+    const f32x4* pl = reinterpret_cast<const f32x4*>(lds + (chunk & 1) * bufsz + WF4 * 4);
+    f32x4 a[2][WM], b[2][WN];
+    int lg = 0, lky = 0, lkx = 0;                     // (tap, group) of the next operand load
+    auto load = [&](f32x4 (&aa)[WM], f32x4 (&bb)[WN], int it) {
+      const f32x4* wt = wl + it * 2 * BM;
+      const f32x4* pt = pl + lg * 2 * PHW + lky * PW + lkx;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) aa[i] = wt[i * 32];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bb[j] = pt[boff[j]];
+      if (++lg == G) {
+        lg = 0;
+        if (++lkx == p.KW) { lkx = 0; ++lky; }
+      }
+    };
+    auto mma = [&](const f32x4 (&aa)[WM], const f32x4 (&bb)[WN]) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[i][s], bb[j][s], acc[i][j], 0, 0, 0);
+    };
+    load(a[0], b[0], 0);
+    for (int it = 0; it < ((p.dbg & 4) ? 0 : NIT); it += 2) {
+      if (it + 1 < NIT) load(a[1], b[1], it + 1);
+      mma(a[0], b[0]);
+      if (it + 1 < NIT) {
+        if (it + 2 < NIT) load(a[0], b[0], it + 2);
+        mma(a[1], b[1]);
+      }
+    }
+  }
+
+  // ---- epilogue: C/D layout col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*half ----
+  const ConvEpi epi = scf_conv_epi(p, n);
+  const bool use_div = p.out_div != 1.0f;
+  int pix[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int oy = ty0 + (wave * WN + j) * FR + fr, ox = tx0 + fc;
+    const bool pok = oy < p.Ho && ox < p.Wo;
+    const int lin = p.out_tile ? (((oy >> 2) * (p.Wo >> 3) + (ox >> 3)) * 32 + (oy & 3) * 8 + (ox & 7))
+                               : oy * p.Wo + ox;
+    pix[j] = pok ? lin : -1;
+  }
+  scf_conv_epilogue_tile<WM, WN>(p, epi, acc, m0, half, pix, use_div);
+}
+
+template <int WM, int WN>
+static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
+  hipLaunchKernelGGL((conv_dma_kernel<WM, WN>), dim3(nblk), dim3(256), lds_bytes, st, k);
+  return scf_launch_status();
+}
+
+// Tile selection + launch.  k comes from conv_plan() (geometry fields are overwritten here).
+// SCF_EUNSUPPORTED -> the caller falls back to the register-staged kernel (strided layers,
+// thin inputs, tiny grids, shapes that exceed the DMA kernel's staging budget).
+int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st) {
+  if (!k.wp4 || k.stride != 1 || k.w_ns != 0) return SCF_EUNSUPPORTED;
+  const int G = k.G4;
+  if (G != 1 && G != 2 && G != 4) return SCF_EUNSUPPORTED;
+  const int KC = 8 * G;
+  if (k.in1 && (k.C0 % KC) != 0) return SCF_EUNSUPPORTED;
+  const int FC = 1 << k.fc_log2, FR = 32 / FC;
+  const int frags_m = (k.Cout + 31) / 32;
+  const int cand[4][2] = {{2, 2}, {3, 1}, {2, 1}, {1, 1}};
+  int best = -1;
+  long long best_blk = 0;
+  size_t best_lds = 0;
+  for (int c = 0; c < 4; ++c) {
+    const int WM = cand[c][0], WN = cand[c][1];
+    if (WM > frags_m) continue;
+    if (WM == 3 && frags_m % 3 != 0) continue;
+    if (WM == 2 && frags_m % 3 == 0 && frags_m % 2 != 0 && WN == 1) continue;   // 96 couts: (3,1)
+    const int TR = WN * 4 * FR;
+    const int PH = TR - 1 + k.KH, PW = FC - 1 + k.KW;
+    const long long PE = (long long)KC * PH * PW;
+    const long long WF4 = (long long)k.T * G * 2 * WM * 32;
+    const size_t ldsb = (size_t)(WF4 * 4 + PE) * 2 * sizeof(float);
+    if (PE > 256 * SCF_DMA_PU || ldsb > 64 * 1024) continue;
+    const long long blk = (long long)N * ((k.Ho + TR - 1) / TR) * ((k.Wo + FC - 1) / FC) *
+                          ((frags_m + WM - 1) / WM);
+    if (best < 0 || (best_blk < 1024 && blk > best_blk)) {
+      best = c; best_blk = blk; best_lds = ldsb;
+      if (blk >= 1024) break;
+    }
+  }
+  if (best < 0 || best_blk < 256 || best_blk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
+  const int WM = cand[best][0], WN = cand[best][1];
+  const int TR = WN * 4 * FR;
+  k.PH = TR - 1 + k.KH;
+  k.PW = FC - 1 + k.KW;
+  k.tiles_y = (k.Ho + TR - 1) / TR;
+  k.tiles_x = (k.Wo + FC - 1) / FC;
+  k.mblocks = (frags_m + WM - 1) / WM;
+  k.nchunk = (k.Cin + KC - 1) / KC;
+  { const char* e = getenv("SCF_DBG"); k.dbg = e ? atoi(e) : 0; }
+  if (info) { info[0] = WM; info[1] = WN; info[2] = (int)best_blk; info[3] = k.T * G * 4 * WM * WN; }
+  if (dry_run) return SCF_OK;
+#define SCF_CASE(M, Nn) if (WM == M && WN == Nn) return launch_dma<M, Nn>(k, (int)best_blk, best_lds, st);
+  SCF_CASE(2, 2) SCF_CASE(3, 1) SCF_CASE(2, 1) SCF_CASE(1, 1)
+#undef SCF_CASE
+  return SCF_EUNSUPPORTED;
+}

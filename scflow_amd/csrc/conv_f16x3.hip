@@ -227,21 +227,17 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvK p) {
   const ConvEpi epi = scf_conv_epi(p, n);
   const bool use_div = p.out_div != 1.0f;
   constexpr float inv_scale = 1.0f / F16_LO_SCALE;
+  int pix[WN];
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int oy = ty0 + (wave * WN + j) * FR + fr, ox = tx0 + fc;
-    const bool pok = oy < p.Ho && ox < p.Wo;
-    const int pix = oy * p.Wo + ox;
-    if (pok) {
+    pix[j] = (oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
 #pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        f32x16 v;
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = acc0[i][j][r] + acc1[i][j][r] * inv_scale;
-        scf_conv_epilogue_frag(p, epi, v, m0 + i * 32, half, pix, use_div);
-      }
-    }
+      for (int r = 0; r < 16; ++r) acc0[i][j][r] = acc0[i][j][r] + acc1[i][j][r] * inv_scale;
   }
+  scf_conv_epilogue_tile<WM, WN>(p, epi, acc0, m0, half, pix, use_div);
 }
 
 template <int WM, int WN, int NK>

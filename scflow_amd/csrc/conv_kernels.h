@@ -9,11 +9,13 @@ struct ConvK {
   int H, W, Ho, Wo;
   const float* wp; long long w_ns;
   const void* wp16;          // split-fp16 packing (conv_f16x3.hip) or nullptr
+  const float* wp4; int G4, Mld4;   // LDS-DMA packing (conv_dma.hip) or nullptr
   int Mld, Cout, Krows;
   int KH, KW, T, stride, pad_h, pad_w, KC, nchunk;
   int fc_log2, tiles_x, tiles_y, mblocks, PH, PW;
   int wvec;
   int out_tile;              // 1: 8x4-float tiled output planes (correlation level 0)
+  int dbg;
   int ksplit;                // 32-pixel tile, the 4 waves split the k-steps (small grids)
   float* out; long long out_ns;
   const float* bias; const float* scale; const float* shift;
@@ -44,18 +46,82 @@ __device__ __forceinline__ ConvEpi scf_conv_epi(const ConvK& p, int n) {
   return e;
 }
 
-// One 32x32 accumulator fragment (16 values per lane: channel rows co0 + (r&3) + 8*(r>>2) +
-// 4*half, one pixel), handled in 4 groups of 4 rows: the auxiliary operands of a group
-// (residual / GRU z, h) are gathered first so that their loads are in flight together instead
-// of one dependent round trip per value.
-// Order: /div, +bias, BN scale/shift, +residual, activation, GRU gating.
+// ---------------------------------------------------------------------------------------------
+// Fused epilogue.  One 32x32 accumulator fragment = 16 values per lane: channel rows
+// co0 + (r&3) + 8*(r>>2) + 4*half of one pixel, handled as 4 groups of 4 consecutive rows.
+// Order of operations: /div, +bias, BN scale/shift, +residual, activation, GRU gating.
+//
+// The epilogue KIND is uniform per launch and selected once per fragment, so that the path a
+// launch actually executes is a short straight run of code: the common affine kind (bias / BN /
+// residual / ReLU-or-none) costs ~5 instructions per value; the transcendental kinds (sigmoid /
+// tanh heads, the two GRU gates) keep their own specialised bodies.  (A single body with
+// per-value switches made the epilogue ~25 % of some layers' time and ~100 KB of code.)
+// ---------------------------------------------------------------------------------------------
 typedef float scf_f32x16 __attribute__((ext_vector_type(16)));
+typedef float scf_f32x4 __attribute__((ext_vector_type(4)));
 
-// one group of 4 consecutive channel rows cb..cb+3 of one pixel
-__device__ __forceinline__ void scf_conv_epilogue_group(const ConvK& p, const ConvEpi& e,
-                                                        const float (&acc)[4], int cb, int pix,
-                                                        bool use_div) {
-  const bool need_aux = (p.mode == SCF_CONV_PLAIN) ? (e.res != nullptr) : true;
+enum { SCF_EPI_AFFINE = 0, SCF_EPI_GENERAL = 1, SCF_EPI_GRU_ZR = 2, SCF_EPI_GRU_Q = 3 };
+
+__device__ __forceinline__ int scf_conv_epi_kind(const ConvK& p) {
+  if (p.mode == SCF_CONV_GRU_ZR) return SCF_EPI_GRU_ZR;
+  if (p.mode == SCF_CONV_GRU_Q) return SCF_EPI_GRU_Q;
+  const bool lin1 = p.act == SCF_ACT_NONE || p.act == SCF_ACT_RELU;
+  const bool lin2 = p.act_split <= 0 || p.act2 == SCF_ACT_NONE || p.act2 == SCF_ACT_RELU;
+  return (lin1 && lin2) ? SCF_EPI_AFFINE : SCF_EPI_GENERAL;
+}
+
+// affine kind, 4 rows cb..cb+3 (cb % 4 == 0) of one pixel
+__device__ __forceinline__ void scf_epi_affine_group(const ConvK& p, const ConvEpi& e,
+                                                     const float (&acc)[4], int cb, int pix,
+                                                     bool use_div) {
+  if (cb >= p.Cout) return;
+  const bool full = cb + 3 < p.Cout;
+  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+  if (use_div) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = v[q] / p.out_div;
+  }
+  int off = cb * e.HWo + pix;
+  float r[4] = {0.f, 0.f, 0.f, 0.f};
+  if (e.res) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (full || cb + q < p.Cout) r[q] = e.res[off + q * e.HWo];
+  }
+  if (p.bias) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] += p.bias[(full || cb + q < p.Cout) ? cb + q : cb];
+  }
+  if (p.scale) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = (full || cb + q < p.Cout) ? cb + q : cb;
+      v[q] = v[q] * p.scale[c] + p.shift[c];
+    }
+  }
+  if (e.res) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] += r[q];
+  }
+  // ReLU as compare+select (keeps NaN, like the reference); per-row choice under act_split
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int a = (p.act_split > 0 && cb + q >= p.act_split) ? p.act2 : p.act;
+    if (a == SCF_ACT_RELU) v[q] = v[q] > 0.f ? v[q] : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (full || cb + q < p.Cout) e.out[off + q * e.HWo] = v[q];
+}
+
+// every other kind: one group of 4 consecutive channel rows cb..cb+3 of one pixel.  The
+// auxiliary operands of the group (residual / GRU z, h) are gathered first so that their loads
+// are in flight together instead of one dependent round trip per value.
+template <int KIND>
+__device__ __forceinline__ void scf_epi_general_group(const ConvK& p, const ConvEpi& e,
+                                                      const float (&acc)[4], int cb, int pix,
+                                                      bool use_div) {
+  const bool need_aux = (KIND == SCF_EPI_GENERAL) ? (e.res != nullptr) : true;
   const int hc = p.Cout >> 1;
   float aux0[4] = {0.f, 0.f, 0.f, 0.f}, aux1[4] = {0.f, 0.f, 0.f, 0.f};
   if (need_aux) {
@@ -64,9 +130,9 @@ __device__ __forceinline__ void scf_conv_epilogue_group(const ConvK& p, const Co
       const int co = cb + q;
       if (co < p.Cout) {
         const int off = co * e.HWo + pix;
-        if (p.mode == SCF_CONV_PLAIN) {
+        if (KIND == SCF_EPI_GENERAL) {
           aux0[q] = e.res[off];
-        } else if (p.mode == SCF_CONV_GRU_ZR) {
+        } else if (KIND == SCF_EPI_GRU_ZR) {
           if (co >= hc) aux0[q] = e.gru_h[off - hc * e.HWo];
         } else {
           aux0[q] = e.gru_h[off];
@@ -83,12 +149,12 @@ __device__ __forceinline__ void scf_conv_epilogue_group(const ConvK& p, const Co
       float v = acc[q];
       if (use_div) v = v / p.out_div;
       if (p.bias) v += p.bias[co];
-      if (p.mode == SCF_CONV_PLAIN) {
+      if (KIND == SCF_EPI_GENERAL) {
         if (p.scale) v = v * p.scale[co] + p.shift[co];
         v += aux0[q];
         const int a = (p.act_split > 0 && co >= p.act_split) ? p.act2 : p.act;
         e.out[off] = scf_apply_act(v, a);
-      } else if (p.mode == SCF_CONV_GRU_ZR) {
+      } else if (KIND == SCF_EPI_GRU_ZR) {
         const float sg = 1.f / (1.f + expf(-v));
         if (co < hc) e.out[off] = sg;
         else e.gru_aux[off - hc * e.HWo] = sg * aux0[q];
@@ -100,16 +166,47 @@ __device__ __forceinline__ void scf_conv_epilogue_group(const ConvK& p, const Co
   }
 }
 
-__device__ __forceinline__ void scf_conv_epilogue_frag(const ConvK& p, const ConvEpi& e,
-                                                       const scf_f32x16 acc, int co0, int half,
-                                                       int pix, bool use_div) {
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-    scf_conv_epilogue_group(p, e, v, co0 + 8 * g + 4 * half, pix, use_div);
+// one group of 4 rows, kind chosen at run time (K-split kernel)
+__device__ __forceinline__ void scf_conv_epilogue_group(const ConvK& p, const ConvEpi& e,
+                                                        const float (&acc)[4], int cb, int pix,
+                                                        bool use_div) {
+  switch (scf_conv_epi_kind(p)) {
+    case SCF_EPI_AFFINE: scf_epi_affine_group(p, e, acc, cb, pix, use_div); break;
+    case SCF_EPI_GENERAL: scf_epi_general_group<SCF_EPI_GENERAL>(p, e, acc, cb, pix, use_div); break;
+    case SCF_EPI_GRU_ZR: scf_epi_general_group<SCF_EPI_GRU_ZR>(p, e, acc, cb, pix, use_div); break;
+    default: scf_epi_general_group<SCF_EPI_GRU_Q>(p, e, acc, cb, pix, use_div); break;
   }
+}
+
+// All fragments of a wave: acc[i][j] covers channels m0 + 32 i .. +31 at pixel pix[j]
+// (pix[j] < 0: outside the image).  The kind switch sits OUTSIDE the fragment loops.
+template <int WM, int WN, typename ACC>
+__device__ __forceinline__ void scf_conv_epilogue_tile(const ConvK& p, const ConvEpi& e,
+                                                       const ACC& acc, int m0, int half,
+                                                       const int (&pix)[WN], bool use_div) {
+  const int kind = scf_conv_epi_kind(p);
+#define SCF_EPI_LOOP(CALL)                                                        \
+  _Pragma("unroll") for (int j = 0; j < WN; ++j) {                                \
+    if (pix[j] >= 0) {                                                            \
+      _Pragma("unroll") for (int i = 0; i < WM; ++i) {                            \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                           \
+          const float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], \
+                              acc[i][j][4 * g + 3]};                              \
+          CALL(p, e, v, m0 + i * 32 + 8 * g + 4 * half, pix[j], use_div);         \
+        }                                                                         \
+      }                                                                           \
+    }                                                                             \
+  }
+  if (kind == SCF_EPI_AFFINE) { SCF_EPI_LOOP(scf_epi_affine_group) }
+  else if (kind == SCF_EPI_GENERAL) { SCF_EPI_LOOP(scf_epi_general_group<SCF_EPI_GENERAL>) }
+  else if (kind == SCF_EPI_GRU_ZR) { SCF_EPI_LOOP(scf_epi_general_group<SCF_EPI_GRU_ZR>) }
+  else { SCF_EPI_LOOP(scf_epi_general_group<SCF_EPI_GRU_Q>) }
+#undef SCF_EPI_LOOP
 }
 
 // conv_f16x3.hip: tile selection + launch of the split-fp16 kernel (SCF_EUNSUPPORTED -> caller
 // falls back to fp32).  info (optional): {WM, WN, blocks, MFMAs per wave per chunk}.
 int scf_conv_f16x3_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st);
+
+// conv_dma.hip: same contract for the stride-1 LDS-DMA fp32 kernel.
+int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st);

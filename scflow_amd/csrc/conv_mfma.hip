@@ -193,18 +193,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
   // ---- epilogue: C/D layout col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*half ----
   const ConvEpi epi = scf_conv_epi(p, n);
   const bool use_div = p.out_div != 1.0f;
+  int pix[WN];
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int oy = ty0 + (wave * WN + j) * FR + fr, ox = tx0 + fc;
     const bool pok = oy < p.Ho && ox < p.Wo;
-    const int pix = p.out_tile ? (((oy >> 2) * (p.Wo >> 3) + (ox >> 3)) * 32 + (oy & 3) * 8 + (ox & 7))
+    const int lin = p.out_tile ? (((oy >> 2) * (p.Wo >> 3) + (ox >> 3)) * 32 + (oy & 3) * 8 + (ox & 7))
                                : oy * p.Wo + ox;
-    if (pok) {
-#pragma unroll
-      for (int i = 0; i < WM; ++i)
-        scf_conv_epilogue_frag(p, epi, acc[i][j], m0 + i * 32, half, pix, use_div);
-    }
+    pix[j] = pok ? lin : -1;
   }
+  scf_conv_epilogue_tile<WM, WN>(p, epi, acc, m0, half, pix, use_div);
 }
 
 // ---------------------------------------------------------------------------------
@@ -418,6 +416,7 @@ static int conv_plan(const scf_conv_desc* d, ConvPlan* plan) {
   if (k.Ho <= 0 || k.Wo <= 0) return SCF_EINVAL;
   k.wp = d->wp; k.w_ns = d->w_nstride; k.Mld = d->Mld; k.Cout = d->Cout;
   k.wp16 = d->wp_f16;
+  k.wp4 = d->wp_a4; k.G4 = d->a4_groups; k.Mld4 = d->a4_mld;
   k.out_tile = d->out_tile8x4;
   k.KH = d->KH; k.KW = d->KW; k.T = d->KH * d->KW; k.stride = d->stride;
   k.pad_h = d->pad_h; k.pad_w = d->pad_w; k.KC = d->KC;
@@ -513,6 +512,12 @@ static bool want_f16x3(const scf_conv_desc* d) {
   return d->wp_f16 != nullptr && !d->out_tile8x4 && d->w_nstride == 0 && d->KH * d->KW > 1 && d->C0 + d->C1 >= 16;
 }
 
+static bool want_dma(const scf_conv_desc* d) {
+  // work in progress: opt-in (SCF_CONV_DMA=1) until it beats the register-staged kernel everywhere
+  static const bool on = [] { const char* e = getenv("SCF_CONV_DMA"); return e && e[0] == '1'; }();
+  return on && d->wp_a4 != nullptr && d->stride == 1 && d->w_nstride == 0 && d->a4_mld >= d->Cout;
+}
+
 extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
   ConvPlan pl;
   const int rc = conv_plan(d, &pl);
@@ -520,6 +525,10 @@ extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
   if (want_f16x3(d)) {
     const int r16 = scf_conv_f16x3_dispatch(pl.k, d->N, false, nullptr, scf_stream(stream));
     if (r16 != SCF_EUNSUPPORTED) return r16;
+  }
+  if (want_dma(d)) {
+    const int rd = scf_conv_dma_dispatch(pl.k, d->N, false, nullptr, scf_stream(stream));
+    if (rd != SCF_EUNSUPPORTED) return rd;
   }
   const ConvK& k = pl.k;
   const int WM = pl.WM, WN = pl.WN;
@@ -548,6 +557,10 @@ extern "C" int scf_conv2d_query(const scf_conv_desc* d, int32_t* info) {
   if (rc != SCF_OK) return rc;
   if (want_f16x3(d) && scf_conv_f16x3_dispatch(pl.k, d->N, true, info, nullptr) == SCF_OK) {
     info[3] = -info[3];      // negative: the split-fp16 kernel will run
+    return SCF_OK;
+  }
+  if (want_dma(d) && scf_conv_dma_dispatch(pl.k, d->N, true, info, nullptr) == SCF_OK) {
+    info[3] = -info[3];      // negative: not the register-staged kernel, KC of d is irrelevant
     return SCF_OK;
   }
   info[0] = pl.WM;

@@ -116,6 +116,28 @@ def pack_conv_weight_f16x3(weight: Tensor) -> Tensor:
     return out.reshape(nchunk * t * 2, 2, mld, 8).contiguous()
 
 
+def choose_a4_groups(cin: int, kh: int, kw: int, stride: int) -> int:
+    """8G channels per staged chunk of the LDS-DMA kernel (0: layer not eligible)."""
+    if stride != 1 or cin < 8 or kh * kw >= 25:
+        return 0
+    t = kh * kw
+    return 4 if t == 1 else 2 if t <= 5 else 1
+
+
+def pack_conv_weight_a4(weight: Tensor, groups: int) -> Tuple[Tensor, int]:
+    """(Cout, Cin, KH, KW) -> [chunk][tap][g][h][Mld][4] (conv_dma.hip): channel
+    chunk*8G + 8g + 2s + h at float s of cell (g, h); zero-padded channels and couts."""
+    cout, cin, kh, kw = weight.shape
+    t, kc = kh * kw, 8 * groups
+    nchunk = (cin + kc - 1) // kc
+    mld = (cout + 31) // 32 * 32
+    w = torch.zeros((mld, nchunk * kc, t), dtype=torch.float32, device=weight.device)
+    w[:cout, :cin] = weight.reshape(cout, cin, t).float()
+    # channel index -> (chunk, g, s, h)
+    w = w.reshape(mld, nchunk, groups, 4, 2, t).permute(1, 5, 2, 4, 0, 3)
+    return w.contiguous().reshape(-1), mld
+
+
 _CONV_PRECISION = 'f32'
 
 
@@ -155,6 +177,8 @@ class PackedConv:
     wp_alt: Optional[Tensor] = None   # KC=32 packing of the same weights (short-chunk regime)
     plans: Optional[dict] = None      # (N, H, W, C0, C1) -> use the KC=32 packing?
     wp16: Optional[Tensor] = None     # split-fp16 packing (spatial kernels, Cin >= 16)
+    wp4: Optional[Tensor] = None      # LDS-DMA packing (stride 1, Cin >= 8)
+    g4: int = 0
 
     @staticmethod
     def from_weight(weight: Tensor, bias: Optional[Tensor], stride: int = 1,
@@ -173,8 +197,10 @@ class PackedConv:
             gamma, beta, mean, var = [b.float() for b in bn]
             scale = (gamma / torch.sqrt(var + eps)).contiguous()
             shift = (beta - mean * scale).contiguous()
+        g4 = choose_a4_groups(cin, kh, kw, stride)
+        wp4 = pack_conv_weight_a4(weight, g4)[0] if g4 else None
         return PackedConv(wp, None if bias is None else bias.float().contiguous(), scale, shift,
-                          cin, cout, kh, kw, stride, ph, pw, kc, mld, wp_alt, {}, wp16)
+                          cin, cout, kh, kw, stride, ph, pw, kc, mld, wp_alt, {}, wp16, wp4, g4)
 
     def out_hw(self, h: int, w: int) -> Tuple[int, int]:
         return ((h + 2 * self.pad_h - self.kh) // self.stride + 1,
@@ -235,6 +261,8 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
     # hide.  Stage 32 channels per chunk instead when that packing fits (decided once per shape).
     if _CONV_PRECISION == 'f16x3' and pc.wp16 is not None:
         d.wp_f16 = pc.wp16.data_ptr()
+    if pc.wp4 is not None:
+        d.wp_a4, d.a4_groups, d.a4_mld = pc.wp4.data_ptr(), pc.g4, pc.mld
     if pc.wp_alt is not None and (c1 == 0 or c0 % 32 == 0):
         key = (n, h, w, c0, c1, d.wp_f16 is not None)
         use_alt = pc.plans.get(key)
