@@ -28,18 +28,39 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
 
-// LDS-DMA, 16 / 4 bytes per lane: lane l's data lands at lds_base + l*16 (l*4).  M0 carries
-// the wave-uniform LDS base; it is compiler-reserved, so it is saved and restored in the same
-// statement.  The compiler does not count these loads: the caller waits (vmcnt) itself.
-__device__ __forceinline__ void dma_b128(const void* g, unsigned lds_base) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(g), "s"(lds_base) : "memory");
+// LDS-DMA, 16 / 4 bytes per lane: lane l's data lands at lds_base + l*16 (l*4); source = scalar
+// base + 32-bit per-lane byte offset; only the lanes of `mask` take part.  Everything that
+// touches EXEC / M0 sits in ONE statement (both are restored to "all lanes" / don't-care before
+// the compiler gets control back; the kernel runs with all 64 lanes active here).  The compiler
+// does not count these loads: the caller waits (vmcnt) itself.
+__device__ __forceinline__ void dma_b128(const void* sbase, unsigned voff, unsigned lds_base,
+                                         unsigned long long mask) {
+  asm volatile("s_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %0\n\ts_mov_b64 exec, -1"
+               : : "s"(sbase), "v"(voff), "s"(lds_base), "s"(mask) : "memory");
 }
-__device__ __forceinline__ void dma_b32(const void* g, unsigned lds_base) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(g), "s"(lds_base) : "memory");
+__device__ __forceinline__ void dma_b32(const void* sbase, unsigned voff, unsigned lds_base,
+                                        unsigned long long mask) {
+  asm volatile("s_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dword %1, %0\n\ts_mov_b64 exec, -1"
+               : : "s"(sbase), "v"(voff), "s"(lds_base), "s"(mask) : "memory");
+}
+
+// a pointer the compiler keeps in SGPRs (block-uniform by construction)
+__device__ __forceinline__ const void* sgpr_ptr(const void* p) {
+  const unsigned long long u = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return (const void*)(((unsigned long long)hi << 32) | lo);
+}
+
+// floor(e / d) for 0 <= e < 2^22, 0 < d < 2^12 without the integer-division expansion
+__device__ __forceinline__ int fast_div(int e, int d, float rd) {
+  int q = (int)((float)e * rd);
+  const int r = e - q * d;
+  q += (r >= d) ? 1 : 0;
+  q -= (r < 0) ? 1 : 0;
+  return q;
 }
 
 template <int WM, int WN>
@@ -79,21 +100,40 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   }
 
   // ---- gather table: LDS patch float e = tid + 256u <-> (group g, half h, py, px, s) ----
+  // Chunk-invariant: byte offset from the chunk's first channel plane + a lane mask per u
+  // (out-of-image positions are never fetched: they keep the zeros written above).
   const int HWin = p.H * p.W;
-  int toff[PU];
+  const float rPHW = 1.0f / (float)PHW, rPW = 1.0f / (float)PW;
+  unsigned toff[PU];
+  unsigned long long tmask[PU];
 #pragma unroll
   for (int u = 0; u < PU; ++u) {
     const int e = tid + u * 256;
-    int o = -1;
-    if (e < PE) {
+    bool ok = false;
+    unsigned o = 0;
+    if (u * 256 < PE) {
       const int s = e & 3, q = e >> 2;
-      const int gh = q / PHW, r = q - gh * PHW;
-      const int py = r / PW, px = r - py * PW;
+      const int gh = fast_div(q, PHW, rPHW), r = q - gh * PHW;
+      const int py = fast_div(r, PW, rPW), px = r - py * PW;
       const int c = 8 * (gh >> 1) + 2 * s + (gh & 1);
       const int iy = iy0 + py, ix = ix0 + px;
-      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) o = c * HWin + iy * p.W + ix;
+      ok = e < PE && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      o = (unsigned)(c * HWin + iy * p.W + ix) * 4u;
     }
-    toff[u] = o;
+    toff[u] = ok ? o : 0xFFFFFFFFu;
+    tmask[u] = __ballot(ok);
+  }
+  // weights: float4 e = tid + 256u of the chunk's [NIT*2 rows][BM] slab out of [rows][Mld4]
+  constexpr int WU = 7;
+  unsigned woff[WU];
+  unsigned long long wmask[WU];
+#pragma unroll
+  for (int u = 0; u < WU; ++u) {
+    const int e = tid + u * 256;
+    const int row = e / BM, m = e - row * BM;
+    const bool ok = e < WF4 && m0 + m < p.Mld4;
+    woff[u] = (unsigned)((row * p.Mld4 + m) * 16);
+    wmask[u] = __ballot(ok);
   }
 
   const int fr = l32 >> p.fc_log2, fc = l32 & (FC - 1);
@@ -116,28 +156,31 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   auto stage = [&](int chunk, int b) {
     float* wb = lds + b * bufsz;
     float* pb = wb + WF4 * 4;
-    // patch: one dword per lane, lane-linear in LDS
     const int c0 = chunk * KC;
     const float* base;
     int nvalid;
     if (c0 < p.C0) { base = in0n + (long long)c0 * HWin; nvalid = p.C0 - c0; }
     else { base = in1n + (long long)(c0 - p.C0) * HWin; nvalid = p.Cin - c0; }
-    const bool tail = nvalid < KC;
-    const unsigned limit = (unsigned)(tail ? nvalid : KC) * (unsigned)HWin;
+    base = (const float*)sgpr_ptr(base);
+    if (nvalid >= KC) {                // chunk-invariant masks apply
 #pragma unroll
-    for (int u = 0; u < PU; ++u) {
-      if (u * 256 < PE) {
-        if ((unsigned)toff[u] < limit && !(p.dbg & 1)) dma_b32(base + toff[u], lds_addr(pb + u * 256 + wave * 64));
-        else if (tail && toff[u] >= 0) pb[u * 256 + tid] = 0.f;      // channels past the end
+      for (int u = 0; u < PU; ++u)
+        if (u * 256 < PE) dma_b32(base, toff[u], lds_addr(pb + u * 256 + wave * 64), tmask[u]);
+    } else {                           // last chunk of a segment: channels past the end are zero
+      const unsigned limit = (unsigned)nvalid * (unsigned)HWin * 4u;
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+        if (u * 256 < PE) {
+          const bool in = toff[u] < limit;
+          dma_b32(base, toff[u], lds_addr(pb + u * 256 + wave * 64), __ballot(in));
+          if (!in && toff[u] != 0xFFFFFFFFu) pb[u * 256 + tid] = 0.f;
+        }
       }
     }
-    // weights: straight copy of [NIT*2 rows][BM float4] out of [rows][Mld4 float4]
-    const float* wsrc = p.wp4 + (long long)chunk * NIT * 2 * wrow + (long long)m0 * 4;
-    for (int e0 = wave * 64; e0 < WF4; e0 += 256) {
-      const int e = e0 + lane;
-      const int row = e / BM, m = e - row * BM;
-      if (e < WF4 && m0 + m < p.Mld4 && !(p.dbg & 2)) dma_b128(wsrc + row * wrow + m * 4, lds_addr(wb + e0 * 4));
-    }
+    const float* wsrc = (const float*)sgpr_ptr(p.wp4 + (long long)chunk * NIT * 2 * wrow + (long long)m0 * 4);
+#pragma unroll
+    for (int u = 0; u < WU; ++u)
+      if (u * 256 < WF4) dma_b128(wsrc, woff[u], lds_addr(wb + (u * 256 + wave * 64) * 4), wmask[u]);
   };
 
   __syncthreads();                     // zero fill complete before any DMA data can land
@@ -174,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[i][s], bb[j][s], acc[i][j], 0, 0, 0);
     };
     load(a[0], b[0], 0);
-    for (int it = 0; it < ((p.dbg & 4) ? 0 : NIT); it += 2) {
+    for (int it = 0; it < NIT; it += 2) {
       if (it + 1 < NIT) load(a[1], b[1], it + 1);
       mma(a[0], b[0]);
       if (it + 1 < NIT) {
@@ -216,26 +259,28 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   if (k.in1 && (k.C0 % KC) != 0) return SCF_EUNSUPPORTED;
   const int FC = 1 << k.fc_log2, FR = 32 / FC;
   const int frags_m = (k.Cout + 31) / 32;
+  // candidates in order of preference; WM must divide the channel fragments (no idle MFMA
+  // rows) unless nothing else fits; take the first that gives >= 2 blocks per CU, else the one
+  // with the most blocks.
   const int cand[4][2] = {{2, 2}, {3, 1}, {2, 1}, {1, 1}};
   int best = -1;
   long long best_blk = 0;
   size_t best_lds = 0;
-  for (int c = 0; c < 4; ++c) {
-    const int WM = cand[c][0], WN = cand[c][1];
-    if (WM > frags_m) continue;
-    if (WM == 3 && frags_m % 3 != 0) continue;
-    if (WM == 2 && frags_m % 3 == 0 && frags_m % 2 != 0 && WN == 1) continue;   // 96 couts: (3,1)
-    const int TR = WN * 4 * FR;
-    const int PH = TR - 1 + k.KH, PW = FC - 1 + k.KW;
-    const long long PE = (long long)KC * PH * PW;
-    const long long WF4 = (long long)k.T * G * 2 * WM * 32;
-    const size_t ldsb = (size_t)(WF4 * 4 + PE) * 2 * sizeof(float);
-    if (PE > 256 * SCF_DMA_PU || ldsb > 64 * 1024) continue;
-    const long long blk = (long long)N * ((k.Ho + TR - 1) / TR) * ((k.Wo + FC - 1) / FC) *
-                          ((frags_m + WM - 1) / WM);
-    if (best < 0 || (best_blk < 1024 && blk > best_blk)) {
-      best = c; best_blk = blk; best_lds = ldsb;
-      if (blk >= 1024) break;
+  for (int pass = 0; pass < 2 && best < 0; ++pass) {
+    for (int c = 0; c < 4; ++c) {
+      const int WM = cand[c][0], WN = cand[c][1];
+      if (WM > frags_m) continue;
+      if (pass == 0 && frags_m % WM != 0) continue;
+      const int TR = WN * 4 * FR;
+      const int PH = TR - 1 + k.KH, PW = FC - 1 + k.KW;
+      const long long PE = (long long)KC * PH * PW;
+      const long long WF4 = (long long)k.T * G * 2 * WM * 32;
+      const size_t ldsb = (size_t)(WF4 * 4 + PE) * 2 * sizeof(float);
+      if (PE > 256 * SCF_DMA_PU || WF4 > 256 * 7 || ldsb > 64 * 1024) continue;
+      const long long blk = (long long)N * ((k.Ho + TR - 1) / TR) * ((k.Wo + FC - 1) / FC) *
+                            ((frags_m + WM - 1) / WM);
+      if (best < 0 || blk > best_blk) { best = c; best_blk = blk; best_lds = ldsb; }
+      if (blk >= 512) break;
     }
   }
   if (best < 0 || best_blk < 256 || best_blk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
@@ -247,7 +292,6 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   k.tiles_x = (k.Wo + FC - 1) / FC;
   k.mblocks = (frags_m + WM - 1) / WM;
   k.nchunk = (k.Cin + KC - 1) / KC;
-  { const char* e = getenv("SCF_DBG"); k.dbg = e ? atoi(e) : 0; }
   if (info) { info[0] = WM; info[1] = WN; info[2] = (int)best_blk; info[3] = k.T * G * 4 * WM * WN; }
   if (dry_run) return SCF_OK;
 #define SCF_CASE(M, Nn) if (WM == M && WN == Nn) return launch_dma<M, Nn>(k, (int)best_blk, best_lds, st);

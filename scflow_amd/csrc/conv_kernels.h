@@ -15,7 +15,6 @@ struct ConvK {
   int fc_log2, tiles_x, tiles_y, mblocks, PH, PW;
   int wvec;
   int out_tile;              // 1: 8x4-float tiled output planes (correlation level 0)
-  int dbg;
   int ksplit;                // 32-pixel tile, the 4 waves split the k-steps (small grids)
   float* out; long long out_ns;
   const float* bias; const float* scale; const float* shift;

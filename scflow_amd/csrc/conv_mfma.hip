@@ -513,9 +513,8 @@ static bool want_f16x3(const scf_conv_desc* d) {
 }
 
 static bool want_dma(const scf_conv_desc* d) {
-  // work in progress: opt-in (SCF_CONV_DMA=1) until it beats the register-staged kernel everywhere
-  static const bool on = [] { const char* e = getenv("SCF_CONV_DMA"); return e && e[0] == '1'; }();
-  return on && d->wp_a4 != nullptr && d->stride == 1 && d->w_nstride == 0 && d->a4_mld >= d->Cout;
+  static const bool off = [] { const char* e = getenv("SCF_CONV_DMA"); return e && e[0] == '0'; }();   // A/B knob
+  return !off && d->wp_a4 != nullptr && d->stride == 1 && d->w_nstride == 0 && d->a4_mld >= d->Cout;
 }
 
 extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {

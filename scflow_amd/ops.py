@@ -118,10 +118,10 @@ def pack_conv_weight_f16x3(weight: Tensor) -> Tensor:
 
 def choose_a4_groups(cin: int, kh: int, kw: int, stride: int) -> int:
     """8G channels per staged chunk of the LDS-DMA kernel (0: layer not eligible)."""
-    if stride != 1 or cin < 8 or kh * kw >= 25:
-        return 0
     t = kh * kw
-    return 4 if t == 1 else 2 if t <= 5 else 1
+    if stride != 1 or cin < 8 or t >= 25 or t == 1:     # 1x1: chunks too short for the DMA pipeline
+        return 0
+    return 2 if t <= 5 else 1
 
 
 def pack_conv_weight_a4(weight: Tensor, groups: int) -> Tuple[Tensor, int]:
