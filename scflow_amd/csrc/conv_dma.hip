@@ -22,7 +22,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #include "conv_kernels.h"
 
-#define SCF_DMA_PU 16   // patch gathers per thread per chunk (256 * 16 floats)
+#define SCF_DMA_PU 20   // patch gathers per thread per chunk (256 * 20 floats)
+#define SCF_DMA_LDS_MAX (80 * 1024)   // two blocks per CU (160 KB)
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
@@ -244,6 +245,15 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
 
 template <int WM, int WN>
 static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
+  if (lds_bytes > 64 * 1024) {       // opt in to > 64 KiB of dynamic LDS once per instantiation
+    static bool raised = false;
+    if (!raised) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WM, WN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, SCF_DMA_LDS_MAX) != hipSuccess)
+        return SCF_ELAUNCH;
+      raised = true;
+    }
+  }
   hipLaunchKernelGGL((conv_dma_kernel<WM, WN>), dim3(nblk), dim3(256), lds_bytes, st, k);
   return scf_launch_status();
 }
@@ -276,7 +286,7 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
       const long long PE = (long long)KC * PH * PW;
       const long long WF4 = (long long)k.T * G * 2 * WM * 32;
       const size_t ldsb = (size_t)(WF4 * 4 + PE) * 2 * sizeof(float);
-      if (PE > 256 * SCF_DMA_PU || WF4 > 256 * 7 || ldsb > 64 * 1024) continue;
+      if (PE > 256 * SCF_DMA_PU || WF4 > 256 * 7 || ldsb > SCF_DMA_LDS_MAX) continue;
       const long long blk = (long long)N * ((k.Ho + TR - 1) / TR) * ((k.Wo + FC - 1) / FC) *
                             ((frags_m + WM - 1) / WM);
       if (best < 0 || blk > best_blk) { best = c; best_blk = blk; best_lds = ldsb; }
