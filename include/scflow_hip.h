@@ -125,6 +125,9 @@ typedef struct scf_conv_desc {
                                            floats, channel = chunk*8G + 8g + 2s + h at float s      */
   int32_t a4_groups;                    /* G in {1,2,4}: 8G channels per staged chunk              */
   int32_t a4_mld;                       /* Cout rounded up to 32                                    */
+  const float* wp_thin;                 /* optional third packing for Cout <= 4 layers (vector-ALU
+                                           kernel): [Cin][KH*KW][CO] floats, CO = 1, 2 or 4 (Cout
+                                           rounded up), zero padded                                */
   int32_t out_tile8x4;                  /* 1: store every output plane in 8(x) x 4(y)-float tiles
                                            of 128 B (tile-major, row-major inside) instead of
                                            row-major; needs Wo % 8 == 0 and Ho % 4 == 0          */

@@ -43,6 +43,7 @@ class ConvDesc(C.Structure):
         ('wp_a4', _fp),
         ('a4_groups', C.c_int32),
         ('a4_mld', C.c_int32),
+        ('wp_thin', _fp),
         ('out_tile8x4', C.c_int32),
     ]
 

@@ -9,6 +9,7 @@ struct ConvK {
   int H, W, Ho, Wo;
   const float* wp; long long w_ns;
   const void* wp16;          // split-fp16 packing (conv_f16x3.hip) or nullptr
+  const float* wthin;               // [Cin][T][CO] packing (conv_thin.hip) or nullptr
   const float* wp4; int G4, Mld4;   // LDS-DMA packing (conv_dma.hip) or nullptr
   int Mld, Cout, Krows;
   int KH, KW, T, stride, pad_h, pad_w, KC, nchunk;
@@ -207,5 +208,7 @@ __device__ __forceinline__ void scf_conv_epilogue_tile(const ConvK& p, const Con
 // falls back to fp32).  info (optional): {WM, WN, blocks, MFMAs per wave per chunk}.
 int scf_conv_f16x3_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st);
 
+// conv_thin.hip: Cout <= 4 layers on the vector ALUs.
+int scf_conv_thin_dispatch(ConvK k, int N, bool dry_run, hipStream_t st);
 // conv_dma.hip: same contract for the stride-1 LDS-DMA fp32 kernel.
 int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st);

@@ -416,6 +416,7 @@ static int conv_plan(const scf_conv_desc* d, ConvPlan* plan) {
   if (k.Ho <= 0 || k.Wo <= 0) return SCF_EINVAL;
   k.wp = d->wp; k.w_ns = d->w_nstride; k.Mld = d->Mld; k.Cout = d->Cout;
   k.wp16 = d->wp_f16;
+  k.wthin = d->wp_thin;
   k.wp4 = d->wp_a4; k.G4 = d->a4_groups; k.Mld4 = d->a4_mld;
   k.out_tile = d->out_tile8x4;
   k.KH = d->KH; k.KW = d->KW; k.T = d->KH * d->KW; k.stride = d->stride;
@@ -521,6 +522,10 @@ extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
   ConvPlan pl;
   const int rc = conv_plan(d, &pl);
   if (rc != SCF_OK) return rc;
+  {
+    const int rt = scf_conv_thin_dispatch(pl.k, d->N, false, scf_stream(stream));
+    if (rt != SCF_EUNSUPPORTED) return rt;
+  }
   if (want_f16x3(d)) {
     const int r16 = scf_conv_f16x3_dispatch(pl.k, d->N, false, nullptr, scf_stream(stream));
     if (r16 != SCF_EUNSUPPORTED) return r16;
@@ -554,6 +559,10 @@ extern "C" int scf_conv2d_query(const scf_conv_desc* d, int32_t* info) {
   ConvPlan pl;
   const int rc = conv_plan(d, &pl);
   if (rc != SCF_OK) return rc;
+  if (scf_conv_thin_dispatch(pl.k, d->N, true, nullptr) == SCF_OK) {
+    info[0] = info[1] = 0; info[2] = 0; info[3] = -1;      // vector-ALU thin-output kernel
+    return SCF_OK;
+  }
   if (want_f16x3(d) && scf_conv_f16x3_dispatch(pl.k, d->N, true, info, nullptr) == SCF_OK) {
     info[3] = -info[3];      // negative: the split-fp16 kernel will run
     return SCF_OK;

@@ -12,6 +12,7 @@ concatenations are expressed without copies.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
@@ -138,6 +139,18 @@ def pack_conv_weight_a4(weight: Tensor, groups: int) -> Tuple[Tensor, int]:
     return w.contiguous().reshape(-1), mld
 
 
+def pack_conv_weight_thin(weight: Tensor) -> Tensor:
+    """(Cout <= 4, Cin, KH, KW) -> [Cin][KH*KW][CO] (conv_thin.hip), CO = Cout rounded up to
+    1 / 2 / 4, padded to a multiple of 4 floats."""
+    cout, cin, kh, kw = weight.shape
+    co = 1 if cout <= 1 else 2 if cout <= 2 else 4
+    w = torch.zeros((cin, kh * kw, co), dtype=torch.float32, device=weight.device)
+    w[:, :, :cout] = weight.reshape(cout, cin, kh * kw).permute(1, 2, 0).float()
+    flat = torch.zeros(((w.numel() + 3) // 4 * 4,), dtype=torch.float32, device=weight.device)
+    flat[:w.numel()] = w.reshape(-1)
+    return flat
+
+
 _CONV_PRECISION = 'f32'
 
 
@@ -179,6 +192,7 @@ class PackedConv:
     wp16: Optional[Tensor] = None     # split-fp16 packing (spatial kernels, Cin >= 16)
     wp4: Optional[Tensor] = None      # LDS-DMA packing (stride 1, Cin >= 8)
     g4: int = 0
+    wthin: Optional[Tensor] = None    # [Cin][T][CO] packing (Cout <= 4)
 
     @staticmethod
     def from_weight(weight: Tensor, bias: Optional[Tensor], stride: int = 1,
@@ -197,10 +211,11 @@ class PackedConv:
             gamma, beta, mean, var = [b.float() for b in bn]
             scale = (gamma / torch.sqrt(var + eps)).contiguous()
             shift = (beta - mean * scale).contiguous()
-        g4 = choose_a4_groups(cin, kh, kw, stride)
+        g4 = 0 if os.environ.get('SCF_TEST_NO_A4') else choose_a4_groups(cin, kh, kw, stride)
         wp4 = pack_conv_weight_a4(weight, g4)[0] if g4 else None
         return PackedConv(wp, None if bias is None else bias.float().contiguous(), scale, shift,
-                          cin, cout, kh, kw, stride, ph, pw, kc, mld, wp_alt, {}, wp16, wp4, g4)
+                          cin, cout, kh, kw, stride, ph, pw, kc, mld, wp_alt, {}, wp16, wp4, g4,
+                          pack_conv_weight_thin(weight) if (cout <= 4 and stride == 1 and cin >= 32) else None)
 
     def out_hw(self, h: int, w: int) -> Tuple[int, int]:
         return ((h + 2 * self.pad_h - self.kh) // self.stride + 1,
@@ -261,6 +276,8 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
     # hide.  Stage 32 channels per chunk instead when that packing fits (decided once per shape).
     if _CONV_PRECISION == 'f16x3' and pc.wp16 is not None:
         d.wp_f16 = pc.wp16.data_ptr()
+    if pc.wthin is not None:
+        d.wp_thin = pc.wthin.data_ptr()
     if pc.wp4 is not None:
         d.wp_a4, d.a4_groups, d.a4_mld = pc.wp4.data_ptr(), pc.g4, pc.mld
     if pc.wp_alt is not None and (c1 == 0 or c0 % 32 == 0):

@@ -152,6 +152,76 @@ def test_conv2d(case):
     close(got, want, atol=2e-5, what=str(case))
 
 
+# shapes large enough for the LDS-DMA kernel (>= 256 blocks), one per tile shape / chunk regime
+DMA_CASES = [
+    # n, cin, cout, k, pad, H, W                      expected tile
+    (32, 64, 64, (3, 3), (1, 1), 64, 64),           # (2,2)
+    (16, 96, 96, (3, 3), (1, 1), 64, 64),           # (3,1), > 64 KB LDS
+    (32, 128, 128, (1, 5), (0, 2), 32, 32),         # (2,1), G=2
+    (32, 128, 128, (5, 1), (2, 0), 32, 32),         # G=2, tall window
+    (32, 60, 126, (3, 3), (1, 1), 32, 32),          # channel tail (60 = 7*8 + 4), ragged couts
+    (64, 24, 40, (3, 3), (1, 1), 24, 40),           # (1,1), ragged tiles (Wo = 40, Ho = 24)
+]
+
+
+@pytest.mark.parametrize('case', DMA_CASES)
+def test_conv2d_dma_kernel(case):
+    import ctypes as C
+    n, cin, cout, k, p, H, W = case
+    x = rnd((n, cin, H, W), 30)
+    wt = rnd((cout, cin, *k), 31, (1.0 / (cin * k[0] * k[1])) ** 0.5)
+    b = rnd((cout,), 32, 0.1)
+    res = rnd((n, cout, H, W), 33)
+    want = torch.relu(F.conv2d(x, wt, b, padding=p) + res)
+    pc = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), padding=p)
+    assert pc.wp4 is not None
+    got = ops.conv2d(pc, x.to(DEV), res=res.to(DEV), act=ops.ACT_RELU)
+    close(got, want, atol=3e-5, what=str(case))
+    # the register-staged kernel must give the same numbers up to summation order
+    os.environ['SCF_TEST_NO_A4'] = '1'
+    try:
+        pc2 = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), padding=p)
+    finally:
+        del os.environ['SCF_TEST_NO_A4']
+    assert pc2.wp4 is None
+    ref = ops.conv2d(pc2, x.to(DEV), res=res.to(DEV), act=ops.ACT_RELU)
+    close(got, ref.cpu(), atol=3e-5, what='dma vs register-staged ' + str(case))
+
+
+def test_conv2d_dma_two_segments_gru_q():
+    """the GRU candidate conv on the DMA kernel: two input segments, tanh gate epilogue."""
+    n, h, w = 32, 32, 32
+    hh, xx = rnd((n, 128, h, w), 40), rnd((n, 256, h, w), 41)
+    z = torch.sigmoid(rnd((n, 128, h, w), 42))
+    wt = rnd((128, 384, 1, 5), 43, 0.02)
+    b = rnd((128,), 44, 0.1)
+    rh = torch.sigmoid(rnd((n, 128, h, w), 45)) * hh
+    q = torch.tanh(F.conv2d(torch.cat([rh, xx], 1), wt, b, padding=(0, 2)))
+    want = (1 - z) * hh + z * q
+    pc = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), padding=(0, 2))
+    out = torch.empty((n, 128, h, w), device=DEV)
+    ops.conv2d(pc, rh.to(DEV), xx.to(DEV), out=out, mode=ops.CONV_GRU_Q, gru_h=hh.to(DEV),
+               gru_z=z.to(DEV))
+    close(out, want, atol=3e-5, what='gru q on dma kernel')
+
+
+@pytest.mark.parametrize('cout,k', [(2, 3), (1, 1), (1, 3), (4, 3), (3, 1)])
+def test_conv2d_thin_output(cout, k):
+    """Cout <= 4 layers (flow / mask prediction) run on the vector-ALU kernel."""
+    n, cin, H, W = 3, 256, 32, 32
+    x = rnd((n, cin + 64, H, W), 50)
+    wt = rnd((cout, cin, k, k), 51, (1.0 / (cin * k * k)) ** 0.5)
+    b = rnd((cout,), 52, 0.1)
+    for act, fn in ((ops.ACT_NONE, lambda t: t), (ops.ACT_SIGMOID, torch.sigmoid)):
+        want = fn(F.conv2d(x[:, 64:], wt, b, padding=k // 2))
+        pc = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), padding=k // 2)
+        got = ops.conv2d(pc, x.to(DEV)[:, 64:], act=act)        # channel-slice view as input
+        close(got, want, atol=2e-5, what=f'thin {cout} {k} {act}')
+    xs = rnd((2, cin, 12, 20), 53)                              # ragged tile
+    pc = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), padding=k // 2)
+    close(ops.conv2d(pc, xs.to(DEV)), F.conv2d(xs, wt, b, padding=k // 2), atol=2e-5, what='thin ragged')
+
+
 def test_conv2d_two_segments_into_channel_slice():
     n, h, w = 2, 16, 16
     xa, xb = rnd((n, 192, h, w), 20), rnd((n, 64, h, w), 21)
