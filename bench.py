@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+MFMA_F32_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 LOOKUP_BYTES_PER_QUERY = 2904  # 4*(10*10*4) read + 8 flow + 4*(9*9*4) write
 
@@ -162,6 +163,11 @@ def main():
         return el, lk
 
     dt, lookup_us = timed(args.precision)
+    # the kernels that dominate the step by TIME are the fp32 MFMA convolutions: one extra
+    # (untimed) step with every conv launch bracketed by events on its stream
+    ops.conv_timing(True)
+    step()
+    conv_launches = ops.conv_timing(False)
     alt = None
     if not args.no_alt:
         other = 'f16x3' if args.precision == 'f32' else 'f32'
@@ -201,7 +207,7 @@ def main():
                        'batch_per_gpu': args.batch, 'global_batch': args.batch * world,
                        'height': 256, 'width': 256, 'iters': args.iters,
                        'parallelism': f'batch-split x{world}, no data-path collective'},
-            'roofline': {'kernel': 'corr_lookup_kernel<4>', 'bound': 'hbm',
+            'roofline': {'kernel': 'corr_lookup_kernel<4, true>', 'bound': 'hbm',
                          'achieved': None if achieved is None else round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
@@ -210,6 +216,27 @@ def main():
                          'avg_launch_us': round(avg_us, 2), 'launches_timed': len(lookup_us),
                          'algorithmic_bytes_per_launch': LOOKUP_BYTES_PER_QUERY * q},
         }
+        rk = pmc.get('rocprof_kernel_trace')
+        if rk:      # committed `rocprofv3 --kernel-trace --stats` pass of this command (profiles/)
+            result['roofline']['rocprof_avg_launch_us'] = rk['avg_us']
+            result['roofline']['note'] = (
+                'achieved/frac use the live event-to-event time, which includes ~3 us of dispatch '
+                'per launch; the kernel-trace duration of the same kernel in profiles/ is '
+                f"{rk['avg_us']} us = {LOOKUP_BYTES_PER_QUERY * q / rk['avg_us'] / 1e3:.0f} GB/s = "
+                f"{LOOKUP_BYTES_PER_QUERY * q / rk['avg_us'] / 1e3 / HBM_PEAK_GBS:.3f} of peak")
+        if conv_launches:
+            c_us = sum(u for u, _ in conv_launches)
+            c_fl = sum(f for _, f in conv_launches)
+            result['roofline_conv'] = {
+                'kernel': 'conv_dma_kernel / conv_mfma_kernel (all convolution launches of one step)',
+                'bound': 'mfma', 'achieved': round(c_fl / (c_us * 1e-6) / 1e12, 1),
+                'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(c_fl / (c_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                'launches_timed': len(conv_launches), 'conv_us_per_step': round(c_us, 1),
+                'share_of_step': round(c_us * 1e-6 / (dt / args.steps), 3),
+                'algorithmic_flops_per_step': c_fl,
+                'note': 'v_mfma_f32_32x32x2_f32 (exact fp32), dense peak 256 CU x 256 flop/clk x 2.4 GHz; '
+                        'flops = 2*Cin*KH*KW*Cout*Ho*Wo*N per launch; events on the launch stream'}
 
     # ---- config[1]: single pair latency (rank 0, informational) ----
     if rank == 0 and world == 1 and not args.no_batch1:

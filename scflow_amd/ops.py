@@ -295,8 +295,30 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
             pc.plans[key] = use_alt
         if use_alt:
             d.wp, d.KC = pc.wp_alt.data_ptr(), 32
+    ev = None
+    if _CONV_EVENTS is not None:        # bench.py: per-launch HIP events + algorithmic flops
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     _lib.check(_lib.load().scf_conv2d(C.byref(d), _stream()), 'scf_conv2d')
+    if ev is not None:
+        ev[1].record()
+        _CONV_EVENTS.append((ev[0], ev[1], 2.0 * pc.cin * pc.kh * pc.kw * pc.cout * ho * wo * n))
     return out
+
+
+_CONV_EVENTS = None
+
+
+def conv_timing(enable: bool):
+    """like ``lookup_timing`` for the convolution launches: enable=False returns a list of
+    (microseconds, algorithmic flops = 2*Cin*KH*KW*Cout*Ho*Wo*N) per launch."""
+    global _CONV_EVENTS
+    if enable:
+        _CONV_EVENTS = []
+        return None
+    evs, _CONV_EVENTS = _CONV_EVENTS or [], None
+    torch.cuda.synchronize()
+    return [(a.elapsed_time(b) * 1e3, fl) for a, b, fl in evs]
 
 
 # ----------------------------------------------------- correlation volume

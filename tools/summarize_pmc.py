@@ -8,6 +8,7 @@ tensor."""
 import csv, json, re, sys, collections
 
 fetch_csv, write_csv, out_json, tag = sys.argv[1:5]
+stats_csv = sys.argv[5] if len(sys.argv) > 5 else None      # --kernel-trace --stats pass (no PMC)
 
 
 def per_kernel(path, counter):
@@ -38,5 +39,11 @@ out = {
               f'{tag}; KiB units, FETCH_SIZE x2 (gfx950 correction, calibration factor measured '
               f'{factor:.2f})',
 }
+if stats_csv:
+    for r in csv.DictReader(open(stats_csv)):
+        if 'corr_lookup' in r['Name']:
+            out['rocprof_kernel_trace'] = {'calls': int(r['Calls']), 'avg_us': round(float(r['AverageNs']) / 1e3, 2),
+                                           'min_us': round(float(r['MinNs']) / 1e3, 2),
+                                           'max_us': round(float(r['MaxNs']) / 1e3, 2)}
 json.dump(out, open(out_json, 'w'), indent=1)
 print(json.dumps(out, indent=1))
