@@ -1,4 +1,4 @@
-// Stride-1 fp32 convolution, second generation of the implicit-GEMM kernel in conv_mfma.hip
+// Stride-1 / stride-2 fp32 convolution, second generation of the implicit-GEMM kernel in conv_mfma.hip
 // (same GEMM view, same v_mfma_f32_32x32x2_f32 arithmetic and k order, same fused epilogue):
 //
 //   * operands are staged by LDS-DMA (global_load_lds): memory -> LDS without passing through
@@ -86,8 +86,12 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   const int tyi = t2 % p.tiles_y;
   const int n = t2 / p.tiles_y;
   const int ty0 = tyi * TR, tx0 = txi * FC;
-  const int iy0 = ty0 - p.pad_h, ix0 = tx0 - p.pad_w;
-  const int PW = p.PW, PHW = p.PH * p.PW;
+  const int st = p.stride;             // 1 or 2
+  const int iy0 = ty0 * st - p.pad_h, ix0 = tx0 * st - p.pad_w;
+  // PW = LDS row pitch of the patch.  Stride 2: a row is stored even columns first, then odd
+  // columns (PWh each), so that the 32 lanes of a fragment read consecutive float4 cells for
+  // every tap (no bank conflicts): input column 2*fc + kx lives at (kx&1)*PWh + fc + (kx>>1).
+  const int PW = p.PW, PHW = p.PH * p.PW, PWh = PW >> 1;
   const int T = p.T, G = p.G4, KC = 8 * G;
   const int NIT = T * G;               // (tap, group) steps per chunk, 4 k-steps each
   const int WF4 = NIT * 2 * BM;        // weight float4 per chunk
@@ -115,10 +119,11 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
     if (u * 256 < PE) {
       const int s = e & 3, q = e >> 2;
       const int gh = fast_div(q, PHW, rPHW), r = q - gh * PHW;
-      const int py = fast_div(r, PW, rPW), px = r - py * PW;
+      const int py = fast_div(r, PW, rPW), pxs = r - py * PW;
+      const int px = st == 1 ? pxs : (pxs >= PWh ? 2 * (pxs - PWh) + 1 : 2 * pxs);
       const int c = 8 * (gh >> 1) + 2 * s + (gh & 1);
       const int iy = iy0 + py, ix = ix0 + px;
-      ok = e < PE && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      ok = e < PE && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && px < p.PWin;
       o = (unsigned)(c * HWin + iy * p.W + ix) * 4u;
     }
     toff[u] = ok ? o : 0xFFFFFFFFu;
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   const int fr = l32 >> p.fc_log2, fc = l32 & (FC - 1);
   int boff[WN];                        // float4 index of this lane's pixel, fragment j, tap (0,0)
 #pragma unroll
-  for (int j = 0; j < WN; ++j) boff[j] = ((wave * WN + j) * FR + fr) * PW + fc + half * PHW;
+  for (int j = 0; j < WN; ++j) boff[j] = ((wave * WN + j) * FR + fr) * st * PW + fc + half * PHW;
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
     int lg = 0, lky = 0, lkx = 0;                     // (tap, group) of the next operand load
     auto load = [&](f32x4 (&aa)[WM], f32x4 (&bb)[WN], int it) {
       const f32x4* wt = wl + it * 2 * BM;
-      const f32x4* pt = pl + lg * 2 * PHW + lky * PW + lkx;
+      const f32x4* pt = pl + lg * 2 * PHW + lky * PW + (st == 1 ? lkx : (lkx & 1) * PWh + (lkx >> 1));
 #pragma unroll
       for (int i = 0; i < WM; ++i) aa[i] = wt[i * 32];
 #pragma unroll
@@ -262,7 +267,7 @@ static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st
 // SCF_EUNSUPPORTED -> the caller falls back to the register-staged kernel (strided layers,
 // thin inputs, tiny grids, shapes that exceed the DMA kernel's staging budget).
 int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st) {
-  if (!k.wp4 || k.stride != 1 || k.w_ns != 0) return SCF_EUNSUPPORTED;
+  if (!k.wp4 || (k.stride != 1 && k.stride != 2) || k.w_ns != 0) return SCF_EUNSUPPORTED;
   const int G = k.G4;
   if (G != 1 && G != 2 && G != 4) return SCF_EUNSUPPORTED;
   const int KC = 8 * G;
@@ -282,7 +287,8 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
       if (WM > frags_m) continue;
       if (pass == 0 && frags_m % WM != 0) continue;
       const int TR = WN * 4 * FR;
-      const int PH = TR - 1 + k.KH, PW = FC - 1 + k.KW;
+      const int PH = (TR - 1) * k.stride + k.KH, PWin = (FC - 1) * k.stride + k.KW;
+      const int PW = k.stride == 1 ? PWin : ((PWin + 1) / 2) * 2;
       const long long PE = (long long)KC * PH * PW;
       const long long WF4 = (long long)k.T * G * 2 * WM * 32;
       const size_t ldsb = (size_t)(WF4 * 4 + PE) * 2 * sizeof(float);
@@ -296,8 +302,9 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   if (best < 0 || best_blk < 256 || best_blk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
   const int WM = cand[best][0], WN = cand[best][1];
   const int TR = WN * 4 * FR;
-  k.PH = TR - 1 + k.KH;
-  k.PW = FC - 1 + k.KW;
+  k.PH = (TR - 1) * k.stride + k.KH;
+  k.PWin = (FC - 1) * k.stride + k.KW;                       // input columns a tile needs
+  k.PW = k.stride == 1 ? k.PWin : ((k.PWin + 1) / 2) * 2;     // LDS row pitch
   k.tiles_y = (k.Ho + TR - 1) / TR;
   k.tiles_x = (k.Wo + FC - 1) / FC;
   k.mblocks = (frags_m + WM - 1) / WM;

@@ -13,7 +13,7 @@ struct ConvK {
   const float* wp4; int G4, Mld4;   // LDS-DMA packing (conv_dma.hip) or nullptr
   int Mld, Cout, Krows;
   int KH, KW, T, stride, pad_h, pad_w, KC, nchunk;
-  int fc_log2, tiles_x, tiles_y, mblocks, PH, PW;
+  int fc_log2, tiles_x, tiles_y, mblocks, PH, PW, PWin;
   int wvec;
   int out_tile;              // 1: 8x4-float tiled output planes (correlation level 0)
   int ksplit;                // 32-pixel tile, the 4 waves split the k-steps (small grids)

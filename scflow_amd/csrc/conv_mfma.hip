@@ -515,7 +515,7 @@ static bool want_f16x3(const scf_conv_desc* d) {
 
 static bool want_dma(const scf_conv_desc* d) {
   static const bool off = [] { const char* e = getenv("SCF_CONV_DMA"); return e && e[0] == '0'; }();   // A/B knob
-  return !off && d->wp_a4 != nullptr && d->stride == 1 && d->w_nstride == 0 && d->a4_mld >= d->Cout;
+  return !off && d->wp_a4 != nullptr && (d->stride == 1 || d->stride == 2) && d->w_nstride == 0 && d->a4_mld >= d->Cout;
 }
 
 extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {

@@ -161,26 +161,31 @@ DMA_CASES = [
     (32, 128, 128, (5, 1), (2, 0), 32, 32),         # G=2, tall window
     (32, 60, 126, (3, 3), (1, 1), 32, 32),          # channel tail (60 = 7*8 + 4), ragged couts
     (64, 24, 40, (3, 3), (1, 1), 24, 40),           # (1,1), ragged tiles (Wo = 40, Ho = 24)
+    (32, 224, 128, (3, 3), (1, 1), 32, 32, 2),      # stride 2 (pose head c0): parity-split patch rows
+    (64, 64, 96, (3, 3), (1, 1), 64, 64, 2),        # stride 2, FC = 32
+    (64, 32, 64, (3, 3), (1, 1), 30, 22, 2),        # stride 2, odd sizes, ragged tiles
 ]
 
 
 @pytest.mark.parametrize('case', DMA_CASES)
 def test_conv2d_dma_kernel(case):
     import ctypes as C
-    n, cin, cout, k, p, H, W = case
+    n, cin, cout, k, p, H, W = case[:7]
+    st = case[7] if len(case) > 7 else 1
     x = rnd((n, cin, H, W), 30)
     wt = rnd((cout, cin, *k), 31, (1.0 / (cin * k[0] * k[1])) ** 0.5)
     b = rnd((cout,), 32, 0.1)
-    res = rnd((n, cout, H, W), 33)
-    want = torch.relu(F.conv2d(x, wt, b, padding=p) + res)
-    pc = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), padding=p)
+    want = F.conv2d(x, wt, b, stride=st, padding=p)
+    res = rnd(tuple(want.shape), 33)
+    want = torch.relu(want + res)
+    pc = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), stride=st, padding=p)
     assert pc.wp4 is not None
     got = ops.conv2d(pc, x.to(DEV), res=res.to(DEV), act=ops.ACT_RELU)
     close(got, want, atol=3e-5, what=str(case))
     # the register-staged kernel must give the same numbers up to summation order
     os.environ['SCF_TEST_NO_A4'] = '1'
     try:
-        pc2 = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), padding=p)
+        pc2 = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), stride=st, padding=p)
     finally:
         del os.environ['SCF_TEST_NO_A4']
     assert pc2.wp4 is None
