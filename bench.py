@@ -168,6 +168,21 @@ def main():
     ops.conv_timing(True)
     step()
     conv_launches = ops.conv_timing(False)
+    # north_star: MFMA utilisation of the correlation-volume build (dense fmap1 . fmap2^T).  The
+    # level-0 contraction alone (num_levels=1: no pooling cascade), same shapes as in the step.
+    fa = torch.randn((args.batch, 256, 32, 32), device=device)
+    fb = torch.randn((args.batch, 256, 32, 32), device=device)
+    lv0 = [torch.empty((args.batch * 1024, 1, 32, 32), device=device)]
+    for _ in range(3):
+        ops.corr_build(fa, fb, 1, out=lv0, level0_tiled=True)
+    cb_ev = []
+    for _ in range(10):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); ops.corr_build(fa, fb, 1, out=lv0, level0_tiled=True); e1.record()
+        cb_ev.append((e0, e1))
+    torch.cuda.synchronize()
+    cb_us = sum(a.elapsed_time(b) for a, b in cb_ev) / len(cb_ev) * 1e3
+    del fa, fb, lv0
     alt = None
     if not args.no_alt:
         other = 'f16x3' if args.precision == 'f32' else 'f32'
@@ -224,6 +239,16 @@ def main():
                 'per launch; the kernel-trace duration of the same kernel in profiles/ is '
                 f"{rk['avg_us']} us = {LOOKUP_BYTES_PER_QUERY * q / rk['avg_us'] / 1e3:.0f} GB/s = "
                 f"{LOOKUP_BYTES_PER_QUERY * q / rk['avg_us'] / 1e3 / HBM_PEAK_GBS:.3f} of peak")
+        cb_fl = 2.0 * 256 * 1024 * 1024 * args.batch
+        result['roofline_corr_build'] = {
+            'kernel': 'conv_mfma_kernel<4, 1, 32> with per-sample weights (scf_corr_build level 0: '
+                      'fmap1 . fmap2^T / sqrt(C), 8x4-tiled store)', 'bound': 'mfma',
+            'achieved': round(cb_fl / (cb_us * 1e-6) / 1e12, 1), 'peak': MFMA_F32_PEAK_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': round(cb_fl / (cb_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+            'avg_launch_us': round(cb_us, 1), 'launches_timed': len(cb_ev),
+            'algorithmic_flops_per_launch': cb_fl,
+            'note': f'2*C*(h*w)^2 flops per pair, C=256, h=w=32, {args.batch} pairs; the launch also '
+                    'writes the 4*(h*w)^2 B volume per pair'}
         if conv_launches:
             c_us = sum(u for u, _ in conv_launches)
             c_fl = sum(f for _, f in conv_launches)

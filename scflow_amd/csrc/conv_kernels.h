@@ -21,6 +21,7 @@ struct ConvK {
   const float* bias; const float* scale; const float* shift;
   const float* res; long long res_ns;
   float out_div;
+  int out_div_pow2;          // out_div is an exact power of two
   int act, act2, act_split, mode;
   const float* gru_h; long long gru_h_ns;
   float* gru_aux; long long gru_aux_ns;
@@ -78,8 +79,16 @@ __device__ __forceinline__ void scf_epi_affine_group(const ConvK& p, const ConvE
   const bool full = cb + 3 < p.Cout;
   float v[4] = {acc[0], acc[1], acc[2], acc[3]};
   if (use_div) {
+    // a power-of-two divisor (sqrt(C) for C = 64, 256, 1024: the SCFlow feature widths) is an
+    // exact multiply by its reciprocal; anything else takes the correctly rounded division
+    if (p.out_div_pow2) {
+      const float rd = 1.0f / p.out_div;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = v[q] / p.out_div;
+      for (int q = 0; q < 4; ++q) v[q] = v[q] * rd;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = v[q] / p.out_div;
+    }
   }
   int off = cb * e.HWo + pix;
   float r[4] = {0.f, 0.f, 0.f, 0.f};

@@ -430,6 +430,10 @@ static int conv_plan(const scf_conv_desc* d, ConvPlan* plan) {
   k.bias = d->bias; k.scale = d->scale; k.shift = d->shift;
   k.res = d->res; k.res_ns = d->res_nstride;
   k.out_div = d->out_div == 0.f ? 1.f : d->out_div;
+  {
+    int ex = 0;
+    k.out_div_pow2 = (k.out_div > 0.f && frexpf(k.out_div, &ex) == 0.5f) ? 1 : 0;
+  }
   k.act = d->act; k.act2 = d->act2; k.act_split = d->act_split; k.mode = d->mode;
   k.gru_h = d->gru_h; k.gru_h_ns = d->gru_h_nstride;
   k.gru_aux = d->gru_aux; k.gru_aux_ns = d->gru_aux_nstride;
