@@ -121,7 +121,7 @@ def choose_a4_groups(cin: int, kh: int, kw: int, stride: int) -> int:
     """8G channels per staged chunk of the LDS-DMA kernel (0: layer not eligible)."""
     t = kh * kw
     if stride not in (1, 2) or cin < 8 or t >= 25 or t == 1:   # 1x1: chunks too short for the DMA pipeline
-        return 0
+        return 0                                                 # (measured 54 vs 62-70 TF/s)
     return 2 if t <= 5 else 1
 
 
