@@ -197,9 +197,11 @@ class PackedConv:
     @staticmethod
     def from_weight(weight: Tensor, bias: Optional[Tensor], stride: int = 1,
                     padding=0, bn: Optional[Sequence[Tensor]] = None,
-                    eps: float = 1e-5) -> 'PackedConv':
+                    eps: float = 1e-5, dma_packing: bool = True) -> 'PackedConv':
         """``bn`` = (gamma, beta, running_mean, running_var): eval-mode BatchNorm
-        folded into a per-channel scale/shift applied after the bias."""
+        folded into a per-channel scale/shift applied after the bias.  ``dma_packing=False``
+        leaves out the LDS-DMA kernel's packing (the layer then runs on the register-staged
+        kernel; used by the A/B parity tests)."""
         cout, cin, kh, kw = weight.shape
         kc = choose_kc(cin, kh, kw, stride)
         wp, mld = pack_conv_weight(weight, kc)
@@ -211,7 +213,7 @@ class PackedConv:
             gamma, beta, mean, var = [b.float() for b in bn]
             scale = (gamma / torch.sqrt(var + eps)).contiguous()
             shift = (beta - mean * scale).contiguous()
-        g4 = 0 if os.environ.get('SCF_TEST_NO_A4') else choose_a4_groups(cin, kh, kw, stride)
+        g4 = choose_a4_groups(cin, kh, kw, stride) if dma_packing else 0
         wp4 = pack_conv_weight_a4(weight, g4)[0] if g4 else None
         return PackedConv(wp, None if bias is None else bias.float().contiguous(), scale, shift,
                           cin, cout, kh, kw, stride, ph, pw, kc, mld, wp_alt, {}, wp16, wp4, g4,

@@ -183,11 +183,7 @@ def test_conv2d_dma_kernel(case):
     got = ops.conv2d(pc, x.to(DEV), res=res.to(DEV), act=ops.ACT_RELU)
     close(got, want, atol=3e-5, what=str(case))
     # the register-staged kernel must give the same numbers up to summation order
-    os.environ['SCF_TEST_NO_A4'] = '1'
-    try:
-        pc2 = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), stride=st, padding=p)
-    finally:
-        del os.environ['SCF_TEST_NO_A4']
+    pc2 = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), stride=st, padding=p, dma_packing=False)
     assert pc2.wp4 is None
     ref = ops.conv2d(pc2, x.to(DEV), res=res.to(DEV), act=ops.ACT_RELU)
     close(got, ref.cpu(), atol=3e-5, what='dma vs register-staged ' + str(case))

@@ -118,3 +118,42 @@ def test_checkpoint_ingestion(tmp_path, golden_dir):
     assert model.render_encoder.__dict__['_packed'] is None       # kernel-layout cache dropped
     for k, v in model.state_dict().items():
         assert torch.equal(v, sd[k]), k
+
+
+# ------------------------------------------------------------ weight packings (host logic)
+def test_pack_conv_weight_a4_layout():
+    """[chunk][tap][g][h][Mld][4]: channel chunk*8G + 8g + 2s + h at float s (conv_dma.hip)."""
+    from scflow_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for cout, cin, kh, kw, G in ((40, 20, 3, 3, 1), (64, 48, 1, 5, 2), (33, 70, 3, 3, 1)):
+        w = torch.randn((cout, cin, kh, kw), generator=g)
+        flat, mld = ops.pack_conv_weight_a4(w, G)
+        t, kc = kh * kw, 8 * G
+        nchunk = (cin + kc - 1) // kc
+        assert mld == (cout + 31) // 32 * 32
+        p = flat.reshape(nchunk, t, G, 2, mld, 4)
+        for (m, c, tap) in ((0, 0, 0), (cout - 1, cin - 1, t - 1), (7, 13, t // 2), (cout // 2, 9, 1 % t)):
+            chunk, r = divmod(c, kc)
+            gg, r = divmod(r, 8)
+            s, h = divmod(r, 2)
+            assert p[chunk, tap, gg, h, m, s] == w[m, c, tap // kw, tap % kw]
+        # padded channels / couts are zero
+        assert float(p[:, :, :, :, cout:, :].abs().sum()) == 0.0
+        total = float(p.abs().sum())
+        assert abs(total - float(w.abs().sum())) <= 1e-3 * total
+
+
+def test_pack_conv_weight_thin_layout_and_eligibility():
+    from scflow_amd import ops
+    w = torch.randn((2, 40, 3, 3), generator=torch.Generator().manual_seed(4))
+    flat = ops.pack_conv_weight_thin(w)
+    assert flat.numel() % 4 == 0
+    p = flat[:40 * 9 * 2].reshape(40, 9, 2)
+    assert p[17, 5, 1] == w[1, 17, 1, 2] and p[0, 0, 0] == w[0, 0, 0, 0]
+    w3 = torch.randn((3, 32, 1, 1))
+    assert ops.pack_conv_weight_thin(w3)[:32 * 4].reshape(32, 1, 4)[:, 0, 3].abs().sum() == 0   # CO = 4
+    # which layers get the LDS-DMA packing
+    assert ops.choose_a4_groups(64, 3, 3, 1) == 1 and ops.choose_a4_groups(384, 1, 5, 1) == 2
+    assert ops.choose_a4_groups(224, 3, 3, 2) == 1
+    assert ops.choose_a4_groups(324, 1, 1, 1) == 0 and ops.choose_a4_groups(3, 7, 7, 2) == 0
+    assert ops.choose_a4_groups(2, 3, 3, 1) == 0
