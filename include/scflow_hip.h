@@ -178,6 +178,14 @@ int scf_reproject_flow(const float* depth, const float* K, const float* R0, cons
                        const float* R, const float* t, float* flow, int N, int H, int W,
                        float invalid_num, scf_stream_t stream);
 
+/* filter_flow_by_mask (models/utils/flow.py:6-26), in place on flow (N,2,H,W): a vector is set
+ * to invalid_num when both components are >= invalid_num or when mask (N,H,W), sampled
+ * bilinearly (zeros padding) at the vector's end point, is < 0.9.  The end point is normalised
+ * with (size-1) (coords_grid, warp.py:9-29) and de-normalised per align_corners, as the
+ * reference does (its default align_corners=0 therefore samples at (x+fx)*W/(W-1) - 0.5). */
+int scf_filter_flow_by_mask(float* flow, const float* mask, int N, int H, int W,
+                            float invalid_num, int align_corners, scf_stream_t stream);
+
 /* object-frame points of every pixel (dense cal_3d_2d_corr): pts (N,3,H,W), 0 where
  * depth <= 0.  Test/diagnostic entry; scf_reproject_flow recomputes them on the fly. */
 int scf_unproject_depth(const float* depth, const float* K, const float* R0, const float* t0,

@@ -27,7 +27,7 @@ __all__ = [
     'rotation_from_ortho6d', 'pose_from_delta_pose', 'unproject_depth',
     'flow_from_pose_and_points', 'scflow_decoder', 'extract_feat',
     'get_pose', 'end_point_error', 'convex_upsample', 'raft_decoder', 'raft_decoder_mask',
-    'cal_epe',
+    'cal_epe', 'flow_from_delta_pose_and_depth', 'coords_grid', 'filter_flow_by_mask',
 ]
 
 
@@ -417,6 +417,48 @@ def raft_decoder_mask(feat1: Tensor, feat2: Tensor, flow: Tensor, h_feat: Tensor
         flows.append(convex_upsample(flow, mask, scale, 2 * radius + 1, x_mul=float(scale)))
         occs.append(convex_upsample(occ, mask, scale, 2 * radius + 1))
     return flows, occs
+
+
+def flow_from_delta_pose_and_depth(rotation_src: Tensor, translation_src: Tensor,
+                                   rotation_dst: Tensor, translation_dst: Tensor,
+                                   depth_src: Tensor, k: Tensor, invalid_num: float = 400.) -> Tensor:
+    """utils/pose.py:92-121 ``get_flow_from_delta_pose_and_depth`` (ground-truth flow of the
+    RAFT refiners, raft_refiner_flow_mask.py:180): un-project the source depth with the source
+    pose (``cal_3d_2d_corr``), project with the destination pose, background = invalid_num."""
+    n = rotation_src.shape[0]
+    h, w = depth_src.shape[-2:]
+    p2, p3 = [], []
+    for i in range(n):
+        a, b = unproject_depth(depth_src[i], k[i], rotation_src[i], translation_src[i])
+        p2.append(a)
+        p3.append(b)
+    return flow_from_pose_and_points(rotation_dst, translation_dst, k, p2, p3, h, w, invalid_num)
+
+
+def coords_grid(flow: Tensor) -> Tensor:
+    """utils/warp.py:9-29: pixel grid + flow, normalised with (size-1) -> (N,H,W,2)."""
+    b, _, h, w = flow.shape
+    yy, xx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+    grid = torch.stack([xx, yy], 0).float()[None].repeat(b, 1, 1, 1) + flow
+    gx = grid[:, 0] * 2. / max(w - 1, 1) - 1.
+    gy = grid[:, 1] * 2. / max(h - 1, 1) - 1.
+    return torch.stack([gx, gy], -1)
+
+
+def filter_flow_by_mask(flow: Tensor, gt_mask: Tensor, invalid_num: float = 400.,
+                        mode: str = 'bilinear', align_corners: bool = False) -> Tensor:
+    """utils/flow.py:6-26: a flow vector is invalid when both components are >= invalid_num or
+    when the target-image mask sampled at its end point is < 0.9 (zeros padding).  NB the grid is
+    normalised with (size-1) but sampled with ``align_corners=False`` by default, i.e. at
+    (x+fx)*W/(W-1) - 0.5 -- restated as-is.  Returns a new tensor (the reference writes in
+    place)."""
+    flow = flow.clone()
+    not_valid = (flow[:, 0] >= invalid_num) & (flow[:, 1] >= invalid_num)
+    m = F.grid_sample(gt_mask[:, None].to(flow.dtype), coords_grid(flow), mode=mode,
+                      padding_mode='zeros', align_corners=align_corners)
+    not_valid = (m < 0.9) | not_valid[:, None]
+    flow[not_valid.expand_as(flow)] = invalid_num
+    return flow
 
 
 def cal_epe(flow_tgt: Tensor, flow_pred: Tensor, mask, max_flow: float = 400,

@@ -192,3 +192,63 @@ extern "C" int scf_pose_update(const float* rot_all, const float* trans_all, con
                      d_rot, d_trans, R_out, t_out, N);
   return scf_launch_status();
 }
+
+
+// ---------------------------------------------------------------------------------
+// filter_flow_by_mask (models/utils/flow.py:6-26): ground-truth flow vectors whose end point
+// leaves the target-image mask are marked invalid.  Per pixel, in place:
+//   grid = ((x + fx) * 2 / max(W-1,1) - 1, ...)                (coords_grid, warp.py:9-29)
+//   m    = grid_sample(mask, grid, bilinear, zeros, align_corners)
+//   invalid <- m < 0.9  ||  (fx >= invalid_num && fy >= invalid_num)
+// The de-normalisation follows ATen's grid_sampler (align_corners=False: ((g+1)*size-1)/2).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void filter_flow_by_mask_kernel(float* __restrict__ flow,
+                                                                  const float* __restrict__ mask,
+                                                                  int N, int H, int W,
+                                                                  float invalid_num, int align_corners) {
+  const long long total = (long long)N * H * W;
+  const int HW = H * W;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(idx / HW), q = (int)(idx - (long long)n * HW);
+    const int y = q / W, x = q - y * W;
+    float* f = flow + (long long)n * 2 * HW + q;
+    const float fx = f[0], fy = f[HW];
+    const bool both = fx >= invalid_num && fy >= invalid_num;
+    const float gx = ((float)x + fx) * 2.f / (float)max(W - 1, 1) - 1.f;
+    const float gy = ((float)y + fy) * 2.f / (float)max(H - 1, 1) - 1.f;
+    const float ix = align_corners ? (gx + 1.f) / 2.f * (float)(W - 1) : ((gx + 1.f) * (float)W - 1.f) / 2.f;
+    const float iy = align_corners ? (gy + 1.f) / 2.f * (float)(H - 1) : ((gy + 1.f) * (float)H - 1.f) / 2.f;
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float x1f = x0f + 1.f, y1f = y0f + 1.f;
+    const float nw = (x1f - ix) * (y1f - iy), ne = (ix - x0f) * (y1f - iy);
+    const float sw = (x1f - ix) * (iy - y0f), se = (ix - x0f) * (iy - y0f);
+    const float* m = mask + (long long)n * HW;
+    float acc = 0.f;
+    // |ix| can be huge (invalid_num = 400 on a 64-px image): range-test in float first
+    const bool fin = ix > -2.f && ix < (float)W + 1.f && iy > -2.f && iy < (float)H + 1.f;
+    if (fin) {
+      const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+      const bool xa = x0 >= 0 && x0 < W, xb = x1 >= 0 && x1 < W;
+      const bool ya = y0 >= 0 && y0 < H, yb = y1 >= 0 && y1 < H;
+      if (ya && xa) acc += m[y0 * W + x0] * nw;
+      if (ya && xb) acc += m[y0 * W + x1] * ne;
+      if (yb && xa) acc += m[y1 * W + x0] * sw;
+      if (yb && xb) acc += m[y1 * W + x1] * se;
+    }
+    if (acc < 0.9f || both) {
+      f[0] = invalid_num;
+      f[HW] = invalid_num;
+    }
+  }
+}
+
+extern "C" int scf_filter_flow_by_mask(float* flow, const float* mask, int N, int H, int W,
+                                       float invalid_num, int align_corners, scf_stream_t stream) {
+  if (!flow || !mask || N <= 0 || H <= 0 || W <= 0) return SCF_EINVAL;
+  const long long total = (long long)N * H * W;
+  const int grid = (int)(scf_cdiv(total, 256) < 8192 ? scf_cdiv(total, 256) : 8192);
+  hipLaunchKernelGGL(filter_flow_by_mask_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), flow, mask,
+                     N, H, W, invalid_num, align_corners);
+  return scf_launch_status();
+}

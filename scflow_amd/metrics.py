@@ -1,4 +1,9 @@
-"""Evaluation metric of the flow path: ``cal_epe`` (reference models/utils/flow.py:64-88).
+"""Evaluation side of the flow path: ``cal_epe`` (reference
+models/utils/flow.py:64-88) and the ground-truth flow it is measured against --
+``get_flow_from_delta_pose_and_depth`` (models/utils/pose.py:92-121) and ``filter_flow_by_mask``
+(models/utils/flow.py:6-26), as the RAFT refiners build it (raft_refiner_flow_mask.py:180-191).
+The two flow functions run on the HIP kernels of the hot path (dense re-projection, one
+element-wise filter); ``cal_epe`` is a handful of torch reductions.
 
 Not a kernel: a handful of reductions over the final flow field, run once per evaluation
 batch with torch ops on whatever device the flows live on.  Restated as-is, including the
@@ -10,7 +15,28 @@ from __future__ import annotations
 
 import torch
 
-__all__ = ['cal_epe']
+__all__ = ['cal_epe', 'get_flow_from_delta_pose_and_depth', 'filter_flow_by_mask']
+
+
+def get_flow_from_delta_pose_and_depth(rotation_src, translation_src, rotation_dst, translation_dst,
+                                       depth_src, k, invalid_num: float = 400):
+    """models/utils/pose.py:92-121, same argument order -> (N,2,H,W); the reference's per-sample
+    nonzero / mm / scatter loop is one launch of ``reproject_flow_kernel``."""
+    from . import ops
+    return ops.reproject_flow(depth_src.contiguous(), k.contiguous(), rotation_src.contiguous(),
+                              translation_src.contiguous(), rotation_dst.contiguous(),
+                              translation_dst.contiguous(), invalid_num=float(invalid_num))
+
+
+def filter_flow_by_mask(flow, gt_mask, invalid_num: float = 400, mode: str = 'bilinear',
+                        align_corners: bool = False):
+    """models/utils/flow.py:6-26: modifies ``flow`` in place and returns it, like the reference."""
+    if mode != 'bilinear':
+        raise NotImplementedError("filter_flow_by_mask: mode='bilinear'")
+    from . import ops
+    if not flow.is_contiguous():
+        raise ValueError('filter_flow_by_mask works in place on a contiguous flow tensor')
+    return ops.filter_flow_by_mask_(flow, gt_mask.to(torch.float32).contiguous(), invalid_num, align_corners)
 
 
 def cal_epe(flow_tgt: torch.Tensor, flow_pred: torch.Tensor, mask, max_flow: float = 400,

@@ -471,6 +471,18 @@ def reproject_flow(depth: Tensor, k: Tensor, rot0: Tensor, trans0: Tensor, rot: 
     return out
 
 
+def filter_flow_by_mask_(flow: Tensor, mask: Tensor, invalid_num: float = 400.,
+                         align_corners: bool = False) -> Tensor:
+    """in-place ``filter_flow_by_mask`` (utils/flow.py:6-26); flow (N,2,H,W), mask (N,H,W)."""
+    n, two, h, w = flow.shape
+    if two != 2 or tuple(mask.shape) != (n, h, w):
+        raise _lib.ScflowHipError('filter_flow_by_mask: flow (N,2,H,W), mask (N,H,W)')
+    _lib.check(_lib.load().scf_filter_flow_by_mask(_dense(flow, 'flow'), _dense(mask, 'mask'), n, h, w,
+                                                   float(invalid_num), int(align_corners), _stream()),
+               'scf_filter_flow_by_mask')
+    return flow
+
+
 def unproject_depth(depth: Tensor, k: Tensor, rot0: Tensor, trans0: Tensor) -> Tensor:
     n, h, w = depth.shape
     out = torch.empty((n, 3, h, w), dtype=torch.float32, device=depth.device)

@@ -247,8 +247,34 @@ def main_next():
     save('cal_epe.npz', STUBS, tgt=tgt, pred=pred, mask=mask, **res)
 
 
+def main_gtflow():
+    """fixtures of SURVEY 8(f) row 3, second half: ground-truth flow generation."""
+    from models.utils.pose import get_flow_from_delta_pose_and_depth
+    from models.utils.flow import filter_flow_by_mask
+    inp = make_inputs(3, 48, 64, seed=21)
+    g = torch.Generator().manual_seed(5)
+    ang = torch.randn((3, 3), generator=g) * 0.05
+    rot_dst = torch.matrix_exp(torch.stack([torch.tensor(
+        [[0., -a[2], a[1]], [a[2], 0., -a[0]], [-a[1], a[0], 0.]]) for a in ang]))
+    rot_dst = torch.bmm(rot_dst, inp['ref_rotation'])
+    trans_dst = inp['ref_translation'] + torch.randn((3, 3), generator=g) * torch.tensor([8., 8., 20.])
+    flow = get_flow_from_delta_pose_and_depth(inp['ref_rotation'], inp['ref_translation'], rot_dst,
+                                              trans_dst, inp['depth'], inp['internel_k'], invalid_num=400)
+    mask = (inp['depth'] > 0).float()
+    mask[:, :, 40:] = 0.                      # part of the target silhouette missing
+    out = {}
+    for ac in (False, True):
+        out[f'filtered_ac{int(ac)}'] = filter_flow_by_mask(flow.clone(), mask, invalid_num=400,
+                                                          align_corners=ac)
+    save('gt_flow.npz', STUBS, depth=inp['depth'], k=inp['internel_k'], rot_src=inp['ref_rotation'],
+         trans_src=inp['ref_translation'], rot_dst=rot_dst, trans_dst=trans_dst, flow=flow,
+         mask=mask, **out)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'next':
         main_next()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'gtflow':
+        main_gtflow()
     else:
         main()

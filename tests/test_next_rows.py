@@ -146,3 +146,42 @@ def test_raft_flow_refiner_480x640_config5(golden_dir):
     epe = oracle.end_point_error(flows[-1].cpu(), wf[-1])
     assert epe <= 1e-3, f'EPE {epe:.2e}'
     _close(occs[-1], wo[-1], atol=1e-4, what='occlusion')
+
+
+# ------------------------------------------------ ground-truth flow generation (8(f) row 3)
+def test_oracle_gt_flow_matches_reference_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'gt_flow.npz'))
+    T = lambda k: torch.from_numpy(g[k])
+    f = oracle.flow_from_delta_pose_and_depth(T('rot_src'), T('trans_src'), T('rot_dst'), T('trans_dst'),
+                                              T('depth'), T('k'), 400.)
+    assert torch.equal(f, T('flow'))
+    for ac in (0, 1):
+        assert torch.equal(oracle.filter_flow_by_mask(T('flow'), T('mask'), 400., align_corners=bool(ac)),
+                           T(f'filtered_ac{ac}'))
+
+
+@pytest.mark.gpu
+def test_gt_flow_generation_hip(golden_dir):
+    from scflow_amd import metrics
+    g = np.load(os.path.join(golden_dir, 'gt_flow.npz'))
+    D = lambda k: torch.from_numpy(g[k]).to('cuda:0')
+    flow = metrics.get_flow_from_delta_pose_and_depth(D('rot_src'), D('trans_src'), D('rot_dst'),
+                                                      D('trans_dst'), D('depth'), D('k'), invalid_num=400)
+    want = torch.from_numpy(g['flow'])
+    assert torch.equal(flow.cpu()[:, 0] >= 400, want[:, 0] >= 400)          # same foreground
+    assert float((flow.cpu() - want).abs().max()) < 2e-3                    # px, |flow| ~ 10 px
+    for ac in (0, 1):
+        # start from the reference's own flow so that the 0.9 threshold sees identical end points
+        got = metrics.filter_flow_by_mask(D('flow').clone(), D('mask'), invalid_num=400, align_corners=bool(ac))
+        ref = torch.from_numpy(g[f'filtered_ac{ac}'])
+        mism = (got.cpu() != ref).any(dim=1).float().mean().item()
+        assert mism < 1e-3, mism               # a sample landing within 1 ulp of 0.9 may flip
+    # a larger random case against the oracle
+    n, h, w = 4, 96, 128
+    gen = torch.Generator().manual_seed(9)
+    fl = torch.randn((n, 2, h, w), generator=gen) * 6
+    fl[:, :, :10] = 400.
+    mk = (torch.rand((n, h, w), generator=gen) > 0.3).float()
+    want = oracle.filter_flow_by_mask(fl, mk, 400.)
+    got = metrics.filter_flow_by_mask(fl.clone().to('cuda:0'), mk.to('cuda:0'), 400).cpu()
+    assert (got != want).any(dim=1).float().mean().item() < 1e-3
