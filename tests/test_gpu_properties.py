@@ -1,0 +1,102 @@
+"""GPU: size-independent properties of the hot path at BASELINE.json's FULL sizes (configs[2]:
+batch 32, 256x256 -> h = w = 32, 8 iterations; configs[4] shape for the lookup), where the CPU
+oracle would take minutes.  Each property is exact in real arithmetic; tolerances only cover
+fp32 rounding.  All calls go through the C-ABI (scflow_amd.ops -> libscflow_hip.so)."""
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import scflow_amd
+from scflow_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def rnd(shape, seed, scale=1.0):
+    return (torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale).to(DEV)
+
+
+@pytest.mark.parametrize('n,h,w', [(32, 32, 32), (2, 60, 80)])
+def test_pyramid_is_symmetric_and_pooled(n, h, w):
+    """corr(f1,f2)[n,i,j] = corr(f2,f1)[n,j,i]; level l+1 = 2x2 average pool of level l."""
+    f1, f2 = rnd((n, 256, h, w), 1), rnd((n, 256, h, w), 2)
+    a = ops.corr_build(f1, f2, 4)
+    b = ops.corr_build(f2, f1, 1)
+    hw = h * w
+    ta = a[0].reshape(n, hw, hw)
+    tb = b[0].reshape(n, hw, hw).transpose(1, 2)
+    assert float((ta - tb).abs().max()) <= 2e-5 * float(ta.abs().max())
+    for l in range(3):
+        want = F.avg_pool2d(a[l], 2, 2)
+        assert float((a[l + 1] - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max()))
+    # tiled level 0 holds the same numbers
+    t = ops.corr_build(f1, f2, 4, level0_tiled=True)
+    assert torch.equal(ops.untile_level0(t[0]), a[0])
+
+
+@pytest.mark.parametrize('n,h,w', [(32, 32, 32), (8, 60, 80)])
+def test_lookup_is_linear_in_the_volume(n, h, w):
+    """L(a P + b Q; flow) = a L(P; flow) + b L(Q; flow) for a fixed flow field."""
+    q = n * h * w
+    flow = rnd((n, 2, h, w), 3, 4.0)
+    P = [rnd((q, 1, h >> l, w >> l), 10 + l) for l in range(4)]
+    Q = [rnd((q, 1, h >> l, w >> l), 20 + l) for l in range(4)]
+    mix = [2.0 * p - 0.5 * r for p, r in zip(P, Q)]
+    lp, lq, lm = ops.corr_lookup(P, flow, 4), ops.corr_lookup(Q, flow, 4), ops.corr_lookup(mix, flow, 4)
+    assert lm.shape == (n, 324, h, w)
+    assert float((lm - (2.0 * lp - 0.5 * lq)).abs().max()) <= 2e-5
+    # integer flow: the centre tap of level 0 is the map value at the displaced position
+    fi = torch.zeros((n, 2, h, w), device=DEV)
+    fi[:, 0] = 1.0
+    centre = ops.corr_lookup(P, fi, 4)[:, 40]                    # k = 9*4 + 4: x_off = y_off = 0
+    ys, xs = torch.meshgrid(torch.arange(h, device=DEV), torch.arange(w, device=DEV), indexing='ij')
+    maps = P[0].reshape(n, h, w, h, w)
+    tgt = torch.where(xs + 1 < w, maps[:, ys, xs, ys, (xs + 1).clamp(max=w - 1)], torch.zeros((), device=DEV))
+    assert float((centre - tgt).abs().max()) <= 1e-5 * max(1.0, float(tgt.abs().max()))
+
+
+def test_convolution_is_linear_and_shift_equivariant_at_full_size():
+    """conv(a x + b y) = a conv(x) + b conv(y) - (a+b-1) bias;  shifting the input by whole
+    pixels shifts the output (interior), on the encoder's 128x128 / batch-64 layer shape."""
+    n, c, H, W = 64, 64, 128, 128
+    wt, b = rnd((64, c, 3, 3), 5, 0.05), rnd((64,), 6, 0.1)
+    pc = ops.PackedConv.from_weight(wt, b, padding=1)
+    x, y = rnd((n, c, H, W), 7), rnd((n, c, H, W), 8)
+    cx, cy = ops.conv2d(pc, x), ops.conv2d(pc, y)
+    cm = ops.conv2d(pc, 1.5 * x - 0.25 * y)
+    want = 1.5 * cx - 0.25 * cy - 0.25 * b.view(1, -1, 1, 1)
+    assert float((cm - want).abs().max()) <= 3e-5 * max(1.0, float(want.abs().max()))
+    xs = torch.roll(x, shifts=(3, 5), dims=(2, 3))
+    cs = ops.conv2d(pc, xs)
+    assert float((cs[:, :, 8:-8, 8:-8] - torch.roll(cx, (3, 5), (2, 3))[:, :, 8:-8, 8:-8]).abs().max()) <= 2e-5
+
+
+def test_refiner_is_batch_permutation_equivariant_at_full_size(golden_dir):
+    """configs[2]: 32 pairs, 8 iterations.  Pairs are independent end to end (same label for all,
+    see the label[0] quirk), so permuting the batch permutes every output."""
+    shapes = json.load(open(os.path.join(golden_dir, 'state_dict_keys.json')))['shapes']
+    m = scflow_amd.build_refiner(scflow_amd.scflow_model_cfg(iters=8))
+    m.load_state_dict(scflow_amd.fill_state_dict(shapes, seed=0), strict=True)
+    m = m.to(DEV)
+    inp = scflow_amd.make_inputs(32, 256, 256, seed=11)
+    inp['label'][:] = 3
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    perm = torch.randperm(32, generator=torch.Generator().manual_seed(0)).to(DEV)
+
+    def run(dd):
+        o = m.get_pose(dd['render_images'], dd['real_images'], dd['ref_rotation'], dd['ref_translation'],
+                       dd['depth'], dd['internel_k'], dd['label'])
+        return o[0][-1], o[2][-1], o[3][-1]
+
+    f0, r0, t0 = run(d)
+    f1, r1, t1 = run({k: v[perm].contiguous() for k, v in d.items()})
+    assert torch.isfinite(f0).all() and torch.isfinite(r0).all()
+    # the tile decomposition does not depend on the sample index -> identical arithmetic
+    assert torch.equal(f0[perm], f1) and torch.equal(r0[perm], r1) and torch.equal(t0[perm], t1)
+    # rotations stay orthonormal after 8 compositions
+    eye = torch.eye(3, device=DEV).expand(32, 3, 3)
+    assert float((torch.bmm(r0, r0.transpose(1, 2)) - eye).abs().max()) <= 1e-4
