@@ -175,6 +175,59 @@ __device__ __forceinline__ void scf_epi_general_group(const ConvK& p, const Conv
   }
 }
 
+// One whole 32x32 fragment (16 rows of one pixel) of a non-affine kind: every load (bias and the
+// auxiliary operands: residual / GRU h, z) is issued before the first store, so the in-order
+// vmcnt counter makes the wave wait for outstanding stores once per fragment instead of once
+// per 4-row group.  cb = first channel of this lane's rows (co0 + 4*half).
+template <int KIND>
+__device__ __forceinline__ void scf_epi_general_frag(const ConvK& p, const ConvEpi& e,
+                                                     const scf_f32x16& acc, int cb, int pix,
+                                                     bool use_div) {
+  const int hc = p.Cout >> 1;
+  float bv[16], a0[16], a1[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = cb + 8 * (r >> 2) + (r & 3);
+    const bool ok = co < p.Cout;
+    const int cc = ok ? co : 0;
+    const int off = cc * e.HWo + pix;
+    bv[r] = p.bias ? p.bias[cc] : 0.f;
+    a0[r] = 0.f;
+    a1[r] = 0.f;
+    if (KIND == SCF_EPI_GENERAL) {
+      if (e.res) a0[r] = e.res[off];
+    } else if (KIND == SCF_EPI_GRU_ZR) {
+      if (ok && co >= hc) a0[r] = e.gru_h[off - hc * e.HWo];
+    } else {
+      a0[r] = e.gru_h[off];
+      a1[r] = e.gru_z[off];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = cb + 8 * (r >> 2) + (r & 3);
+    if (co < p.Cout) {
+      const int off = co * e.HWo + pix;
+      float v = acc[r];
+      if (use_div) v = v / p.out_div;
+      v += bv[r];
+      if (KIND == SCF_EPI_GENERAL) {
+        if (p.scale) v = v * p.scale[co] + p.shift[co];
+        v += a0[r];
+        const int a = (p.act_split > 0 && co >= p.act_split) ? p.act2 : p.act;
+        e.out[off] = scf_apply_act(v, a);
+      } else if (KIND == SCF_EPI_GRU_ZR) {
+        const float sg = 1.f / (1.f + expf(-v));
+        if (co < hc) e.out[off] = sg;
+        else e.gru_aux[off - hc * e.HWo] = sg * a0[r];
+      } else {
+        const float qv = tanhf(v);
+        e.out[off] = (1.f - a1[r]) * a0[r] + a1[r] * qv;
+      }
+    }
+  }
+}
+
 // one group of 4 rows, kind chosen at run time (K-split kernel)
 __device__ __forceinline__ void scf_conv_epilogue_group(const ConvK& p, const ConvEpi& e,
                                                         const float (&acc)[4], int cb, int pix,
@@ -194,6 +247,36 @@ __device__ __forceinline__ void scf_conv_epilogue_tile(const ConvK& p, const Con
                                                        const ACC& acc, int m0, int half,
                                                        const int (&pix)[WN], bool use_div) {
   const int kind = scf_conv_epi_kind(p);
+  // Fast path (most launches: bias, optional ReLU, whole channel fragments): every load of the
+  // tile is issued BEFORE the first store.  Loads and stores share the in-order vmcnt counter on
+  // gfx9, so a bias load issued after a store cannot be consumed until that store has been
+  // acknowledged by memory (~2k cycles) -- per 4-row group in the generic path below.
+  if (kind == SCF_EPI_AFFINE && !e.res && !p.scale && p.act_split <= 0 && !use_div &&
+      m0 + WM * 32 <= p.Cout && ((uintptr_t)p.bias & 15) == 0) {
+    scf_f32x4 bv[WM][4];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        bv[i][g] = p.bias ? *reinterpret_cast<const scf_f32x4*>(p.bias + m0 + i * 32 + 8 * g + 4 * half)
+                          : scf_f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool relu = p.act == SCF_ACT_RELU;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      if (pix[j] < 0) continue;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        float* o = e.out + (m0 + i * 32 + 4 * half) * e.HWo + pix[j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + bv[i][r >> 2][r & 3];
+          if (relu) v = v > 0.f ? v : 0.f;
+          o[(8 * (r >> 2) + (r & 3)) * e.HWo] = v;
+        }
+      }
+    }
+    return;
+  }
 #define SCF_EPI_LOOP(CALL)                                                        \
   _Pragma("unroll") for (int j = 0; j < WN; ++j) {                                \
     if (pix[j] >= 0) {                                                            \
@@ -207,10 +290,18 @@ __device__ __forceinline__ void scf_conv_epilogue_tile(const ConvK& p, const Con
     }                                                                             \
   }
   if (kind == SCF_EPI_AFFINE) { SCF_EPI_LOOP(scf_epi_affine_group) }
-  else if (kind == SCF_EPI_GENERAL) { SCF_EPI_LOOP(scf_epi_general_group<SCF_EPI_GENERAL>) }
-  else if (kind == SCF_EPI_GRU_ZR) { SCF_EPI_LOOP(scf_epi_general_group<SCF_EPI_GRU_ZR>) }
-  else { SCF_EPI_LOOP(scf_epi_general_group<SCF_EPI_GRU_Q>) }
 #undef SCF_EPI_LOOP
+#define SCF_EPI_FRAGS(KIND_)                                                      \
+  _Pragma("unroll") for (int j = 0; j < WN; ++j) {                                \
+    if (pix[j] >= 0) {                                                            \
+      _Pragma("unroll") for (int i = 0; i < WM; ++i)                              \
+        scf_epi_general_frag<KIND_>(p, e, acc[i][j], m0 + i * 32 + 4 * half, pix[j], use_div); \
+    }                                                                             \
+  }
+  else if (kind == SCF_EPI_GENERAL) { SCF_EPI_FRAGS(SCF_EPI_GENERAL) }
+  else if (kind == SCF_EPI_GRU_ZR) { SCF_EPI_FRAGS(SCF_EPI_GRU_ZR) }
+  else { SCF_EPI_FRAGS(SCF_EPI_GRU_Q) }
+#undef SCF_EPI_FRAGS
 }
 
 // conv_f16x3.hip: tile selection + launch of the split-fp16 kernel (SCF_EUNSUPPORTED -> caller
