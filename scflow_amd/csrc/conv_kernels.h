@@ -277,6 +277,45 @@ __device__ __forceinline__ void scf_conv_epilogue_tile(const ConvK& p, const Con
     }
     return;
   }
+  // Same idea for BN scale/shift and residual adds (context-encoder blocks), one fragment at a
+  // time: all of a fragment's loads, then its 16 stores (one store-acknowledge wait per fragment
+  // instead of one per 4-row group).  The scheduling barriers keep the other fragments' loads
+  // from being hoisted on top (registers).
+  if (kind == SCF_EPI_AFFINE && p.act_split <= 0 && !use_div && m0 + WM * 32 <= p.Cout &&
+      (((uintptr_t)p.bias | (uintptr_t)p.scale | (uintptr_t)p.shift) & 15) == 0) {
+    const scf_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+    const bool relu = p.act == SCF_ACT_RELU;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      if (pix[j] < 0) continue;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int c0 = m0 + i * 32 + 4 * half;
+        const int o0 = c0 * e.HWo + pix[j];
+        scf_f32x4 bv[4], sc[4], sh[4];
+        float rs[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bv[g] = p.bias ? *reinterpret_cast<const scf_f32x4*>(p.bias + c0 + 8 * g) : zero4;
+          sc[g] = p.scale ? *reinterpret_cast<const scf_f32x4*>(p.scale + c0 + 8 * g) : one4;
+          sh[g] = p.scale ? *reinterpret_cast<const scf_f32x4*>(p.shift + c0 + 8 * g) : zero4;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rs[r] = e.res ? e.res[o0 + (8 * (r >> 2) + (r & 3)) * e.HWo] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + bv[r >> 2][r & 3];
+          if (p.scale) v = v * sc[r >> 2][r & 3] + sh[r >> 2][r & 3];
+          v += rs[r];
+          if (relu) v = v > 0.f ? v : 0.f;
+          e.out[o0 + (8 * (r >> 2) + (r & 3)) * e.HWo] = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    return;
+  }
 #define SCF_EPI_LOOP(CALL)                                                        \
   _Pragma("unroll") for (int j = 0; j < WN; ++j) {                                \
     if (pix[j] >= 0) {                                                            \
