@@ -178,6 +178,16 @@ int scf_reproject_flow(const float* depth, const float* K, const float* R0, cons
                        const float* R, const float* t, float* flow, int N, int H, int W,
                        float invalid_num, scf_stream_t stream);
 
+/* BaseDataset.eval_pose_error (datasets/base_dataset.py:378-424; project_3d_point,
+ * datasets/pose.py:18-78) for the samples sample_idx[0..nsel) that share one vertex set
+ * verts (nv,3): err3d[s] = ADD (symmetric = 0) or ADD-S (closest predicted point, symmetric
+ * != 0), err2d[s] = mean reprojection distance with x / (z + 1e-8).  float64 throughout, like
+ * the reference's numpy arrays; gt_r/pred_r/K (N,3,3), gt_t/pred_t (N,3), outputs (N). */
+int scf_pose_error(const double* verts, int nv, const double* gt_r, const double* gt_t,
+                   const double* pred_r, const double* pred_t, const double* K,
+                   const int* sample_idx, int nsel, int symmetric, double* err3d, double* err2d,
+                   scf_stream_t stream);
+
 /* filter_flow_by_mask (models/utils/flow.py:6-26), in place on flow (N,2,H,W): a vector is set
  * to invalid_num when both components are >= invalid_num or when mask (N,H,W), sampled
  * bilinearly (zeros padding) at the vector's end point, is < 0.9.  The end point is normalised

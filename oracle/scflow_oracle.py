@@ -28,6 +28,7 @@ __all__ = [
     'flow_from_pose_and_points', 'scflow_decoder', 'extract_feat',
     'get_pose', 'end_point_error', 'convex_upsample', 'raft_decoder', 'raft_decoder_mask',
     'cal_epe', 'flow_from_delta_pose_and_depth', 'coords_grid', 'filter_flow_by_mask',
+    'eval_pose_error', 'eval_rot_error', 'eval_tran_error',
 ]
 
 
@@ -486,3 +487,55 @@ def cal_epe(flow_tgt: Tensor, flow_pred: Tensor, mask, max_flow: float = 400,
         for t in threshs:
             acc[f'{t}px'] = (err[valid] < t).sum() / total
     return acc
+
+
+# --------------------------------------------------------------------------
+# pose-error evaluation: numpy, like the reference
+# --------------------------------------------------------------------------
+def eval_pose_error(verts_list, gt_t, gt_r, pred_t, pred_r, labels, k, symmetry_types,
+                    mesh_diameters):
+    """datasets/base_dataset.py:378-424 ``BaseDataset.eval_pose_error`` + ``project_3d_point``
+    (datasets/pose.py:18-78): per sample, with the model vertices of its class,
+      3d error (ADD)   = mean_i || (R_gt v_i + t_gt) - (R_pr v_i + t_pr) ||
+      3d error (ADD-S) = mean_i || gt_i - pred_{argmin_j ||gt_i - pred_j||} ||   (symmetric classes,
+                         ``symmetry_types['cls_<label+1>']``)
+      2d error         = mean_i || proj(gt_i) - proj(pred_i) ||, proj = K p, x / (z + 1e-8)
+      normalised 3d    = 3d error / mesh diameter of the class.
+    Returns (error_3d_normalized, error_2d, error_3d), float64 arrays of length N."""
+    import numpy as np
+    n = len(gt_t)
+    e3n, e2, e3 = np.zeros(n), np.zeros(n), np.zeros(n)
+    for c in np.unique(labels):
+        idx = labels == c
+        v = np.asarray(verts_list[c])
+
+        def project(r, t):
+            cam = np.matmul(r[idx], v.transpose()) + t[idx][..., None]          # (M,3,n)
+            px = np.matmul(k[idx], cam).transpose((0, 2, 1))                   # (M,n,3)
+            xy = px[..., :2] / (px[..., 2:3] + 1e-8)
+            return xy, cam.transpose((0, 2, 1))
+
+        g2, g3 = project(gt_r, gt_t)
+        p2, p3 = project(pred_r, pred_t)
+        if symmetry_types.get(f'cls_{c + 1}', False):
+            p3 = np.stack([pp[np.argmin(np.linalg.norm(gg[:, None] - pp[None], axis=-1), axis=-1)]
+                           for gg, pp in zip(g3, p3)], 0)
+        err = np.linalg.norm(g3 - p3, axis=-1).mean(-1)
+        e3n[idx] = err / mesh_diameters[c]
+        e2[idx] = np.linalg.norm(g2 - p2, axis=-1).mean(-1)
+        e3[idx] = err
+    return e3n, e2, e3
+
+
+def eval_rot_error(gt_r, pred_r):
+    """datasets/pose.py:106-112: geodesic angle (degrees) of pred_r gt_r^-1."""
+    import numpy as np
+    c = 0.5 * (np.trace(np.matmul(pred_r, np.linalg.inv(gt_r)), axis1=1, axis2=2) - 1.0)
+    return 180.0 * np.arccos(np.clip(c, -1.0, 1.0)) / np.pi
+
+
+def eval_tran_error(gt_t, pred_t):
+    """datasets/pose.py:114-119: (|dt|, |dz|, |dxy|)."""
+    import numpy as np
+    return (np.linalg.norm(gt_t - pred_t, axis=-1), np.abs(gt_t[:, -1] - pred_t[:, -1]),
+            np.linalg.norm(gt_t[:, :2] - pred_t[:, :2], axis=-1))

@@ -15,7 +15,8 @@ from .modules import (ConvGRU, CorrelationPyramid, CorrLookup, MotionEncoder,  #
                       MultiClassPoseHead, RAFTDecoder, RAFTDecoderMask, RAFTEncoder,
                       SCFlowDecoder, XHead)
 from .refiner import RAFTRefinerFlow, RAFTRefinerFlowMask, SCFlowRefiner  # noqa: F401
-from .metrics import (cal_epe, filter_flow_by_mask,  # noqa: F401
+from .metrics import (cal_epe, eval_pose_error, eval_rot_error,  # noqa: F401
+                      eval_tran_error, filter_flow_by_mask,
                       get_flow_from_delta_pose_and_depth)
 from .config import scflow_model_cfg  # noqa: F401
 from .weights import fill_state_dict  # noqa: F401

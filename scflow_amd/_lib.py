@@ -61,6 +61,7 @@ SIGNATURES = {
                                     C.c_int, C.c_int, _fp]),
     'scf_corr_lookup_ex': (C.c_int, [C.POINTER(_fp), _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, _fp]),
+    'scf_pose_error': (C.c_int, [_fp, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     'scf_filter_flow_by_mask': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _fp]),
     'scf_conv2d': (C.c_int, [C.POINTER(ConvDesc), _fp]),
     'scf_conv2d_query': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int32)]),

@@ -252,3 +252,102 @@ extern "C" int scf_filter_flow_by_mask(float* flow, const float* mask, int N, in
                      N, H, W, invalid_num, align_corners);
   return scf_launch_status();
 }
+
+
+// ---------------------------------------------------------------------------------
+// Pose-error evaluation (BaseDataset.eval_pose_error, datasets/base_dataset.py:378-424 +
+// project_3d_point, datasets/pose.py:18-78), float64 like the reference's numpy arrays.
+// One block per sample; all samples of a launch share one vertex set (one class):
+//   gt_i = R_gt v_i + t_gt, pr_i = R_pr v_i + t_pr
+//   err3d = mean_i |gt_i - pr_i|                          (ADD)
+//         = mean_i |gt_i - pr_{argmin_j |gt_i - pr_j|}|   (ADD-S, symmetric != 0)
+//   err2d = mean_i |proj(gt_i) - proj(pr_i)|,  proj = K p, (x, y) / (z + 1e-8)
+// Sums are combined in a fixed order (per-thread strided partials, then an LDS tree).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pose_error_kernel(const double* __restrict__ verts, int nv,
+                                                         const double* __restrict__ gt_r,
+                                                         const double* __restrict__ gt_t,
+                                                         const double* __restrict__ pr_r,
+                                                         const double* __restrict__ pr_t,
+                                                         const double* __restrict__ kmat,
+                                                         const int* __restrict__ sample_idx,
+                                                         int symmetric, double* __restrict__ err3d,
+                                                         double* __restrict__ err2d) {
+  __shared__ double red3[256], red2[256];
+  __shared__ double tile[256 * 3];
+  const int s = sample_idx[blockIdx.x];
+  const int tid = threadIdx.x;
+  double Rg[9], Rp[9], K[9], tg[3], tp[3];
+  for (int i = 0; i < 9; ++i) { Rg[i] = gt_r[s * 9 + i]; Rp[i] = pr_r[s * 9 + i]; K[i] = kmat[s * 9 + i]; }
+  for (int i = 0; i < 3; ++i) { tg[i] = gt_t[s * 3 + i]; tp[i] = pr_t[s * 3 + i]; }
+  auto xform = [](const double (&R)[9], const double (&t)[3], const double* v, double (&o)[3]) {
+    for (int a = 0; a < 3; ++a) o[a] = (R[3 * a] * v[0] + R[3 * a + 1] * v[1]) + R[3 * a + 2] * v[2] + t[a];
+  };
+  double acc3 = 0.0, acc2 = 0.0;
+  const int rounds = (nv + 255) / 256;
+  for (int rd = 0; rd < rounds; ++rd) {
+    const int i = rd * 256 + tid;
+    const bool live = i < nv;
+    double g[3] = {0, 0, 0}, q[3] = {0, 0, 0};
+    if (live) {
+      xform(Rg, tg, verts + 3 * i, g);
+      xform(Rp, tp, verts + 3 * i, q);
+      double pg[3], pp[3];
+      for (int a = 0; a < 3; ++a) {
+        pg[a] = (K[3 * a] * g[0] + K[3 * a + 1] * g[1]) + K[3 * a + 2] * g[2];
+        pp[a] = (K[3 * a] * q[0] + K[3 * a + 1] * q[1]) + K[3 * a + 2] * q[2];
+      }
+      const double dx = pg[0] / (pg[2] + 1e-8) - pp[0] / (pp[2] + 1e-8);
+      const double dy = pg[1] / (pg[2] + 1e-8) - pp[1] / (pp[2] + 1e-8);
+      acc2 += sqrt(dx * dx + dy * dy);
+    }
+    if (!symmetric) {
+      if (live) {
+        const double a = g[0] - q[0], b = g[1] - q[1], c = g[2] - q[2];
+        acc3 += sqrt(a * a + b * b + c * c);
+      }
+    } else {                                   // nearest predicted point, tiles of 256 through LDS
+      double best = 1e300;
+      for (int j0 = 0; j0 < nv; j0 += 256) {
+        __syncthreads();
+        if (j0 + tid < nv) {
+          double o[3];
+          xform(Rp, tp, verts + 3 * (j0 + tid), o);
+          tile[tid * 3] = o[0]; tile[tid * 3 + 1] = o[1]; tile[tid * 3 + 2] = o[2];
+        }
+        __syncthreads();
+        const int m = min(256, nv - j0);
+        if (live)
+          for (int j = 0; j < m; ++j) {
+            const double a = g[0] - tile[3 * j], b = g[1] - tile[3 * j + 1], c = g[2] - tile[3 * j + 2];
+            const double d = a * a + b * b + c * c;
+            best = d < best ? d : best;
+          }
+      }
+      if (live) acc3 += sqrt(best);
+    }
+  }
+  red3[tid] = acc3;
+  red2[tid] = acc2;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) { red3[tid] += red3[tid + w]; red2[tid] += red2[tid + w]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    err3d[s] = red3[0] / (double)nv;
+    err2d[s] = red2[0] / (double)nv;
+  }
+}
+
+extern "C" int scf_pose_error(const double* verts, int nv, const double* gt_r, const double* gt_t,
+                              const double* pred_r, const double* pred_t, const double* K,
+                              const int* sample_idx, int nsel, int symmetric, double* err3d,
+                              double* err2d, scf_stream_t stream) {
+  if (!verts || !gt_r || !gt_t || !pred_r || !pred_t || !K || !sample_idx || !err3d || !err2d)
+    return SCF_EINVAL;
+  if (nv <= 0 || nsel <= 0) return SCF_EINVAL;
+  hipLaunchKernelGGL(pose_error_kernel, dim3(nsel), dim3(256), 0, scf_stream(stream), verts, nv, gt_r,
+                     gt_t, pred_r, pred_t, K, sample_idx, symmetric, err3d, err2d);
+  return scf_launch_status();
+}

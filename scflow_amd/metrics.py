@@ -15,7 +15,8 @@ from __future__ import annotations
 
 import torch
 
-__all__ = ['cal_epe', 'get_flow_from_delta_pose_and_depth', 'filter_flow_by_mask']
+__all__ = ['cal_epe', 'get_flow_from_delta_pose_and_depth', 'filter_flow_by_mask',
+           'eval_pose_error', 'eval_rot_error', 'eval_tran_error']
 
 
 def get_flow_from_delta_pose_and_depth(rotation_src, translation_src, rotation_dst, translation_dst,
@@ -62,3 +63,52 @@ def cal_epe(flow_tgt: torch.Tensor, flow_pred: torch.Tensor, mask, max_flow: flo
     else:
         raise ValueError(reduction)
     return acc
+
+
+# ---------------------------------------------------------------- pose errors (8(f) row 4)
+def eval_pose_error(verts_list, gt_t, gt_r, pred_t, pred_r, labels, k, symmetry_types,
+                    mesh_diameters, device='cuda:0'):
+    """``BaseDataset.eval_pose_error`` (datasets/base_dataset.py:378-424), same arguments
+    (numpy arrays / lists) and returns: (error_3d_normalized, error_2d, error_3d) float64
+    arrays.  ADD, ADD-S (``symmetry_types['cls_<label+1>']``) and the 2-D reprojection error
+    run in one HIP launch per class (``scf_pose_error``, float64)."""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    lib = _lib.load()
+    n = len(gt_t)
+    to = lambda a, shape: torch.as_tensor(np.ascontiguousarray(np.asarray(a, dtype=np.float64)
+                                                               ).reshape(shape), device=device)
+    gr, pr, kk = to(gt_r, (n, 9)), to(pred_r, (n, 9)), to(k, (n, 9))
+    gt, pt = to(gt_t, (n, 3)), to(pred_t, (n, 3))
+    e3 = torch.zeros(n, dtype=torch.float64, device=device)
+    e2 = torch.zeros(n, dtype=torch.float64, device=device)
+    labels = np.asarray(labels)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    keep = []
+    for c in np.unique(labels):
+        sel = np.nonzero(labels == c)[0].astype(np.int32)
+        v = to(verts_list[c], (-1, 3))
+        idx = torch.as_tensor(sel, device=device)
+        keep += [v, idx]
+        _lib.check(lib.scf_pose_error(v.data_ptr(), v.shape[0], gr.data_ptr(), gt.data_ptr(),
+                                      pr.data_ptr(), pt.data_ptr(), kk.data_ptr(), idx.data_ptr(),
+                                      len(sel), int(bool(symmetry_types.get(f'cls_{c + 1}', False))),
+                                      e3.data_ptr(), e2.data_ptr(), stream), 'scf_pose_error')
+    e3 = e3.cpu().numpy()
+    diam = np.asarray([mesh_diameters[c] for c in labels], dtype=np.float64)
+    return e3 / diam, e2.cpu().numpy(), e3
+
+
+def eval_rot_error(gt_r, pred_r):
+    """datasets/pose.py:106-112: geodesic angle in degrees (torch, any device)."""
+    gt_r, pred_r = torch.as_tensor(gt_r), torch.as_tensor(pred_r)
+    c = 0.5 * (torch.diagonal(pred_r @ torch.linalg.inv(gt_r), dim1=1, dim2=2).sum(-1) - 1.0)
+    return torch.rad2deg(torch.arccos(c.clamp(-1.0, 1.0)))
+
+
+def eval_tran_error(gt_t, pred_t):
+    """datasets/pose.py:114-119 -> (|dt|, |dz|, |dxy|)."""
+    gt_t, pred_t = torch.as_tensor(gt_t), torch.as_tensor(pred_t)
+    return ((gt_t - pred_t).norm(dim=-1), (gt_t[:, -1] - pred_t[:, -1]).abs(),
+            (gt_t[:, :2] - pred_t[:, :2]).norm(dim=-1))

@@ -271,8 +271,41 @@ def main_gtflow():
          mask=mask, **out)
 
 
+def main_poseerr():
+    """fixtures of SURVEY 8(f) row 4: ADD / ADD-S / 2-D pose errors (numpy, float64)."""
+    from datasets.base_dataset import BaseDataset
+    from datasets.pose import eval_rot_error, eval_tran_error
+    rs = np.random.RandomState(12)
+    verts = [rs.randn(150, 3) * 40., rs.randn(210, 3) * 25., rs.randn(64, 3) * 60.]
+    n = 7
+    labels = np.array([0, 2, 1, 1, 0, 2, 1])
+
+    def rot(a):
+        a = np.asarray(a, dtype=np.float64)
+        th = np.linalg.norm(a)
+        kx = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]]) / th
+        return np.eye(3) + np.sin(th) * kx + (1 - np.cos(th)) * kx @ kx
+
+    gt_r = np.stack([rot(rs.randn(3)) for _ in range(n)])
+    pred_r = np.stack([rot(rs.randn(3) * 0.05) @ r for r in gt_r])
+    gt_t = np.stack([np.array([rs.randn() * 50, rs.randn() * 50, 800 + rs.rand() * 300]) for _ in range(n)])
+    pred_t = gt_t + rs.randn(n, 3) * np.array([3., 3., 12.])
+    k = np.tile(np.array([[600., 0, 128], [0, 600., 128], [0, 0, 1]]), (n, 1, 1))
+    sym = {'cls_2': True}                       # label 1 is symmetric -> ADD-S
+    diam = [180., 110., 260.]
+    e3n, e2, e3 = BaseDataset.eval_pose_error(None, verts, gt_t, gt_r, pred_t, pred_r, labels, k, sym, diam)
+    te, tz, txy = eval_tran_error(gt_t, pred_t)
+    np.savez(os.path.join(HERE, 'pose_error.npz'), pinned_under=np.array(STUBS),
+             verts0=verts[0], verts1=verts[1], verts2=verts[2], labels=labels, gt_r=gt_r, pred_r=pred_r,
+             gt_t=gt_t, pred_t=pred_t, k=k, diam=np.array(diam), e3n=e3n, e2=e2, e3=e3,
+             rot_err=eval_rot_error(gt_r, pred_r), t_err=te, tz_err=tz, txy_err=txy)
+    print('pose_error.npz')
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'next':
+    if len(sys.argv) > 1 and sys.argv[1] == 'poseerr':
+        main_poseerr()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'next':
         main_next()
     elif len(sys.argv) > 1 and sys.argv[1] == 'gtflow':
         main_gtflow()

@@ -185,3 +185,50 @@ def test_gt_flow_generation_hip(golden_dir):
     want = oracle.filter_flow_by_mask(fl, mk, 400.)
     got = metrics.filter_flow_by_mask(fl.clone().to('cuda:0'), mk.to('cuda:0'), 400).cpu()
     assert (got != want).any(dim=1).float().mean().item() < 1e-3
+
+
+# ------------------------------------------------ pose-error evaluation (8(f) row 4)
+def _pose_error_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'pose_error.npz'))
+    return g, [g['verts0'], g['verts1'], g['verts2']]
+
+
+def test_oracle_pose_error_matches_reference_fixture(golden_dir):
+    g, verts = _pose_error_fixture(golden_dir)
+    got = oracle.eval_pose_error(verts, g['gt_t'], g['gt_r'], g['pred_t'], g['pred_r'], g['labels'],
+                                 g['k'], {'cls_2': True}, list(g['diam']))
+    for a, b in zip(got, (g['e3n'], g['e2'], g['e3'])):
+        assert np.array_equal(a, b)
+    assert np.array_equal(oracle.eval_rot_error(g['gt_r'], g['pred_r']), g['rot_err'])
+    for a, b in zip(oracle.eval_tran_error(g['gt_t'], g['pred_t']), (g['t_err'], g['tz_err'], g['txy_err'])):
+        assert np.array_equal(a, b)
+    # rot / tran errors of the product are torch one-liners: check them here too (CPU tensors)
+    from scflow_amd import metrics
+    assert np.allclose(metrics.eval_rot_error(g['gt_r'], g['pred_r']).numpy(), g['rot_err'], rtol=0, atol=1e-9)
+    for a, b in zip(metrics.eval_tran_error(g['gt_t'], g['pred_t']), (g['t_err'], g['tz_err'], g['txy_err'])):
+        assert np.allclose(a.numpy(), b, rtol=1e-13, atol=0)
+
+
+@pytest.mark.gpu
+def test_pose_error_hip(golden_dir):
+    from scflow_amd import metrics
+    g, verts = _pose_error_fixture(golden_dir)
+    got = metrics.eval_pose_error(verts, g['gt_t'], g['gt_r'], g['pred_t'], g['pred_r'], g['labels'],
+                                  g['k'], {'cls_2': True}, list(g['diam']))
+    for a, b, name in zip(got, (g['e3n'], g['e2'], g['e3']), ('3d normalised', '2d', '3d')):
+        assert np.allclose(a, b, rtol=1e-12, atol=1e-12), name            # float64, fixed-order sums
+    # larger models, every class symmetric, against the oracle (ADD-S is O(n^2) per sample)
+    rs = np.random.RandomState(3)
+    big = [rs.randn(1500, 3) * 50., rs.randn(3001, 3) * 30.]
+    n = 5
+    labels = np.array([1, 0, 1, 0, 0])
+    gt_r = np.stack([np.linalg.qr(rs.randn(3, 3))[0] for _ in range(n)])
+    pred_r = np.stack([np.linalg.qr(r + 0.02 * rs.randn(3, 3))[0] for r in gt_r])
+    gt_t = rs.randn(n, 3) * 20 + np.array([0, 0, 900.])
+    pred_t = gt_t + rs.randn(n, 3) * 4
+    k = np.tile(np.array([[600., 0, 128], [0, 600., 128], [0, 0, 1]]), (n, 1, 1))
+    sym = {'cls_1': True, 'cls_2': True}
+    want = oracle.eval_pose_error(big, gt_t, gt_r, pred_t, pred_r, labels, k, sym, [100., 70.])
+    got = metrics.eval_pose_error(big, gt_t, gt_r, pred_t, pred_r, labels, k, sym, [100., 70.])
+    for a, b in zip(got, want):
+        assert np.allclose(a, b, rtol=1e-11, atol=1e-11)
