@@ -55,6 +55,20 @@ __device__ __forceinline__ const void* sgpr_ptr(const void* p) {
   return (const void*)(((unsigned long long)hi << 32) | lo);
 }
 
+// Same, with the lane mask derived from the offset itself (0xFFFFFFFF = this lane stays off): one
+// v_cmp instead of a lane mask kept in (spilled) SGPRs -- VALU issue slots are scarce while the
+// co-resident wave streams MFMAs.
+__device__ __forceinline__ void dma_b128_v(const void* sbase, unsigned voff, unsigned lds_base) {
+  asm volatile("v_cmp_ne_u32_e32 vcc, -1, %1\n\ts_mov_b64 exec, vcc\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %0\n\ts_mov_b64 exec, -1"
+               : : "s"(sbase), "v"(voff), "s"(lds_base) : "memory", "vcc");
+}
+__device__ __forceinline__ void dma_b32_v(const void* sbase, unsigned voff, unsigned lds_base) {
+  asm volatile("v_cmp_ne_u32_e32 vcc, -1, %1\n\ts_mov_b64 exec, vcc\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dword %1, %0\n\ts_mov_b64 exec, -1"
+               : : "s"(sbase), "v"(voff), "s"(lds_base) : "memory", "vcc");
+}
+
 // floor(e / d) for 0 <= e < 2^22, 0 < d < 2^12 without the integer-division expansion
 __device__ __forceinline__ int fast_div(int e, int d, float rd) {
   int q = (int)((float)e * rd);
@@ -110,7 +124,6 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   const int HWin = p.H * p.W;
   const float rPHW = 1.0f / (float)PHW, rPW = 1.0f / (float)PW;
   unsigned toff[PU];
-  unsigned long long tmask[PU];
 #pragma unroll
   for (int u = 0; u < PU; ++u) {
     const int e = tid + u * 256;
@@ -127,19 +140,16 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
       o = (unsigned)(c * HWin + iy * p.W + ix) * 4u;
     }
     toff[u] = ok ? o : 0xFFFFFFFFu;
-    tmask[u] = __ballot(ok);
   }
   // weights: float4 e = tid + 256u of the chunk's [NIT*2 rows][BM] slab out of [rows][Mld4]
   constexpr int WU = 7;
   unsigned woff[WU];
-  unsigned long long wmask[WU];
 #pragma unroll
   for (int u = 0; u < WU; ++u) {
     const int e = tid + u * 256;
     const int row = e / BM, m = e - row * BM;
     const bool ok = e < WF4 && m0 + m < p.Mld4;
-    woff[u] = (unsigned)((row * p.Mld4 + m) * 16);
-    wmask[u] = __ballot(ok);
+    woff[u] = ok ? (unsigned)((row * p.Mld4 + m) * 16) : 0xFFFFFFFFu;
   }
 
   const int fr = l32 >> p.fc_log2, fc = l32 & (FC - 1);
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
     if (nvalid >= KC) {                // chunk-invariant masks apply
 #pragma unroll
       for (int u = 0; u < PU; ++u)
-        if (u * 256 < PE) dma_b32(base, toff[u], lds_addr(pb + u * 256 + wave * 64), tmask[u]);
+        if (u * 256 < PE) dma_b32_v(base, toff[u], lds_addr(pb + u * 256 + wave * 64));
     } else {                           // last chunk of a segment: channels past the end are zero
       const unsigned limit = (unsigned)nvalid * (unsigned)HWin * 4u;
 #pragma unroll
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
     const float* wsrc = (const float*)sgpr_ptr(p.wp4 + (long long)chunk * NIT * 2 * wrow + (long long)m0 * 4);
 #pragma unroll
     for (int u = 0; u < WU; ++u)
-      if (u * 256 < WF4) dma_b128(wsrc, woff[u], lds_addr(wb + (u * 256 + wave * 64) * 4), wmask[u]);
+      if (u * 256 < WF4) dma_b128_v(wsrc, woff[u], lds_addr(wb + (u * 256 + wave * 64) * 4));
   };
 
   __syncthreads();                     // zero fill complete before any DMA data can land

@@ -5,6 +5,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 dma_issue_probe.hip -o bin/dma_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void probe(const float* src, unsigned long long* out, int reps) {
@@ -42,18 +43,21 @@ __global__ __launch_bounds__(256, 2) void probe(const float* src, unsigned long 
   if (lane == 0) atomicAdd(out, t1 - t0);
 }
 
+static int g_threads = 256;
 template <int MODE>
 void run(const char* name, const float* src, unsigned long long* out) {
   const int reps = 64, nblk = 512;
   hipMemset(out, 0, 8);
-  hipLaunchKernelGGL(probe<MODE>, dim3(nblk), dim3(256), 70000, 0, src, out, reps);
+  hipLaunchKernelGGL(probe<MODE>, dim3(nblk), dim3(g_threads), 70000, 0, src, out, reps);
   hipDeviceSynchronize();
   unsigned long long h = 0;
   hipMemcpy(&h, out, 8, hipMemcpyDeviceToHost);
-  printf("%-44s %7.1f cycles per wave-instruction\n", name, (double)h / (nblk * 4.0) / (reps * 16.0));
+  printf("%-44s %7.1f cycles per wave-instruction\n", name, (double)h / (nblk * (g_threads / 64.0)) / (reps * 16.0));
 }
 
-int main() {
+int main(int argc, char** argv) {
+  g_threads = argc > 1 ? atoi(argv[1]) : 256;   // 64: one issuing wave per block (2 per CU)
+  printf("threads per block %d\n", g_threads);
   float* src; unsigned long long* out;
   hipMalloc(&src, 64 << 20); hipMemset(src, 0, 64 << 20); hipMalloc(&out, 8);
   hipFuncSetAttribute((const void*)probe<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 70000);
