@@ -178,10 +178,15 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
     if (c0 < p.C0) { base = in0n + (long long)c0 * HWin; nvalid = p.C0 - c0; }
     else { base = in1n + (long long)(c0 - p.C0) * HWin; nvalid = p.Cin - c0; }
     base = (const float*)sgpr_ptr(base);
+    // site counts re-materialised per call (one s_cmp per site): left to itself hipcc hoists the
+    // 27 loop-invariant guards out of the chunk loop as 64-bit masks, spills them, and reloads
+    // each with two v_readlane -- VALU slots the co-resident wave's MFMA stream leaves scarce
+    int npu = (PE + 255) >> 8, nwu = (WF4 + 255) >> 8;
+    asm volatile("" : "+s"(npu), "+s"(nwu));
     if (nvalid >= KC) {                // chunk-invariant masks apply
 #pragma unroll
       for (int u = 0; u < PU; ++u)
-        if (u * 256 < PE) dma_b32_v(base, toff[u], lds_addr(pb + u * 256 + wave * 64));
+        if (u < npu) dma_b32_v(base, toff[u], lds_addr(pb + u * 256 + wave * 64));
     } else {                           // last chunk of a segment: channels past the end are zero
       const unsigned limit = (unsigned)nvalid * (unsigned)HWin * 4u;
 #pragma unroll
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
     const float* wsrc = (const float*)sgpr_ptr(p.wp4 + (long long)chunk * NIT * 2 * wrow + (long long)m0 * 4);
 #pragma unroll
     for (int u = 0; u < WU; ++u)
-      if (u * 256 < WF4) dma_b128_v(wsrc, woff[u], lds_addr(wb + (u * 256 + wave * 64) * 4));
+      if (u < nwu) dma_b128_v(wsrc, woff[u], lds_addr(wb + (u * 256 + wave * 64) * 4));
   };
 
   __syncthreads();                     // zero fill complete before any DMA data can land
