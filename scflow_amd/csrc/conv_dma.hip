@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   constexpr int NFRAG = WN * 4;
   constexpr int PU = SCF_DMA_PU;
 
+  __builtin_amdgcn_s_setprio(3);       // setup / staging / epilogue instructions go first
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, half = lane >> 5;
@@ -208,9 +209,11 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   stage(0, 0);
 
   for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+    __builtin_amdgcn_s_setprio(3);
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's DMA has landed
     __syncthreads();                                   // everyone's has; previous MFMA phase done
     if (chunk + 1 < p.nchunk) stage(chunk + 1, (chunk + 1) & 1);
+    __builtin_amdgcn_s_setprio(0);                     // the MFMA stream yields to the other waves
 
     const f32x4* wl = reinterpret_cast<const f32x4*>(lds + (chunk & 1) * bufsz) + half * BM + l32;
     const f32x4* pl = reinterpret_cast<const f32x4*>(lds + (chunk & 1) * bufsz + WF4 * 4);
@@ -249,6 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   }
 
   // ---- epilogue: C/D layout col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*half ----
+  __builtin_amdgcn_s_setprio(3);
   const ConvEpi epi = scf_conv_epi(p, n);
   const bool use_div = p.out_div != 1.0f;
   int pix[WN];

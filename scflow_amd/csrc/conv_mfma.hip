@@ -61,6 +61,7 @@ __host__ __device__ constexpr int wu_max(int kc) { return kc == 32 ? 10 : kc == 
 template <int WM, int WN, int KC>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  __builtin_amdgcn_s_setprio(3);
   constexpr int BM = WM * 32;
   constexpr int B4 = BM / 4;
   constexpr int NFRAG = WN * 4;
@@ -186,8 +187,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
         }
       }
     }
-    if (chunk >= 0)
+    if (chunk >= 0) {
+      // the MFMA stream yields issue priority to waves that are staging / in their epilogue:
+      // their vector instructions otherwise crawl behind it
+      __builtin_amdgcn_s_setprio(0);
       mfma_taps<WM, WN, KC / 2>(acc, wl, pl, boff, T, p.KW, KC, BM, PW, PHW, half, l32);
+      __builtin_amdgcn_s_setprio(3);
+    }
   }
 
   // ---- epilogue: C/D layout col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*half ----
