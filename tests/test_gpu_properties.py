@@ -100,3 +100,20 @@ def test_refiner_is_batch_permutation_equivariant_at_full_size(golden_dir):
     # rotations stay orthonormal after 8 compositions
     eye = torch.eye(3, device=DEV).expand(32, 3, 3)
     assert float((torch.bmm(r0, r0.transpose(1, 2)) - eye).abs().max()) <= 1e-4
+
+
+def test_repeated_launches_are_bit_identical():
+    """The LDS-DMA kernels synchronise by hand (vmcnt waits + barriers around asynchronous
+    memory -> LDS copies): a missing wait shows up as run-to-run differences."""
+    x, w, b = rnd((32, 128, 32, 32), 31), rnd((512, 128, 3, 3), 32, 0.03), rnd((512,), 33)
+    pc = ops.PackedConv.from_weight(w, b, padding=1)
+    ref = ops.conv2d(pc, x, act=ops.ACT_RELU).clone()
+    for _ in range(50):
+        assert torch.equal(ops.conv2d(pc, x, act=ops.ACT_RELU), ref)
+    f1, f2 = rnd((32, 256, 32, 32), 34), rnd((32, 256, 32, 32), 35)
+    flow = rnd((32, 2, 32, 32), 36, 3.0)
+    pyr = ops.corr_build(f1, f2, 4, level0_tiled=True)
+    want = ops.corr_lookup(pyr, flow, 4, level0_tiled=True).clone()
+    for _ in range(50):
+        assert torch.equal(ops.corr_lookup(pyr, flow, 4, level0_tiled=True), want)
+        assert torch.equal(ops.corr_build(f1, f2, 1, level0_tiled=True)[0], pyr[0])
