@@ -164,11 +164,11 @@ __device__ __forceinline__ void scf_epi_general_group(const ConvK& p, const Conv
         const int a = (p.act_split > 0 && co >= p.act_split) ? p.act2 : p.act;
         e.out[off] = scf_apply_act(v, a);
       } else if (KIND == SCF_EPI_GRU_ZR) {
-        const float sg = 1.f / (1.f + expf(-v));
+        const float sg = scf_fast_sigmoid(v);
         if (co < hc) e.out[off] = sg;
         else e.gru_aux[off - hc * e.HWo] = sg * aux0[q];
       } else {
-        const float qv = tanhf(v);
+        const float qv = scf_fast_tanh(v);
         e.out[off] = (1.f - aux1[q]) * aux0[q] + aux1[q] * qv;
       }
     }
@@ -217,11 +217,11 @@ __device__ __forceinline__ void scf_epi_general_frag(const ConvK& p, const ConvE
         const int a = (p.act_split > 0 && co >= p.act_split) ? p.act2 : p.act;
         e.out[off] = scf_apply_act(v, a);
       } else if (KIND == SCF_EPI_GRU_ZR) {
-        const float sg = 1.f / (1.f + expf(-v));
+        const float sg = scf_fast_sigmoid(v);
         if (co < hc) e.out[off] = sg;
         else e.gru_aux[off - hc * e.HWo] = sg * a0[r];
       } else {
-        const float qv = tanhf(v);
+        const float qv = scf_fast_tanh(v);
         e.out[off] = (1.f - a1[r]) * a0[r] + a1[r] * qv;
       }
     }

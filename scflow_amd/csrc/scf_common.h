@@ -27,6 +27,19 @@ __device__ __forceinline__ int scf_xcd_remap(int b, int nblk) {
   return base + slot;
 }
 
+// sigmoid / tanh on the hardware transcendental units (v_exp_f32, v_rcp_f32: ~1 ulp each) for the
+// fused convolution epilogues: ~6 vector instructions instead of ~35 for the libm expansions --
+// vector issue slots are the scarce resource next to a co-resident wave's MFMA stream.
+// |error| <= ~3e-7 (sigmoid, relative) / ~1.5e-7 (tanh, absolute).
+__device__ __forceinline__ float scf_fast_sigmoid(float v) {
+  return __builtin_amdgcn_rcpf(1.f + __expf(-v));
+}
+__device__ __forceinline__ float scf_fast_tanh(float v) {
+  const float t = __expf(-2.f * fabsf(v));            // in (0, 1]: never overflows
+  const float r = (1.f - t) * __builtin_amdgcn_rcpf(1.f + t);
+  return copysignf(r, v);
+}
+
 __device__ __forceinline__ float scf_apply_act(float v, int act) {
   switch (act) {
     case SCF_ACT_RELU: return v > 0.f ? v : 0.f;
