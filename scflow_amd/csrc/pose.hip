@@ -247,7 +247,7 @@ extern "C" int scf_filter_flow_by_mask(float* flow, const float* mask, int N, in
                                        float invalid_num, int align_corners, scf_stream_t stream) {
   if (!flow || !mask || N <= 0 || H <= 0 || W <= 0) return SCF_EINVAL;
   const long long total = (long long)N * H * W;
-  const int grid = (int)(scf_cdiv(total, 256) < 8192 ? scf_cdiv(total, 256) : 8192);
+  const int grid = (int)(scf_cdiv(total, 256) < 262144 ? scf_cdiv(total, 256) : 262144);
   hipLaunchKernelGGL(filter_flow_by_mask_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), flow, mask,
                      N, H, W, invalid_num, align_corners);
   return scf_launch_status();

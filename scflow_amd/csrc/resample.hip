@@ -44,7 +44,7 @@ extern "C" int scf_resize_bilinear(const float* a, const float* b, float* out, i
   const float sh = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
   const float sw = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
   const long long total = (long long)planes * Hout * Wout;
-  const int grid = (int)(scf_cdiv(total, 256) < 8192 ? scf_cdiv(total, 256) : 8192);
+  const int grid = (int)(scf_cdiv(total, 256) < 262144 ? scf_cdiv(total, 256) : 262144);
   hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), a, b,
                      out, (long long)planes, Hin, Win, Hout, Wout, sh, sw, mul);
   return scf_launch_status();
@@ -72,7 +72,7 @@ extern "C" int scf_avgpool2x2(const float* x, float* out, int64_t planes, int Hi
   if (!x || !out || planes <= 0 || Hin < 2 || Win < 2) return SCF_EINVAL;
   const int Ho = Hin / 2, Wo = Win / 2;
   const long long total = (long long)planes * Ho * Wo;
-  const int grid = (int)(scf_cdiv(total, 256) < 16384 ? scf_cdiv(total, 256) : 16384);
+  const int grid = (int)(scf_cdiv(total, 256) < 262144 ? scf_cdiv(total, 256) : 262144);
   hipLaunchKernelGGL(avgpool2x2_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), x, out,
                      (long long)planes, Hin, Win, Ho, Wo);
   return scf_launch_status();
@@ -103,7 +103,7 @@ extern "C" int scf_avgpool2x2_tiled_in(const float* x, float* out, int64_t plane
   if (!x || !out || planes <= 0 || Hin < 4 || Win < 8 || (Win & 7) || (Hin & 3)) return SCF_EINVAL;
   const int Ho = Hin / 2, Wo = Win / 2;
   const long long total = (long long)planes * Ho * Wo;
-  const int grid = (int)(scf_cdiv(total, 256) < 16384 ? scf_cdiv(total, 256) : 16384);
+  const int grid = (int)(scf_cdiv(total, 256) < 262144 ? scf_cdiv(total, 256) : 262144);
   hipLaunchKernelGGL(avgpool2x2_tiled_in_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), x, out,
                      (long long)planes, Hin, Win, Ho, Wo);
   return scf_launch_status();
@@ -124,7 +124,7 @@ extern "C" int scf_copy_strided(const float* src, int64_t src_nstride, float* ds
                                 int64_t dst_nstride, int N, int64_t count, scf_stream_t stream) {
   if (!src || !dst || N <= 0 || count <= 0) return SCF_EINVAL;
   const long long total = (long long)N * count;
-  const int grid = (int)(scf_cdiv(total, 256) < 8192 ? scf_cdiv(total, 256) : 8192);
+  const int grid = (int)(scf_cdiv(total, 256) < 262144 ? scf_cdiv(total, 256) : 262144);
   hipLaunchKernelGGL(copy_strided_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), src,
                      (long long)src_nstride, dst, (long long)dst_nstride, N, (long long)count);
   return scf_launch_status();
