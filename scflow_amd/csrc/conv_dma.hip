@@ -90,16 +90,19 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, half = lane >> 5;
 
+  // block-uniform tile coordinates, pinned to SGPRs (the integer divisions are expanded on the
+  // vector ALU and would otherwise leave n / m0 / the tile origin -- and every pointer derived
+  // from them -- in VGPRs)
   const int lb = scf_xcd_remap(blockIdx.x, gridDim.x);
-  const int mblk = lb % p.mblocks;
-  const int tile = lb / p.mblocks;
+  const int mblk = __builtin_amdgcn_readfirstlane(lb % p.mblocks);
+  const int tile = __builtin_amdgcn_readfirstlane(lb / p.mblocks);
   const int m0 = mblk * BM;
 
   const int FC = 1 << p.fc_log2, FR = 32 >> p.fc_log2, TR = NFRAG * FR;
-  const int txi = tile % p.tiles_x;
+  const int txi = __builtin_amdgcn_readfirstlane(tile % p.tiles_x);
   const int t2 = tile / p.tiles_x;
-  const int tyi = t2 % p.tiles_y;
-  const int n = t2 / p.tiles_y;
+  const int tyi = __builtin_amdgcn_readfirstlane(t2 % p.tiles_y);
+  const int n = __builtin_amdgcn_readfirstlane(t2 / p.tiles_y);
   const int ty0 = tyi * TR, tx0 = txi * FC;
   const int st = p.stride;             // 1 or 2
   const int iy0 = ty0 * st - p.pad_h, ix0 = tx0 * st - p.pad_w;
