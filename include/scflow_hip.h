@@ -128,6 +128,9 @@ typedef struct scf_conv_desc {
   const float* wp_thin;                 /* optional third packing for Cout <= 4 layers (vector-ALU
                                            kernel): [Cin][KH*KW][CO] floats, CO = 1, 2 or 4 (Cout
                                            rounded up), zero padded                                */
+  int32_t in_c4, out_c4;                /* EXPERIMENTAL (measurement only):
+                                           input / output stored channel-interleaved
+                                           [N][C/4][H][W][4]; in_c4 needs wp_a4 packed for it     */
   int32_t out_tile8x4;                  /* 1: store every output plane in 8(x) x 4(y)-float tiles
                                            of 128 B (tile-major, row-major inside) instead of
                                            row-major; needs Wo % 8 == 0 and Ho % 4 == 0          */

@@ -44,6 +44,8 @@ class ConvDesc(C.Structure):
         ('a4_groups', C.c_int32),
         ('a4_mld', C.c_int32),
         ('wp_thin', _fp),
+        ('in_c4', C.c_int32),
+        ('out_c4', C.c_int32),
         ('out_tile8x4', C.c_int32),
     ]
 

@@ -422,6 +422,7 @@ static int conv_plan(const scf_conv_desc* d, ConvPlan* plan) {
   if (k.Ho <= 0 || k.Wo <= 0) return SCF_EINVAL;
   k.wp = d->wp; k.w_ns = d->w_nstride; k.Mld = d->Mld; k.Cout = d->Cout;
   k.wp16 = d->wp_f16;
+  k.in_c4 = d->in_c4; k.out_c4 = d->out_c4;
   k.wthin = d->wp_thin;
   k.wp4 = d->wp_a4; k.G4 = d->a4_groups; k.Mld4 = d->a4_mld;
   k.out_tile = d->out_tile8x4;

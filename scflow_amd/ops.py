@@ -125,7 +125,7 @@ def choose_a4_groups(cin: int, kh: int, kw: int, stride: int) -> int:
     return 2 if t <= 5 else 1
 
 
-def pack_conv_weight_a4(weight: Tensor, groups: int) -> Tuple[Tensor, int]:
+def pack_conv_weight_a4(weight: Tensor, groups: int, c4: bool = False) -> Tuple[Tensor, int]:
     """(Cout, Cin, KH, KW) -> [chunk][tap][g][h][Mld][4] (conv_dma.hip): channel
     chunk*8G + 8g + 2s + h at float s of cell (g, h); zero-padded channels and couts."""
     cout, cin, kh, kw = weight.shape
@@ -134,6 +134,9 @@ def pack_conv_weight_a4(weight: Tensor, groups: int) -> Tuple[Tensor, int]:
     mld = (cout + 31) // 32 * 32
     w = torch.zeros((mld, nchunk * kc, t), dtype=torch.float32, device=weight.device)
     w[:cout, :cin] = weight.reshape(cout, cin, t).float()
+    if c4:      # experimental NC/4HW4 inputs: channel chunk*8G + 8g + 4h + s at float s of cell (g, h)
+        w = w.reshape(mld, nchunk, groups, 2, 4, t).permute(1, 5, 2, 3, 0, 4)
+        return w.contiguous().reshape(-1), mld
     # channel index -> (chunk, g, s, h)
     w = w.reshape(mld, nchunk, groups, 4, 2, t).permute(1, 5, 2, 4, 0, 3)
     return w.contiguous().reshape(-1), mld

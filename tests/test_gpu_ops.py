@@ -424,3 +424,29 @@ def test_conv2d_f16x3_gru_and_segments():
         ops.set_conv_precision(prev)
     close(zb, z, atol=2e-5, what='z')
     close(hxd[:, :128], want, atol=3e-5, what='h_new f16x3')
+
+
+def test_conv2d_experimental_c4_layout_matches_nchw():
+    """EXPERIMENTAL scf_conv_desc.in_c4 / out_c4 (channel-interleaved activations, DESIGN.md
+    section 7 lever 1): same numbers as the NCHW path after converting the layout back."""
+    import ctypes as C
+    from scflow_amd import _lib
+    n, cin, cout, H, W = 32, 128, 256, 32, 32
+    x, w, b = rnd((n, cin, H, W), 60).to(DEV), rnd((cout, cin, 3, 3), 61, 0.03).to(DEV), rnd((cout,), 62).to(DEV)
+    pc = ops.PackedConv.from_weight(w, b, padding=1)
+    ref = ops.conv2d(pc, x, act=ops.ACT_RELU)
+    w4 = ops.pack_conv_weight_a4(w, pc.g4, c4=True)[0]
+    x4 = x.view(n, cin // 4, 4, H, W).permute(0, 1, 3, 4, 2).contiguous()
+    out4 = torch.empty((n, cout // 4, H, W, 4), device=DEV)
+    d = _lib.ConvDesc()
+    d.in0, d.C0, d.C1, d.in0_nstride = x4.data_ptr(), cin, 0, cin * H * W
+    d.N, d.H, d.W = n, H, W
+    d.wp, d.w_nstride, d.Mld, d.Cout = pc.wp.data_ptr(), 0, pc.mld, cout
+    d.KH, d.KW, d.stride, d.pad_h, d.pad_w, d.KC = 3, 3, 1, 1, 1, pc.kc
+    d.out, d.out_nstride = out4.data_ptr(), cout * H * W
+    d.bias, d.out_div, d.act = b.data_ptr(), 1.0, ops.ACT_RELU
+    d.wp_a4, d.a4_groups, d.a4_mld = w4.data_ptr(), pc.g4, pc.mld
+    d.in_c4, d.out_c4 = 1, 1
+    _lib.check(_lib.load().scf_conv2d(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'c4')
+    got = out4.permute(0, 1, 4, 2, 3).reshape(n, cout, H, W)
+    close(got, ref.cpu(), atol=3e-5, what='c4 layout')
