@@ -227,7 +227,7 @@ def main():
                        'batch_per_gpu': args.batch, 'global_batch': args.batch * world,
                        'height': 256, 'width': 256, 'iters': args.iters,
                        'parallelism': f'batch-split x{world}, no data-path collective'},
-            'roofline': {'kernel': 'corr_lookup_kernel<4, true>', 'bound': 'hbm',
+            'roofline': {'kernel': 'corr_lookup_kernel<4, true, 32>', 'bound': 'hbm',
                          'achieved': None if achieved is None else round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
@@ -240,9 +240,9 @@ def main():
         if rk:      # committed `rocprofv3 --kernel-trace --stats` pass of this command (profiles/)
             result['roofline']['rocprof_avg_launch_us'] = rk['avg_us']
             result['roofline']['note'] = (
-                'achieved/frac use the live event-to-event time, which includes ~3 us of dispatch '
-                'per launch; the kernel-trace duration of the same kernel in profiles/ is '
-                f"{rk['avg_us']} us = {LOOKUP_BYTES_PER_QUERY * q / rk['avg_us'] / 1e3:.0f} GB/s = "
+                'avg_launch_us: HIP start/stop events bound to each lookup launch of the timed steps '
+                '(hipExtLaunchKernel on the launch stream = the dispatch\'s own begin/end timestamps); '
+                f"the committed kernel trace of this command averages {rk['avg_us']} us = "
                 f"{LOOKUP_BYTES_PER_QUERY * q / rk['avg_us'] / 1e3 / HBM_PEAK_GBS:.3f} of peak")
         cb_fl = 2.0 * 256 * 1024 * 1024 * args.batch
         if cb_us:

@@ -82,6 +82,18 @@ int scf_corr_build_ex(const float* feat1, const float* feat2, float* const* leve
 int scf_corr_lookup_ex(const float* const* levels, const float* flow, float* out, int N, int h,
                        int w, int r, int L, int level0_tiled, scf_stream_t stream);
 
+/* Measurement aid: the same launch with a timer bound to it (hipExtLaunchKernel start / stop
+ * events = the dispatch's own begin / end timestamps, what a kernel trace reports; a pair of
+ * recorded events around a launch additionally contains ~3 us of dispatch).  A timer is reusable
+ * after its launch has completed; read it after synchronising the stream. */
+typedef void* scf_timer_t;
+int scf_timer_create(scf_timer_t* timer);
+int scf_timer_destroy(scf_timer_t timer);
+int scf_timer_elapsed_us(scf_timer_t timer, float* microseconds);
+int scf_corr_lookup_timed(const float* const* levels, const float* flow, float* out, int N, int h,
+                          int w, int r, int L, int level0_tiled, scf_timer_t timer,
+                          scf_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * Direct convolution as implicit GEMM on MFMA with fused epilogue.
  * replaces every torch conv2d (+bias +BN(eval) +residual +activation +GRU gating) on

@@ -65,6 +65,11 @@ SIGNATURES = {
                                      C.c_int, C.c_int, _fp]),
     'scf_pose_error': (C.c_int, [_fp, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     'scf_filter_flow_by_mask': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _fp]),
+    'scf_timer_create': (C.c_int, [C.POINTER(_fp)]),
+    'scf_timer_destroy': (C.c_int, [_fp]),
+    'scf_timer_elapsed_us': (C.c_int, [_fp, C.POINTER(C.c_float)]),
+    'scf_corr_lookup_timed': (C.c_int, [C.POINTER(_fp), _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, _fp, _fp]),
     'scf_conv2d': (C.c_int, [C.POINTER(ConvDesc), _fp]),
     'scf_conv2d_query': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int32)]),
     'scf_instance_norm': (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int, C.c_float, C.c_int, _fp]),

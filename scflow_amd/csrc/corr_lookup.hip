@@ -21,6 +21,7 @@
 //                weights are per (query, level) constants because offsets are integers.
 //   store      : out[n, k, y, x]; each half-wave writes 32 consecutive queries of one
 //                channel = one full 128-B line.
+#include <hip/hip_ext.h>
 #include "scf_common.h"
 
 struct LookupParams {
@@ -257,8 +258,37 @@ __global__ __launch_bounds__(256, QB == 32 ? 4 : 8) void corr_lookup_kernel(Look
   }
 }
 
-extern "C" int scf_corr_lookup_ex(const float* const* levels, const float* flow, float* out, int N,
-                                  int h, int w, int r, int L, int level0_tiled, scf_stream_t stream) {
+// A timer = two HIP events bound to ONE kernel launch (hipExtLaunchKernel start / stop events):
+// they carry the dispatch's own begin / end timestamps, i.e. the duration a kernel trace reports,
+// not the event-to-event interval of hipEventRecord pairs (which adds ~3 us of dispatch).
+struct ScfTimer { hipEvent_t start, stop; };
+
+extern "C" int scf_timer_create(scf_timer_t* out) {
+  if (!out) return SCF_EINVAL;
+  ScfTimer* t = new ScfTimer;
+  if (hipEventCreate(&t->start) != hipSuccess || hipEventCreate(&t->stop) != hipSuccess) { delete t; return SCF_ELAUNCH; }
+  *out = t;
+  return SCF_OK;
+}
+extern "C" int scf_timer_destroy(scf_timer_t tm) {
+  ScfTimer* t = static_cast<ScfTimer*>(tm);
+  if (!t) return SCF_EINVAL;
+  (void)hipEventDestroy(t->start);
+  (void)hipEventDestroy(t->stop);
+  delete t;
+  return SCF_OK;
+}
+extern "C" int scf_timer_elapsed_us(scf_timer_t tm, float* us) {
+  ScfTimer* t = static_cast<ScfTimer*>(tm);
+  if (!t || !us) return SCF_EINVAL;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, t->start, t->stop) != hipSuccess) return SCF_ELAUNCH;
+  *us = ms * 1e3f;
+  return SCF_OK;
+}
+
+static int lookup_launch(const float* const* levels, const float* flow, float* out, int N, int h, int w,
+                         int r, int L, int level0_tiled, ScfTimer* tm, scf_stream_t stream) {
   if (level0_tiled && ((w & 7) || (h & 3) || h <= 2 * r + 2 || w <= 2 * r + 2)) return SCF_EUNSUPPORTED;
   if (!levels || !flow || !out || N <= 0 || h <= 0 || w <= 0 || L <= 0) return SCF_EINVAL;
   if (L > SCF_MAX_LEVELS) return SCF_EUNSUPPORTED;
@@ -297,10 +327,14 @@ extern "C" int scf_corr_lookup_ex(const float* const* levels, const float* flow,
   }
   const size_t lds = (size_t)off * sizeof(float);
 #define SCF_LK2(R_, T_, Q_)                                                                         \
-  hipLaunchKernelGGL((corr_lookup_kernel<R_, T_, Q_>), dim3(nblk), dim3(256), lds, scf_stream(stream), p)
+  do {                                                                                              \
+    if (tm) hipExtLaunchKernelGGL((corr_lookup_kernel<R_, T_, Q_>), dim3(nblk), dim3(256), (unsigned)lds, \
+                                  scf_stream(stream), tm->start, tm->stop, 0, p);                   \
+    else hipLaunchKernelGGL((corr_lookup_kernel<R_, T_, Q_>), dim3(nblk), dim3(256), lds, scf_stream(stream), p); \
+  } while (0)
 #define SCF_LK(R_)                                                                                 \
   case R_:                                                                                         \
-    if (level0_tiled) SCF_LK2(R_, true, 32); else SCF_LK2(R_, false, 32);                          \
+    if (level0_tiled) { SCF_LK2(R_, true, 32); } else { SCF_LK2(R_, false, 32); }                  \
     break;
   switch (r) {
     SCF_LK(4) SCF_LK(3) SCF_LK(2) SCF_LK(1)
@@ -311,7 +345,19 @@ extern "C" int scf_corr_lookup_ex(const float* const* levels, const float* flow,
   return scf_launch_status();
 }
 
+extern "C" int scf_corr_lookup_ex(const float* const* levels, const float* flow, float* out, int N,
+                                  int h, int w, int r, int L, int level0_tiled, scf_stream_t stream) {
+  return lookup_launch(levels, flow, out, N, h, w, r, L, level0_tiled, nullptr, stream);
+}
+
+extern "C" int scf_corr_lookup_timed(const float* const* levels, const float* flow, float* out, int N,
+                                     int h, int w, int r, int L, int level0_tiled, scf_timer_t timer,
+                                     scf_stream_t stream) {
+  if (!timer) return SCF_EINVAL;
+  return lookup_launch(levels, flow, out, N, h, w, r, L, level0_tiled, static_cast<ScfTimer*>(timer), stream);
+}
+
 extern "C" int scf_corr_lookup(const float* const* levels, const float* flow, float* out, int N,
                                int h, int w, int r, int L, scf_stream_t stream) {
-  return scf_corr_lookup_ex(levels, flow, out, N, h, w, r, L, 0, stream);
+  return lookup_launch(levels, flow, out, N, h, w, r, L, 0, nullptr, stream);
 }

@@ -376,16 +376,18 @@ def corr_lookup(pyramid: Sequence[Tensor], flow: Tensor, radius: int = 4,
     if out is None:
         out = torch.empty((n, k, h, w), dtype=torch.float32, device=flow.device)
     arr = (C.c_void_p * L)(*[_dense(t, 'level') for t in pyramid])
-    ev = None
-    if _LOOKUP_EVENTS is not None:      # bench.py: per-launch HIP events on the launch stream
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        ev[0].record()
+    if _LOOKUP_EVENTS is not None:      # bench.py: a HIP start/stop event pair bound to this launch
+        lib = _lib.load()
+        tm = C.c_void_p()
+        _lib.check(lib.scf_timer_create(C.byref(tm)), 'scf_timer_create')
+        _lib.check(lib.scf_corr_lookup_timed(arr, pf, _dense(out, 'out'), n, h, w, radius, L,
+                                             1 if level0_tiled else 0, tm, _stream()),
+                   'scf_corr_lookup_timed')
+        _LOOKUP_EVENTS.append(tm)
+        return out
     _lib.check(_lib.load().scf_corr_lookup_ex(arr, pf, _dense(out, 'out'), n, h, w, radius, L,
                                               1 if level0_tiled else 0, _stream()),
                'scf_corr_lookup')
-    if ev is not None:
-        ev[1].record()
-        _LOOKUP_EVENTS.append(ev)
     return out
 
 
@@ -393,16 +395,23 @@ _LOOKUP_EVENTS = None
 
 
 def lookup_timing(enable: bool):
-    """enable=True: start bracketing every corr-lookup launch with a pair of events recorded
-    on the stream it is launched on.  enable=False: stop, synchronise and return the
-    per-launch durations in microseconds."""
+    """enable=True: every corr-lookup launch from now on carries a timer (HIP start / stop events
+    bound to the launch on its stream: the kernel's own duration).  enable=False: stop,
+    synchronise and return the per-launch durations in microseconds."""
     global _LOOKUP_EVENTS
     if enable:
         _LOOKUP_EVENTS = []
         return None
-    evs, _LOOKUP_EVENTS = _LOOKUP_EVENTS or [], None
+    timers, _LOOKUP_EVENTS = _LOOKUP_EVENTS or [], None
     torch.cuda.synchronize()
-    return [a.elapsed_time(b) * 1e3 for a, b in evs]
+    lib = _lib.load()
+    out = []
+    for tm in timers:
+        us = C.c_float()
+        _lib.check(lib.scf_timer_elapsed_us(tm, C.byref(us)), 'scf_timer_elapsed_us')
+        lib.scf_timer_destroy(tm)
+        out.append(float(us.value))
+    return out
 
 
 # ------------------------------------------------------------- norms etc.
