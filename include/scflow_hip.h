@@ -90,6 +90,9 @@ typedef void* scf_timer_t;
 int scf_timer_create(scf_timer_t* timer);
 int scf_timer_destroy(scf_timer_t timer);
 int scf_timer_elapsed_us(scf_timer_t timer, float* microseconds);
+/* attach the timer to the NEXT kernel this thread launches through the library (the convolution
+ * of scf_conv2d / scf_corr_build*, the lookup, ...); NULL disarms */
+int scf_timer_arm(scf_timer_t timer);
 int scf_corr_lookup_timed(const float* const* levels, const float* flow, float* out, int N, int h,
                           int w, int r, int L, int level0_tiled, scf_timer_t timer,
                           scf_stream_t stream);

@@ -67,6 +67,7 @@ SIGNATURES = {
     'scf_filter_flow_by_mask': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _fp]),
     'scf_timer_create': (C.c_int, [C.POINTER(_fp)]),
     'scf_timer_destroy': (C.c_int, [_fp]),
+    'scf_timer_arm': (C.c_int, [_fp]),
     'scf_timer_elapsed_us': (C.c_int, [_fp, C.POINTER(C.c_float)]),
     'scf_corr_lookup_timed': (C.c_int, [C.POINTER(_fp), _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, _fp, _fp]),

@@ -295,7 +295,7 @@ static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st
       raised = true;
     }
   }
-  hipLaunchKernelGGL((conv_dma_kernel<WM, WN, C4>), dim3(nblk), dim3(256), lds_bytes, st, k);
+  scf_launch((conv_dma_kernel<WM, WN, C4>), dim3(nblk), dim3(256), lds_bytes, st, k);
   return scf_launch_status();
 }
 

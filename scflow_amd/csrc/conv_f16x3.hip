@@ -251,7 +251,7 @@ static int launch_f16(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st
       raised = true;
     }
   }
-  hipLaunchKernelGGL((conv_f16x3_kernel<WM, WN, NK>), dim3(nblk), dim3(256), lds_bytes, st, k);
+  scf_launch((conv_f16x3_kernel<WM, WN, NK>), dim3(nblk), dim3(256), lds_bytes, st, k);
   return scf_launch_status();
 }
 

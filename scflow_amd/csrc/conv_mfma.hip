@@ -371,18 +371,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_ksplit_kernel(ConvK p) {
 
 template <int KC>
 static int launch_ksplit(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
-  hipLaunchKernelGGL((conv_mfma_ksplit_kernel<KC>), dim3(nblk), dim3(256), lds_bytes, st, k);
+  scf_launch((conv_mfma_ksplit_kernel<KC>), dim3(nblk), dim3(256), lds_bytes, st, k);
   return scf_launch_status();
 }
 
 template <int WM, int WN>
 static int launch_conv(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
   if (k.KC == 32)
-    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, 32>), dim3(nblk), dim3(256), lds_bytes, st, k);
+    scf_launch((conv_mfma_kernel<WM, WN, 32>), dim3(nblk), dim3(256), lds_bytes, st, k);
   else if (k.KC == 8)
-    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, 8>), dim3(nblk), dim3(256), lds_bytes, st, k);
+    scf_launch((conv_mfma_kernel<WM, WN, 8>), dim3(nblk), dim3(256), lds_bytes, st, k);
   else
-    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, 2>), dim3(nblk), dim3(256), lds_bytes, st, k);
+    scf_launch((conv_mfma_kernel<WM, WN, 2>), dim3(nblk), dim3(256), lds_bytes, st, k);
   return scf_launch_status();
 }
 

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvK p) {
 
 template <int K, int CO>
 static int launch_thin(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
-  hipLaunchKernelGGL((conv_thin_kernel<K, CO>), dim3(nblk), dim3(256), lds_bytes, st, k);
+  scf_launch((conv_thin_kernel<K, CO>), dim3(nblk), dim3(256), lds_bytes, st, k);
   return scf_launch_status();
 }
 

@@ -21,7 +21,6 @@
 //                weights are per (query, level) constants because offsets are integers.
 //   store      : out[n, k, y, x]; each half-wave writes 32 consecutive queries of one
 //                channel = one full 128-B line.
-#include <hip/hip_ext.h>
 #include "scf_common.h"
 
 struct LookupParams {
@@ -258,37 +257,8 @@ __global__ __launch_bounds__(256, QB == 32 ? 4 : 8) void corr_lookup_kernel(Look
   }
 }
 
-// A timer = two HIP events bound to ONE kernel launch (hipExtLaunchKernel start / stop events):
-// they carry the dispatch's own begin / end timestamps, i.e. the duration a kernel trace reports,
-// not the event-to-event interval of hipEventRecord pairs (which adds ~3 us of dispatch).
-struct ScfTimer { hipEvent_t start, stop; };
-
-extern "C" int scf_timer_create(scf_timer_t* out) {
-  if (!out) return SCF_EINVAL;
-  ScfTimer* t = new ScfTimer;
-  if (hipEventCreate(&t->start) != hipSuccess || hipEventCreate(&t->stop) != hipSuccess) { delete t; return SCF_ELAUNCH; }
-  *out = t;
-  return SCF_OK;
-}
-extern "C" int scf_timer_destroy(scf_timer_t tm) {
-  ScfTimer* t = static_cast<ScfTimer*>(tm);
-  if (!t) return SCF_EINVAL;
-  (void)hipEventDestroy(t->start);
-  (void)hipEventDestroy(t->stop);
-  delete t;
-  return SCF_OK;
-}
-extern "C" int scf_timer_elapsed_us(scf_timer_t tm, float* us) {
-  ScfTimer* t = static_cast<ScfTimer*>(tm);
-  if (!t || !us) return SCF_EINVAL;
-  float ms = 0.f;
-  if (hipEventElapsedTime(&ms, t->start, t->stop) != hipSuccess) return SCF_ELAUNCH;
-  *us = ms * 1e3f;
-  return SCF_OK;
-}
-
 static int lookup_launch(const float* const* levels, const float* flow, float* out, int N, int h, int w,
-                         int r, int L, int level0_tiled, ScfTimer* tm, scf_stream_t stream) {
+                         int r, int L, int level0_tiled, scf_stream_t stream) {
   if (level0_tiled && ((w & 7) || (h & 3) || h <= 2 * r + 2 || w <= 2 * r + 2)) return SCF_EUNSUPPORTED;
   if (!levels || !flow || !out || N <= 0 || h <= 0 || w <= 0 || L <= 0) return SCF_EINVAL;
   if (L > SCF_MAX_LEVELS) return SCF_EUNSUPPORTED;
@@ -327,11 +297,7 @@ static int lookup_launch(const float* const* levels, const float* flow, float* o
   }
   const size_t lds = (size_t)off * sizeof(float);
 #define SCF_LK2(R_, T_, Q_)                                                                         \
-  do {                                                                                              \
-    if (tm) hipExtLaunchKernelGGL((corr_lookup_kernel<R_, T_, Q_>), dim3(nblk), dim3(256), (unsigned)lds, \
-                                  scf_stream(stream), tm->start, tm->stop, 0, p);                   \
-    else hipLaunchKernelGGL((corr_lookup_kernel<R_, T_, Q_>), dim3(nblk), dim3(256), lds, scf_stream(stream), p); \
-  } while (0)
+  scf_launch((corr_lookup_kernel<R_, T_, Q_>), dim3(nblk), dim3(256), lds, scf_stream(stream), p)
 #define SCF_LK(R_)                                                                                 \
   case R_:                                                                                         \
     if (level0_tiled) { SCF_LK2(R_, true, 32); } else { SCF_LK2(R_, false, 32); }                  \
@@ -347,17 +313,20 @@ static int lookup_launch(const float* const* levels, const float* flow, float* o
 
 extern "C" int scf_corr_lookup_ex(const float* const* levels, const float* flow, float* out, int N,
                                   int h, int w, int r, int L, int level0_tiled, scf_stream_t stream) {
-  return lookup_launch(levels, flow, out, N, h, w, r, L, level0_tiled, nullptr, stream);
+  return lookup_launch(levels, flow, out, N, h, w, r, L, level0_tiled, stream);
 }
 
 extern "C" int scf_corr_lookup_timed(const float* const* levels, const float* flow, float* out, int N,
                                      int h, int w, int r, int L, int level0_tiled, scf_timer_t timer,
                                      scf_stream_t stream) {
   if (!timer) return SCF_EINVAL;
-  return lookup_launch(levels, flow, out, N, h, w, r, L, level0_tiled, static_cast<ScfTimer*>(timer), stream);
+  scf_timer_arm(timer);
+  const int rc = lookup_launch(levels, flow, out, N, h, w, r, L, level0_tiled, stream);
+  scf_timer_arm(nullptr);
+  return rc;
 }
 
 extern "C" int scf_corr_lookup(const float* const* levels, const float* flow, float* out, int N,
                                int h, int w, int r, int L, scf_stream_t stream) {
-  return lookup_launch(levels, flow, out, N, h, w, r, L, 0, nullptr, stream);
+  return lookup_launch(levels, flow, out, N, h, w, r, L, 0, stream);
 }

@@ -1,6 +1,7 @@
 // Shared helpers for the gfx950 kernels of libscflow_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/scflow_hip.h"
@@ -15,6 +16,25 @@ static inline int scf_launch_status() {
 static inline hipStream_t scf_stream(scf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int64_t scf_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// A timer = two HIP events bound to ONE kernel launch (hipExtLaunchKernel start / stop events:
+// the dispatch's own begin / end timestamps, i.e. what a kernel trace reports; a pair of
+// recorded events around a launch additionally contains ~3 us of dispatch).  scf_timer_arm()
+// attaches a timer to the NEXT kernel this thread launches through scf_launch().
+struct ScfTimer { hipEvent_t start, stop; };
+ScfTimer*& scf_armed_timer();          // thread-local slot, defined in capi.hip
+
+template <typename F, typename... Args>
+static inline void scf_launch(F kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+  ScfTimer*& slot = scf_armed_timer();
+  if (slot) {
+    ScfTimer* t = slot;
+    slot = nullptr;
+    hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)lds, st, t->start, t->stop, 0, args...);
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+  }
+}
 
 // XCD-aware block remap (bijective for any grid size): consecutive LOGICAL ids run on the
 // same XCD so that blocks sharing an input halo / a weight slab hit the same L2.

@@ -300,18 +300,33 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
             pc.plans[key] = use_alt
         if use_alt:
             d.wp, d.KC = pc.wp_alt.data_ptr(), 32
-    ev = None
-    if _CONV_EVENTS is not None:        # bench.py: per-launch HIP events + algorithmic flops
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        ev[0].record()
+    if _CONV_EVENTS is not None:        # bench.py: a timer bound to this launch + algorithmic flops
+        lib = _lib.load()
+        tm = C.c_void_p()
+        _lib.check(lib.scf_timer_create(C.byref(tm)), 'scf_timer_create')
+        lib.scf_timer_arm(tm)
+        try:
+            _lib.check(lib.scf_conv2d(C.byref(d), _stream()), 'scf_conv2d')
+        finally:
+            lib.scf_timer_arm(None)
+        _CONV_EVENTS.append((tm, 2.0 * pc.cin * pc.kh * pc.kw * pc.cout * ho * wo * n))
+        return out
     _lib.check(_lib.load().scf_conv2d(C.byref(d), _stream()), 'scf_conv2d')
-    if ev is not None:
-        ev[1].record()
-        _CONV_EVENTS.append((ev[0], ev[1], 2.0 * pc.cin * pc.kh * pc.kw * pc.cout * ho * wo * n))
     return out
 
 
 _CONV_EVENTS = None
+
+
+def _read_timers(timers):
+    lib = _lib.load()
+    out = []
+    for tm in timers:
+        us = C.c_float()
+        _lib.check(lib.scf_timer_elapsed_us(tm, C.byref(us)), 'scf_timer_elapsed_us')
+        lib.scf_timer_destroy(tm)
+        out.append(float(us.value))
+    return out
 
 
 def conv_timing(enable: bool):
@@ -323,7 +338,22 @@ def conv_timing(enable: bool):
         return None
     evs, _CONV_EVENTS = _CONV_EVENTS or [], None
     torch.cuda.synchronize()
-    return [(a.elapsed_time(b) * 1e3, fl) for a, b, fl in evs]
+    return list(zip(_read_timers([t for t, _ in evs]), [fl for _, fl in evs]))
+
+
+def time_first_kernel(fn) -> float:
+    """run ``fn()`` with a launch-bound timer armed: microseconds of the FIRST kernel it launches
+    through the library (e.g. the contraction of ``corr_build``, not its pooling cascade)."""
+    lib = _lib.load()
+    tm = C.c_void_p()
+    _lib.check(lib.scf_timer_create(C.byref(tm)), 'scf_timer_create')
+    lib.scf_timer_arm(tm)
+    try:
+        fn()
+    finally:
+        lib.scf_timer_arm(None)
+    torch.cuda.synchronize()
+    return _read_timers([tm])[0]
 
 
 # ----------------------------------------------------- correlation volume
@@ -404,14 +434,7 @@ def lookup_timing(enable: bool):
         return None
     timers, _LOOKUP_EVENTS = _LOOKUP_EVENTS or [], None
     torch.cuda.synchronize()
-    lib = _lib.load()
-    out = []
-    for tm in timers:
-        us = C.c_float()
-        _lib.check(lib.scf_timer_elapsed_us(tm, C.byref(us)), 'scf_timer_elapsed_us')
-        lib.scf_timer_destroy(tm)
-        out.append(float(us.value))
-    return out
+    return _read_timers(timers)
 
 
 # ------------------------------------------------------------- norms etc.
