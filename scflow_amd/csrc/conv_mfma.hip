@@ -533,6 +533,16 @@ extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
   ConvPlan pl;
   const int rc = conv_plan(d, &pl);
   if (rc != SCF_OK) return rc;
+  if (d->in_c4 || d->out_c4) {
+    // experimental channel-interleaved activations: only the LDS-DMA kernel with the bias / ReLU
+    // epilogue understands them -- never fall through to a kernel that would misread the layout
+    const bool plain = d->mode == SCF_CONV_PLAIN && !d->res && !d->scale && d->act_split <= 0 &&
+                       (d->act == SCF_ACT_NONE || d->act == SCF_ACT_RELU) &&
+                       (d->out_div == 0.f || d->out_div == 1.f) && !d->out_tile8x4;
+    if (!(d->in_c4 && d->out_c4) || !plain || !want_dma(d) || (d->Cout % 64) != 0 || ((d->C0 + d->C1) % 4) != 0)
+      return SCF_EUNSUPPORTED;
+    return scf_conv_dma_dispatch(pl.k, d->N, false, nullptr, scf_stream(stream));
+  }
   {
     const int rt = scf_conv_thin_dispatch(pl.k, d->N, false, scf_stream(stream));
     if (rt != SCF_EUNSUPPORTED) return rt;

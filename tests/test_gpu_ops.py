@@ -450,3 +450,8 @@ def test_conv2d_experimental_c4_layout_matches_nchw():
     _lib.check(_lib.load().scf_conv2d(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'c4')
     got = out4.permute(0, 1, 4, 2, 3).reshape(n, cout, H, W)
     close(got, ref.cpu(), atol=3e-5, what='c4 layout')
+    # anything the experimental layout does not cover is refused, never silently misread
+    d.act = ops.ACT_SIGMOID
+    assert _lib.load().scf_conv2d(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)) < 0
+    d.act, d.out_c4 = ops.ACT_RELU, 0
+    assert _lib.load().scf_conv2d(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)) < 0

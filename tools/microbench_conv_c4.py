@@ -47,7 +47,6 @@ def timeit(fn, n=15):
 
 
 for name, cin, cout, k, pad, H, W, n in (('heads 3x3 128>512', 128, 512, (3, 3), (1, 1), 32, 32, 32),
-                                         ('corr_net.1 3x3 256>192', 256, 192, (3, 3), (1, 1), 32, 32, 32),
                                          ('gru 1x5 384>256', 384, 256, (1, 5), (0, 2), 32, 32, 32),
                                          ('gru 5x1 384>128', 384, 128, (5, 1), (2, 0), 32, 32, 32),
                                          ('enc l1 3x3 64>64 @128', 64, 64, (3, 3), (1, 1), 128, 128, 64)):
