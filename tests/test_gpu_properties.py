@@ -117,3 +117,27 @@ def test_repeated_launches_are_bit_identical():
     for _ in range(50):
         assert torch.equal(ops.corr_lookup(pyr, flow, 4, level0_tiled=True), want)
         assert torch.equal(ops.corr_build(f1, f2, 1, level0_tiled=True)[0], pyr[0])
+
+
+def test_launch_bound_timers_measure_the_kernel():
+    """scf_timer_* / ops.lookup_timing / ops.time_first_kernel: a timer bound to a launch reports a
+    positive duration no longer than a recorded-event pair around the same launch."""
+    f1, f2 = rnd((8, 256, 32, 32), 41), rnd((8, 256, 32, 32), 42)
+    flow = rnd((8, 2, 32, 32), 43, 2.0)
+    pyr = ops.corr_build(f1, f2, 4, level0_tiled=True)
+    out = ops.corr_lookup(pyr, flow, 4, level0_tiled=True)
+    ops.lookup_timing(True)
+    pairs = []
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        got = ops.corr_lookup(pyr, flow, 4, level0_tiled=True)
+        b.record()
+        pairs.append((a, b))
+    us = ops.lookup_timing(False)
+    assert torch.equal(got, out)                      # the timed entry point computes the same thing
+    assert len(us) == 5 and all(1.0 < u < 1e4 for u in us)
+    outer = [a.elapsed_time(b) * 1e3 for a, b in pairs]
+    assert min(us) <= min(outer) + 1.0
+    t = ops.time_first_kernel(lambda: ops.corr_build(f1, f2, 4, level0_tiled=True))
+    assert 1.0 < t < 1e5
