@@ -157,3 +157,49 @@ def test_pack_conv_weight_thin_layout_and_eligibility():
     assert ops.choose_a4_groups(224, 3, 3, 2) == 1
     assert ops.choose_a4_groups(324, 1, 1, 1) == 0 and ops.choose_a4_groups(3, 7, 7, 2) == 0
     assert ops.choose_a4_groups(2, 3, 3, 1) == 0
+
+
+# ------------------------------------------------------------ property tests (hypothesis)
+def test_shard_range_partitions_any_job():
+    from hypothesis import given, settings, strategies as st
+    from scflow_amd.dist import shard_range
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(0, 5000), st.integers(1, 64))
+    def check(total, world):
+        edges = [shard_range(total, r, world) for r in range(world)]
+        assert edges[0][0] == 0 and edges[-1][1] == total
+        for (a, b), (c, d) in zip(edges, edges[1:]):
+            assert b == c and a <= b
+        sizes = [b - a for a, b in edges]
+        assert max(sizes) - min(sizes) <= 1
+
+    check()
+
+
+def test_weight_packings_are_permutations_of_the_weights():
+    """every packing holds each weight exactly once (plus zero padding): same multiset of values."""
+    from hypothesis import given, settings, strategies as st
+    from scflow_amd import ops
+
+    @settings(max_examples=25, deadline=None)
+    @given(st.integers(1, 70), st.integers(8, 70), st.sampled_from([(3, 3), (1, 5), (5, 1), (1, 1)]),
+           st.integers(0, 2 ** 31 - 1))
+    def check(cout, cin, k, seed):
+        w = torch.randn((cout, cin, *k), generator=torch.Generator().manual_seed(seed))
+        ref = torch.sort(w.reshape(-1)).values
+        for kc in (2, 8, 32):
+            p, _ = ops.pack_conv_weight(w, kc)
+            nz = p.reshape(-1)
+            assert torch.equal(torch.sort(nz[nz != 0]).values, ref[ref != 0])
+        for g in (1, 2, 4):
+            for c4 in (False, True):
+                p, _ = ops.pack_conv_weight_a4(w, g, c4=c4)
+                assert torch.equal(torch.sort(p[p != 0]).values, ref[ref != 0])
+        h16 = ops.pack_conv_weight_f16x3(w).float()
+        hi, lo = h16[:, 0], h16[:, 1]
+        # hi + lo * 2^-11 reproduces every weight to ~22 bits
+        tot = float((hi + lo / 2048.0).abs().sum())
+        assert abs(tot - float(w.abs().sum())) <= 2e-6 * float(w.abs().sum()) + 1e-6
+
+    check()
