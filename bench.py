@@ -2,18 +2,29 @@
 """Benchmark of the SCFlow refinement hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W [--batch B]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+
+``--gpus N`` with N > 1 and no torchrun environment RE-LAUNCHES this script under
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`` (one
+rank per GPU, RCCL); under an existing torchrun environment (RANK / WORLD_SIZE set, the driver's
+way of starting it) it just joins.  It refuses (exit code 2) when fewer than N GPUs are visible or
+when WORLD_SIZE disagrees with --gpus: it never silently runs a different number of ranks.
 
 One *step* = one pass of the hot path over one batch per GPU: ``SCFlowRefiner.get_pose`` on B
 synthetic 256x256 image pairs, 8 GRU iterations, fp32, seeded random weights of the reference
 architecture (no dataset / checkpoint is reachable).  Inputs are resident in HBM before the
 timed region.  Metric (BASELINE.json): image pairs per second, whole job (all GPUs).
 
+Timing: W warm-up steps (and at least ``--min-warmup-seconds``), then BLOCKS of exactly K steps,
+each bracketed by barrier + synchronize on both sides and reduced with MAX over ranks, repeated
+until ``--min-seconds`` (default 3 s) of timed work have run; ``value`` / ``ms_per_step`` come
+from the MEDIAN block, ``spread`` carries min / max.
+
 Extra objects on the JSON line:
   roofline      corr-lookup kernel: algorithmic bytes per launch (2904 B/query) /
-                average launch duration measured live with HIP events on the launch stream
-                inside the timed steps, against the 8 TB/s HBM3E peak.
+                average launch duration measured live with HIP events bound to each launch on the
+                launch stream inside the timed steps, against the 8 TB/s HBM3E peak.
+  config4       BASELINE configs[4]: RAFTRefinerFlowMask, 480x640, 12 iterations, batch 8 -- the
+                lookup on a 933 MiB pyramid (larger than the 256 MiB Infinity Cache).
   cpu_baseline  the CPU oracle (oracle/, a port of the reference's torch path) timed on the
                 host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -22,6 +33,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,14 +42,66 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 MFMA_F32_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 LOOKUP_BYTES_PER_QUERY = 2904  # 4*(10*10*4) read + 8 flow + 4*(9*9*4) write
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='image pairs per GPU per step')
+    ap.add_argument('--iters', type=int, default=8)
+    ap.add_argument('--min-seconds', type=float, default=3.0,
+                    help='repeat blocks of --steps steps until this much timed work has run')
+    ap.add_argument('--min-warmup-seconds', type=float, default=1.0)
+    ap.add_argument('--precision', choices=['f32', 'f16x3'], default='f32',
+                    help='convolution arithmetic: exact fp32 MFMA, or split-fp16 3xMFMA '
+                         '(fp32 accumulate, ~22 mantissa bits; see DESIGN.md)')
+    ap.add_argument('--no-alt', action='store_true', help='skip the second timed loop in the other '
+                    'convolution precision')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-batch1', action='store_true')
+    ap.add_argument('--no-config4', action='store_true')
+    ap.add_argument('--standin', action='store_true',
+                    help='launcher self-test (tests/test_bench_launcher.py): the step is a CPU '
+                         'stand-in, backend gloo; the line is marked "standin": true and is not a '
+                         'measurement')
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------ launcher
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def maybe_self_launch(args) -> None:
+    """--gpus N > 1 outside a torchrun environment: start N ranks of this script (one per GPU)
+    and exit with the launcher's return code.  Mirrors what the reference does with
+    ``tools/dist_test.sh`` -> ``torch.distributed.launch`` -> test.py:100-127."""
+    if args.gpus <= 1 or 'WORLD_SIZE' in os.environ:
+        return
+    if not args.standin:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f'[bench] --gpus {args.gpus} but only {have} GPU(s) are visible: refusing to run '
+                  'a different number of ranks', file=sys.stderr)
+            sys.exit(2)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC only on this driver (RCCL)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    print(f'[bench] launching {args.gpus} ranks: {" ".join(cmd)}', file=sys.stderr)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+# ------------------------------------------------------------------ workload
 def build_model(iters: int, device: str):
     import scflow_amd
     shapes = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'state_dict_keys.json')))['shapes']
@@ -78,6 +143,7 @@ def host_cores() -> int:
 def cpu_baseline(sd, iters: int, pairs: int = 8, reps: int = 10, budget_s: float = 20.0):
     """the oracle on the host cores: bounded sample (<= ``reps`` passes over ``pairs`` pairs
     after one warm-up pair, stopped once ``budget_s`` seconds of CPU work are spent)."""
+    import torch
     import oracle
     import scflow_amd
     cores = host_cores()
@@ -94,123 +160,268 @@ def cpu_baseline(sd, iters: int, pairs: int = 8, reps: int = 10, budget_s: float
             done += 1
         dt = time.perf_counter() - t0
     return dict(value=round(pairs * done / dt, 3), unit='pairs/s', cores=cores, kind='port',
-                sample=f'{done} x oracle.get_pose on a batch of {pairs} synthetic 256x256 pairs, '
+                sample=f'{done} x oracle.get_pose on a batch of {pairs} synthetic 256x256 pairs '
+                       f'(the GPU line uses batches of 32: same per-pair work), '
                        f'{iters} iters, torch CPU fp32, {cores} threads (cgroup quota), after 1 '
                        f'warm-up pair ({dt:.1f} s timed)')
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=32, help='image pairs per GPU per step')
-    ap.add_argument('--iters', type=int, default=8)
-    ap.add_argument('--precision', choices=['f32', 'f16x3'], default='f32',
-                    help='convolution arithmetic: exact fp32 MFMA, or split-fp16 3xMFMA '
-                         '(fp32 accumulate, ~22 mantissa bits; see DESIGN.md)')
-    ap.add_argument('--no-alt', action='store_true', help='skip the second timed loop in the other '
-                    'convolution precision')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-batch1', action='store_true')
-    args = ap.parse_args()
+def _median(xs):
+    s = sorted(xs)
+    n = len(s)
+    return s[n // 2] if n % 2 else 0.5 * (s[n // 2 - 1] + s[n // 2])
 
+
+class BlockTimer:
+    """W warm-up steps, then blocks of exactly K steps (barrier + synchronize on both sides of
+    every block, MAX over ranks per block) until ``min_seconds`` of timed work."""
+
+    def __init__(self, step, fence, allmax, steps, warmup, min_seconds, min_warmup_seconds):
+        self.step, self.fence, self.allmax = step, fence, allmax
+        self.steps, self.warmup = steps, warmup
+        self.min_seconds, self.min_warmup_seconds = min_seconds, min_warmup_seconds
+
+    def run(self, before_block=None, after_block=None):
+        t0 = time.perf_counter()
+        done = 0
+        while done < self.warmup or (time.perf_counter() - t0) < self.min_warmup_seconds:
+            self.step()
+            done += 1
+            if done >= self.warmup and done % 4 == 0:
+                self.fence()                 # keep the host from running far ahead of the clock
+        self.fence()
+        blocks, total = [], 0.0
+        while True:
+            if before_block:
+                before_block()
+            self.fence()
+            t1 = time.perf_counter()
+            for _ in range(self.steps):
+                self.step()
+            self.fence()
+            el = self.allmax(time.perf_counter() - t1)
+            if after_block:
+                after_block()
+            blocks.append(el)
+            total += el
+            # every rank sees the same (all-reduced) totals, so they leave the loop together
+            if total >= self.min_seconds or len(blocks) >= 200:
+                break
+        return blocks, done
+
+
+def config4_block(device: str, reps_min_s: float = 2.0):
+    """BASELINE configs[4]: 480x640 crops, 12 iterations, batch 8 on the pose-free
+    RAFTRefinerFlowMask route (the SCFlow pose head is hard-wired to 256x256)."""
+    import torch
+    import scflow_amd
     from scflow_amd import ops
+    n, H, W, iters = 8, 480, 640, 12
+    h, w = H // 8, W // 8
+    m = scflow_amd.build_refiner(scflow_amd.raft_model_cfg(iters=iters))
+    sd = scflow_amd.fill_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed=9)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(device)
+    g = torch.Generator().manual_seed(3)
+    rend = torch.rand((n, 3, H, W), generator=g).to(device)
+    real = torch.rand((n, 3, H, W), generator=g).to(device)
+    for _ in range(2):
+        m.get_flow(rend, real)
+    torch.cuda.synchronize()
+    ops.lookup_timing(True, reserve=iters * 64)
+    t0 = time.perf_counter()
+    done = 0
+    while done < 3 or time.perf_counter() - t0 < reps_min_s:
+        m.get_flow(rend, real)
+        done += 1
+        if done % 4 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lk = ops.lookup_timing(False)
+    q = n * h * w
+    lk_us = sum(lk) / len(lk)
+    gbs = LOOKUP_BYTES_PER_QUERY * q / lk_us / 1e3
+    # correlation build alone at hw = 4800 (level-0 contraction, launch-bound timer)
+    fa = torch.randn((n, 256, h, w), device=device)
+    fb = torch.randn((n, 256, h, w), device=device)
+    lv0 = [torch.empty((n * h * w, 1, h, w), device=device)]
+    tiled = ops.tiled_level0_ok(h, w, 4)
+    for _ in range(2):
+        ops.corr_build(fa, fb, 1, out=lv0, level0_tiled=tiled)
+    cb = [ops.time_first_kernel(lambda: ops.corr_build(fa, fb, 1, out=lv0, level0_tiled=tiled))
+          for _ in range(5)]
+    cb_us = sum(cb) / len(cb)
+    cb_fl = 2.0 * 256 * (h * w) ** 2 * n
+    pyr_mib = sum(n * h * w * (h >> l) * (w >> l) * 4 for l in range(4)) / 2 ** 20
+    return {
+        'workload': 'BASELINE configs[4]: RAFTRefinerFlowMask.get_flow, batch=8 synthetic 480x640 '
+                    'pairs, 12 GRU iters, corr radius 4, 4 levels (pose-free route: the SCFlow pose '
+                    'head is hard-wired to 256x256)',
+        'value': round(n * done / dt, 2), 'unit': 'pairs/s', 'ms_per_step': round(dt / done * 1e3, 2),
+        'steps': done, 'pyramid_mib': round(pyr_mib, 1),
+        'roofline': {'kernel': 'corr_lookup_kernel', 'bound': 'hbm', 'achieved': round(gbs, 1),
+                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
+                     'avg_launch_us': round(lk_us, 2), 'launches_timed': len(lk),
+                     'algorithmic_bytes_per_launch': LOOKUP_BYTES_PER_QUERY * q, 'queries': q},
+        'roofline_corr_build': {'bound': 'mfma', 'achieved': round(cb_fl / cb_us / 1e6, 1),
+                                'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                'frac': round(cb_fl / cb_us / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
+                                'avg_launch_us': round(cb_us, 1), 'hw': h * w},
+    }
+
+
+# ------------------------------------------------------------------ main
+def main():
+    args = parse_args()
+    maybe_self_launch(args)
+
+    import torch
+    import torch.distributed as dist
     from scflow_amd.dist import gather_poses, init_from_env
-    ops.set_conv_precision(args.precision)
+
+    if args.standin:
+        os.environ.setdefault('SCF_DIST_BACKEND', 'gloo')
     rank, world, local = init_from_env()
     if world != args.gpus:
         if rank == 0:
-            print(f'[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using {world}',
-                  file=sys.stderr)
-    dev_index = local % torch.cuda.device_count()   # one process per GPU (torchrun LOCAL_RANK)
-    torch.cuda.set_device(dev_index)
-    device = f'cuda:{dev_index}'
+            print(f'[bench] WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a line '
+                  'for a different number of ranks', file=sys.stderr)
+        sys.exit(2)
 
-    model, sd = build_model(args.iters, device)
-    batch = make_batch(args.batch, seed=1000 + rank, device=device)
+    standin = args.standin
+    if standin:
+        device = 'cpu'
+        dev_name = 'cpu (stand-in)'
+    else:
+        from scflow_amd import ops
+        ops.set_conv_precision(args.precision)
+        ndev = torch.cuda.device_count()
+        if ndev < 1 or (world > 1 and ndev < world):
+            print(f'[bench] rank {rank}: {ndev} GPU(s) visible for {world} ranks', file=sys.stderr)
+            sys.exit(2)
+        dev_index = local            # one process per GPU (torchrun LOCAL_RANK)
+        torch.cuda.set_device(dev_index)
+        device = f'cuda:{dev_index}'
+        dev_name = torch.cuda.get_device_name(dev_index)
 
-    def step():
-        outs = run_step(model, batch)
-        rot, trans = outs[2][-1], outs[3][-1]
-        if world > 1:
-            rot, trans = gather_poses(rot, trans, args.batch * world)
-        return rot, trans
+    # rank -> device map, and the world size the collective backend itself reports
+    rank_map = [None] * world
+    coll_world = 1
+    if world > 1:
+        dist.all_gather_object(rank_map, {'rank': rank, 'local_rank': local, 'device': device,
+                                          'name': dev_name, 'pid': os.getpid()})
+        one = torch.ones(1, device=device)
+        parts = [torch.zeros(1, device=device) for _ in range(world)]
+        dist.all_gather(parts, one)
+        coll_world = int(sum(float(p.item()) for p in parts))
+    else:
+        rank_map = [{'rank': 0, 'local_rank': local, 'device': device, 'name': dev_name,
+                     'pid': os.getpid()}]
+
+    if standin:
+        model = sd = None
+        g = torch.Generator().manual_seed(rank)
+        a = torch.randn((args.batch, 64, 64), generator=g)
+
+        def step():
+            y = torch.bmm(a, a)
+            rot = y[:, :3, :3].contiguous()
+            trans = y[:, 0, :3].contiguous()
+            if world > 1:
+                rot, trans = gather_poses(rot, trans, args.batch * world)
+            return rot, trans
+    else:
+        model, sd = build_model(args.iters, device)
+        batch = make_batch(args.batch, seed=1000 + rank, device=device)
+
+        def step():
+            outs = run_step(model, batch)
+            rot, trans = outs[2][-1], outs[3][-1]
+            if world > 1:
+                rot, trans = gather_poses(rot, trans, args.batch * world)
+            return rot, trans
+
+    def sync():
+        if not standin:
+            torch.cuda.synchronize()
 
     def fence():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
+
+    def allmax(x: float) -> float:
+        if world > 1:
+            t = torch.tensor([x], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
 
     def timed(precision):
-        """W warm-up + K timed steps in one convolution precision -> (seconds, lookup us list)."""
+        """-> (block seconds list, lookup launch durations in us, warm-up steps done)"""
+        lookups = []
+        if standin:
+            bt = BlockTimer(step, fence, allmax, args.steps, args.warmup, args.min_seconds,
+                            args.min_warmup_seconds)
+            blocks, wdone = bt.run()
+            return blocks, lookups, wdone
         ops.set_conv_precision(precision)
-        for _ in range(args.warmup):
-            step()
-        fence()
-        ops.lookup_timing(True)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        el = time.perf_counter() - t0
-        lk = ops.lookup_timing(False)
-        if world > 1:
-            t = torch.tensor([el], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el, lk
+        ops.lookup_timing(True, reserve=args.steps * args.iters)   # timers created BEFORE the loop
+        bt = BlockTimer(step, fence, allmax, args.steps, args.warmup, args.min_seconds,
+                        args.min_warmup_seconds)
+        blocks, wdone = bt.run(before_block=ops.lookup_timing_reset,
+                               after_block=lambda: lookups.extend(ops.lookup_timing_read()))
+        ops.lookup_timing(False)
+        return blocks, lookups, wdone
 
-    dt, lookup_us = timed(args.precision)
-    # Secondary measurements: never allowed to take the headline line down with them.
-    conv_launches, cb_us, cb_ev = None, None, []
-    try:
-        # the kernels that dominate the step by TIME are the fp32 MFMA convolutions: one extra
-        # (untimed) step with every conv launch bracketed by events on its stream
-        ops.conv_timing(True)
-        step()
-        conv_launches = ops.conv_timing(False)
-        # north_star: MFMA utilisation of the correlation-volume build (dense fmap1 . fmap2^T).  The
-        # level-0 contraction alone (num_levels=1: no pooling cascade), same shapes as in the step.
-        fa = torch.randn((args.batch, 256, 32, 32), device=device)
-        fb = torch.randn((args.batch, 256, 32, 32), device=device)
-        lv0 = [torch.empty((args.batch * 1024, 1, 32, 32), device=device)]
-        for _ in range(3):
-            ops.corr_build(fa, fb, 1, out=lv0, level0_tiled=True)
-        cb_ev = [ops.time_first_kernel(lambda: ops.corr_build(fa, fb, 1, out=lv0, level0_tiled=True))
-                 for _ in range(10)]
-        cb_us = sum(cb_ev) / len(cb_ev)
-        del fa, fb, lv0
-    except Exception as exc:          # pragma: no cover - reported, not fatal
-        print(f'[bench] secondary measurement failed: {exc!r}', file=sys.stderr)
-    alt = None
-    if not args.no_alt:
-        other = 'f16x3' if args.precision == 'f32' else 'f32'
-        dt_alt, lk_alt = timed(other)
-        alt = {'precision': other,
-               'value': round(args.batch * world * args.steps / dt_alt, 2), 'unit': 'pairs/s',
-               'ms_per_step': round(dt_alt / args.steps * 1e3, 3),
-               'lookup_avg_launch_us': round(sum(lk_alt) / max(len(lk_alt), 1), 2),
-               'note': 'f16x3 = spatial convs with >=16 input channels as 3 fp16 MFMAs over an exact '
-                       'hi/lo split of both operands, fp32 accumulate (~22 mantissa bits); flow EPE vs '
-                       'the fp32 CPU oracle 7.6e-5 px over 8 iterations (tests/test_gpu_refiner.py), '
-                       'north-star tolerance 1e-3 px.  f32 = v_mfma_f32_32x32x2_f32 everywhere.'}
-        ops.set_conv_precision(args.precision)
+    blocks, lookup_us, warm_done = timed(args.precision)
+    dt = _median(blocks)
 
     result = None
+    conv_launches, cb_us, cb_ev = None, None, []
+    alt = None
+    if not standin:
+        # Secondary measurements: never allowed to take the headline line down with them.
+        try:
+            # the kernels that dominate the step by TIME are the fp32 MFMA convolutions: one extra
+            # (untimed) step with every conv launch bracketed by events on its stream
+            ops.conv_timing(True)
+            step()
+            conv_launches = ops.conv_timing(False)
+            # north_star: MFMA utilisation of the correlation-volume build (dense fmap1 . fmap2^T).
+            # The level-0 contraction alone, same shapes as in the step.
+            fa = torch.randn((args.batch, 256, 32, 32), device=device)
+            fb = torch.randn((args.batch, 256, 32, 32), device=device)
+            lv0 = [torch.empty((args.batch * 1024, 1, 32, 32), device=device)]
+            for _ in range(3):
+                ops.corr_build(fa, fb, 1, out=lv0, level0_tiled=True)
+            cb_ev = [ops.time_first_kernel(lambda: ops.corr_build(fa, fb, 1, out=lv0, level0_tiled=True))
+                     for _ in range(10)]
+            cb_us = sum(cb_ev) / len(cb_ev)
+            del fa, fb, lv0
+        except Exception as exc:          # pragma: no cover - reported, not fatal
+            print(f'[bench] secondary measurement failed: {exc!r}', file=sys.stderr)
+        if not args.no_alt:
+            other = 'f16x3' if args.precision == 'f32' else 'f32'
+            blocks_alt, lk_alt, _ = timed(other)
+            dt_alt = _median(blocks_alt)
+            alt = {'precision': other,
+                   'value': round(args.batch * world * args.steps / dt_alt, 2), 'unit': 'pairs/s',
+                   'ms_per_step': round(dt_alt / args.steps * 1e3, 3), 'blocks': len(blocks_alt),
+                   'lookup_avg_launch_us': round(sum(lk_alt) / max(len(lk_alt), 1), 2),
+                   'note': 'f16x3 = spatial convs with >=16 input channels as 3 fp16 MFMAs over an exact '
+                           'hi/lo split of both operands, fp32 accumulate (~22 mantissa bits); flow EPE vs '
+                           'the fp32 CPU oracle 7.6e-5 px over 8 iterations (tests/test_gpu_refiner.py), '
+                           'north-star tolerance 1e-3 px.  f32 = v_mfma_f32_32x32x2_f32 everywhere.'}
+            ops.set_conv_precision(args.precision)
+
     if rank == 0:
-        pmc = {}
-        pmc_path = os.path.join(ROOT, 'profiles', 'lookup_pmc.json')
-        if os.path.exists(pmc_path) and args.batch == 32:      # PMC passes are separate rocprofv3 runs
-            pmc = json.load(open(pmc_path))
-        pairs = args.batch * world * args.steps
-        q = args.batch * 32 * 32
-        avg_us = sum(lookup_us) / max(len(lookup_us), 1)
-        achieved = LOOKUP_BYTES_PER_QUERY * q / (avg_us * 1e-6) / 1e9 if lookup_us else None
+        pairs_per_block = args.batch * world * args.steps
         result = {
             'metric': 'image-pairs/sec at 256x256, 8 GRU iters',
-            'value': round(pairs / dt, 2), 'unit': 'pairs/s', 'n_gpus': world,
+            'value': round(pairs_per_block / dt, 2), 'unit': 'pairs/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
@@ -223,34 +434,56 @@ def main():
                        'batch_per_gpu': args.batch, 'global_batch': args.batch * world,
                        'height': 256, 'width': 256, 'iters': args.iters,
                        'parallelism': f'batch-split x{world}, no data-path collective'},
-            'roofline': {'kernel': 'corr_lookup_kernel<4, true, 32>', 'bound': 'hbm',
-                         'achieved': None if achieved is None else round(achieved, 1),
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': pmc.get('traffic_bytes_per_launch'),
-                         'traffic_source': pmc.get('source'),
-                         'avg_launch_us': round(avg_us, 2), 'launches_timed': len(lookup_us),
-                         'algorithmic_bytes_per_launch': LOOKUP_BYTES_PER_QUERY * q},
+            'timing': {'blocks': len(blocks), 'steps_per_block': args.steps,
+                       'timed_seconds': round(sum(blocks), 3), 'warmup_steps_run': warm_done,
+                       'ms_per_step_median': round(dt / args.steps * 1e3, 3),
+                       'ms_per_step_min': round(min(blocks) / args.steps * 1e3, 3),
+                       'ms_per_step_max': round(max(blocks) / args.steps * 1e3, 3),
+                       'note': 'value = median over blocks of exactly --steps steps (barrier + '
+                               'synchronize on both sides, max over ranks per block)'},
+            'ranks': rank_map, 'collective_world_size': coll_world,
         }
+        if standin:
+            result['standin'] = True
+            result['metric'] = 'LAUNCHER SELF-TEST (CPU stand-in step, not a measurement)'
+    if rank == 0 and not standin:
+        pmc = {}
+        pmc_path = os.path.join(ROOT, 'profiles', 'lookup_pmc.json')
+        if os.path.exists(pmc_path) and args.batch == 32:      # PMC passes are separate rocprofv3 runs
+            pmc = json.load(open(pmc_path))
+        q = args.batch * 32 * 32
+        avg_us = sum(lookup_us) / max(len(lookup_us), 1)
+        achieved = LOOKUP_BYTES_PER_QUERY * q / (avg_us * 1e-6) / 1e9 if lookup_us else None
+        result['roofline'] = {
+            'kernel': pmc.get('kernel', 'corr_lookup_kernel'), 'bound': 'hbm',
+            'achieved': None if achieved is None else round(achieved, 1),
+            'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
+            'traffic': pmc.get('traffic_bytes_per_launch'),
+            'traffic_source': pmc.get('source'),
+            'avg_launch_us': round(avg_us, 2), 'launches_timed': len(lookup_us),
+            'median_launch_us': round(_median(lookup_us), 2) if lookup_us else None,
+            'algorithmic_bytes_per_launch': LOOKUP_BYTES_PER_QUERY * q}
         rk = pmc.get('rocprof_kernel_trace')
         if rk:      # committed `rocprofv3 --kernel-trace --stats` pass of this command (profiles/)
             result['roofline']['rocprof_avg_launch_us'] = rk['avg_us']
             result['roofline']['note'] = (
                 'avg_launch_us: HIP start/stop events bound to each lookup launch of the timed steps '
-                '(hipExtLaunchKernel on the launch stream = the dispatch\'s own begin/end timestamps); '
+                '(hipExtLaunchKernel on the launch stream = the dispatch\'s own begin/end timestamps; '
+                'timers are created before the timed loop); '
                 f"the committed kernel trace of this command averages {rk['avg_us']} us = "
                 f"{LOOKUP_BYTES_PER_QUERY * q / rk['avg_us'] / 1e3 / HBM_PEAK_GBS:.3f} of peak")
         cb_fl = 2.0 * 256 * 1024 * 1024 * args.batch
         if cb_us:
-          result['roofline_corr_build'] = {
-            'kernel': 'conv_mfma_kernel<4, 1, 32> with per-sample weights (scf_corr_build level 0: '
-                      'fmap1 . fmap2^T / sqrt(C), 8x4-tiled store)', 'bound': 'mfma',
-            'achieved': round(cb_fl / (cb_us * 1e-6) / 1e12, 1), 'peak': MFMA_F32_PEAK_TFLOPS,
-            'unit': 'TFLOP/s', 'frac': round(cb_fl / (cb_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-            'avg_launch_us': round(cb_us, 1), 'launches_timed': len(cb_ev),
-            'algorithmic_flops_per_launch': cb_fl,
-            'note': f'2*C*(h*w)^2 flops per pair, C=256, h=w=32, {args.batch} pairs; the launch also '
-                    'writes the 4*(h*w)^2 B volume per pair'}
+            result['roofline_corr_build'] = {
+                'kernel': 'correlation build, level 0 (fmap1 . fmap2^T / sqrt(C), 8x4-tiled store)',
+                'bound': 'mfma',
+                'achieved': round(cb_fl / (cb_us * 1e-6) / 1e12, 1), 'peak': MFMA_F32_PEAK_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(cb_fl / (cb_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                'avg_launch_us': round(cb_us, 1), 'launches_timed': len(cb_ev),
+                'algorithmic_flops_per_launch': cb_fl,
+                'note': f'2*C*(h*w)^2 flops per pair, C=256, h=w=32, {args.batch} pairs; the launch also '
+                        'writes the 4*(h*w)^2 B volume per pair'}
         if conv_launches:
             c_us = sum(u for u, _ in conv_launches)
             c_fl = sum(f for _, f in conv_launches)
@@ -266,7 +499,7 @@ def main():
                         'flops = 2*Cin*KH*KW*Cout*Ho*Wo*N per launch; HIP start/stop events bound to each launch'}
 
     # ---- config[1]: single pair latency (rank 0, informational) ----
-    if rank == 0 and world == 1 and not args.no_batch1:
+    if rank == 0 and world == 1 and not standin and not args.no_batch1:
         try:
             from scflow_amd.graph import GraphedRefiner
             b1 = make_batch(1, seed=5, device=device)
@@ -293,12 +526,20 @@ def main():
                                 'ms_per_pair_hipgraph': round(ms, 3),
                                 'pairs_per_s_hipgraph': round(1e3 / ms, 2),
                                 'ms_per_pair_eager': round(ms_eager, 3)}
+            del graphed
         except Exception as exc:      # pragma: no cover - informational block, never fatal
             print(f'[bench] batch-1 block failed: {exc!r}', file=sys.stderr)
 
+    if rank == 0 and world == 1 and not standin and not args.no_config4:
+        try:
+            ops.set_conv_precision(args.precision)
+            result['config4'] = config4_block(device)
+        except Exception as exc:      # pragma: no cover
+            print(f'[bench] config4 block failed: {exc!r}', file=sys.stderr)
+
     if rank == 0 and alt is not None:
         result['alt_precision'] = alt
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not standin and not args.no_cpu_baseline:
         try:
             result['cpu_baseline'] = cpu_baseline(sd, args.iters)
         except Exception as exc:      # pragma: no cover

@@ -143,15 +143,52 @@ typedef struct scf_conv_desc {
   const float* wp_thin;                 /* optional third packing for Cout <= 4 layers (vector-ALU
                                            kernel): [Cin][KH*KW][CO] floats, CO = 1, 2 or 4 (Cout
                                            rounded up), zero padded                                */
-  int32_t in_c4, out_c4;                /* EXPERIMENTAL (measurement only):
-                                           input / output stored channel-interleaved
-                                           [N][C/4][H][W][4]; in_c4 needs wp_a4 packed for it     */
   int32_t out_tile8x4;                  /* 1: store every output plane in 8(x) x 4(y)-float tiles
                                            of 128 B (tile-major, row-major inside) instead of
                                            row-major; needs Wo % 8 == 0 and Ho % 4 == 0          */
 } scf_conv_desc;
 
 int scf_conv2d(const scf_conv_desc* desc, scf_stream_t stream);
+
+/* Host-side weight packers (plain CPU loops, run once per checkpoint): w is a HOST pointer to a
+ * contiguous (Cout, Cin, KH, KW) fp32 tensor -- a torch Conv2d weight as stored in the reference's
+ * state_dict -- and out a HOST buffer of scf_pack_conv_weight*_size() floats; copy the result
+ * to the device and pass it as scf_conv_desc.wp (+ KC, Mld = Cout rounded up to 32) or
+ * scf_conv_desc.wp_a4 (+ a4_groups, a4_mld = Cout rounded up to 32).
+ *   KC packing : out[((chunk*T + t)*KC + cl)*Mld + co] = w[co][chunk*KC + cl][t], zeros elsewhere
+ *   a4 packing : out[((((chunk*T + t)*G + g)*2 + h)*Mld + co)*4 + s] = w[co][chunk*8G + 8g + 2s + h][t] */
+int64_t scf_pack_conv_weight_size(int Cout, int Cin, int KH, int KW, int KC);
+int scf_pack_conv_weight(const float* w, int Cout, int Cin, int KH, int KW, int KC, float* out);
+int64_t scf_pack_conv_weight_a4_size(int Cout, int Cin, int KH, int KW, int groups);
+int scf_pack_conv_weight_a4(const float* w, int Cout, int Cin, int KH, int KW, int groups, float* out);
+
+/* ---------------------------------------------------------------------------------
+ * Convolutional GRU update, whole cell.     replaces ConvGRU.forward
+ *                                           models/decoder/raft_decoder.py:235-253
+ * hx = [h (Ch channels) | x (Cx channels)] of one sample-strided NCHW buffer; for every pass
+ * (SeqConv: a (1,5) then a (5,1) convolution triple, :180-181; Conv: one 3x3 triple)
+ *     z = sigmoid(conv_z(hx)),  r = sigmoid(conv_r(hx)),  q = tanh(conv_q([r*h | x])),
+ *     h <- (1 - z)*h + z*q                                              (in place in hx)
+ * as two launches: one 2*Ch-row convolution whose epilogue emits z and r*h, one Ch-row
+ * convolution whose epilogue applies tanh and the state update.  z and rh are caller-provided
+ * dense (N, Ch, H, W) scratch buffers.
+ * Weights per pass, DEVICE pointers in the packings above:
+ *   wp_zr : KC = 8 packing of the (2*Ch, Ch+Cx, KH, KW) tensor cat([conv_z.weight, conv_r.weight], 0)
+ *   wp_q  : KC = 8 packing of conv_q.weight (Ch, Ch+Cx, KH, KW);  bias_zr [2*Ch], bias_q [Ch]
+ *   wp_*_a4 (+ a4_groups: 2 for (1,5)/(5,1), 1 for 3x3) select the LDS-DMA kernel (optional, faster)
+ *   wp_*_f16 select the split-fp16 3xMFMA kernel (optional, see scf_conv_desc.wp_f16)
+ * --------------------------------------------------------------------------------- */
+typedef struct scf_gru_pass {
+  int32_t KH, KW, pad_h, pad_w;
+  const float* wp_zr; const float* bias_zr;
+  const float* wp_q; const float* bias_q;
+  const float* wp_zr_a4; const float* wp_q_a4; int32_t a4_groups;
+  const void* wp_zr_f16; const void* wp_q_f16;
+} scf_gru_pass;
+
+int scf_sepconv_gru(float* hx, int64_t hx_nstride, int N, int Ch, int Cx, int H, int W,
+                    const scf_gru_pass* passes, int npass, float* z, float* rh,
+                    scf_stream_t stream);
 /* dry run of scf_conv2d's tile selection: info[4] = {WM, WN, grid blocks, MFMAs per wave per
  * staged chunk}; SCF_EUNSUPPORTED when the packing's KC does not fit this shape.         */
 int scf_conv2d_query(const scf_conv_desc* desc, int32_t* info);
@@ -180,6 +217,8 @@ int scf_linear(const float* x, const float* W, const float* b, float* y, int N, 
  * label_mode 0 reproduces the reference (every sample uses class label[0]);
  * label_mode 1 uses label[n].   Outputs: d_rot (N,6), d_trans (N,3), R_out (N,3,3),
  * t_out (N,3).  R_out/t_out may alias R_in/t_in.
+ * A label outside [0, num_class) is CLAMPED (a kernel cannot raise; the reference's index_select
+ * does): validate labels on the host (SCFlowRefiner.forward_single_pass does).
  * --------------------------------------------------------------------------------- */
 int scf_pose_update(const float* rot_all, const float* trans_all, const int64_t* label,
                     int num_class, int label_mode, const float* R_in, const float* t_in,

@@ -18,6 +18,6 @@ from .refiner import RAFTRefinerFlow, RAFTRefinerFlowMask, SCFlowRefiner  # noqa
 from .metrics import (cal_epe, eval_pose_error, eval_rot_error,  # noqa: F401
                       eval_tran_error, filter_flow_by_mask,
                       get_flow_from_delta_pose_and_depth)
-from .config import scflow_model_cfg  # noqa: F401
+from .config import raft_model_cfg, scflow_model_cfg  # noqa: F401
 from .weights import fill_state_dict  # noqa: F401
 from .synthetic import make_inputs  # noqa: F401

@@ -44,9 +44,17 @@ class ConvDesc(C.Structure):
         ('a4_groups', C.c_int32),
         ('a4_mld', C.c_int32),
         ('wp_thin', _fp),
-        ('in_c4', C.c_int32),
-        ('out_c4', C.c_int32),
         ('out_tile8x4', C.c_int32),
+    ]
+
+
+class GruPass(C.Structure):
+    """mirror of ``scf_gru_pass`` (include/scflow_hip.h)."""
+    _fields_ = [
+        ('KH', C.c_int32), ('KW', C.c_int32), ('pad_h', C.c_int32), ('pad_w', C.c_int32),
+        ('wp_zr', _fp), ('bias_zr', _fp), ('wp_q', _fp), ('bias_q', _fp),
+        ('wp_zr_a4', _fp), ('wp_q_a4', _fp), ('a4_groups', C.c_int32),
+        ('wp_zr_f16', _fp), ('wp_q_f16', _fp),
     ]
 
 
@@ -73,6 +81,12 @@ SIGNATURES = {
                                         C.c_int, C.c_int, _fp, _fp]),
     'scf_conv2d': (C.c_int, [C.POINTER(ConvDesc), _fp]),
     'scf_conv2d_query': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int32)]),
+    'scf_pack_conv_weight_size': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'scf_pack_conv_weight': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'scf_pack_conv_weight_a4_size': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    'scf_pack_conv_weight_a4': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'scf_sepconv_gru': (C.c_int, [_fp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.POINTER(GruPass), C.c_int, _fp, _fp, _fp]),
     'scf_instance_norm': (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int, C.c_float, C.c_int, _fp]),
     'scf_group_norm_relu': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_float, _fp]),

@@ -21,6 +21,49 @@ extern "C" int scf_device_count(void) {
 }
 
 
+// ---- host-side weight packers (plain CPU loops; layouts documented in include/scflow_hip.h) ----
+extern "C" int64_t scf_pack_conv_weight_size(int Cout, int Cin, int KH, int KW, int KC) {
+  if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || (KC != 2 && KC != 8 && KC != 32)) return SCF_EINVAL;
+  const int64_t nchunk = (Cin + KC - 1) / KC, mld = (Cout + 31) / 32 * 32;
+  return nchunk * KH * KW * KC * mld;
+}
+
+extern "C" int scf_pack_conv_weight(const float* w, int Cout, int Cin, int KH, int KW, int KC, float* out) {
+  const int64_t total = scf_pack_conv_weight_size(Cout, Cin, KH, KW, KC);
+  if (!w || !out || total < 0) return SCF_EINVAL;
+  const int T = KH * KW;
+  const int64_t mld = (Cout + 31) / 32 * 32;
+  for (int64_t i = 0; i < total; ++i) out[i] = 0.f;
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int t = 0; t < T; ++t) {
+        const int64_t chunk = ci / KC, cl = ci % KC;
+        out[((chunk * T + t) * KC + cl) * mld + co] = w[((int64_t)co * Cin + ci) * T + t];
+      }
+  return SCF_OK;
+}
+
+extern "C" int64_t scf_pack_conv_weight_a4_size(int Cout, int Cin, int KH, int KW, int groups) {
+  if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || (groups != 1 && groups != 2 && groups != 4)) return SCF_EINVAL;
+  const int64_t kc = 8 * groups, nchunk = (Cin + kc - 1) / kc, mld = (Cout + 31) / 32 * 32;
+  return nchunk * KH * KW * groups * 2 * mld * 4;
+}
+
+extern "C" int scf_pack_conv_weight_a4(const float* w, int Cout, int Cin, int KH, int KW, int groups, float* out) {
+  const int64_t total = scf_pack_conv_weight_a4_size(Cout, Cin, KH, KW, groups);
+  if (!w || !out || total < 0) return SCF_EINVAL;
+  const int T = KH * KW, kc = 8 * groups;
+  const int64_t mld = (Cout + 31) / 32 * 32;
+  for (int64_t i = 0; i < total; ++i) out[i] = 0.f;
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int t = 0; t < T; ++t) {
+        const int64_t chunk = ci / kc, r = ci % kc, g = r / 8, r8 = r % 8, s = r8 / 2, h = r8 % 2;
+        out[((((chunk * T + t) * groups + g) * 2 + h) * mld + co) * 4 + s] = w[((int64_t)co * Cin + ci) * T + t];
+      }
+  return SCF_OK;
+}
+
 // ---- launch-bound timers (measurement aid, see scf_common.h) ----
 ScfTimer*& scf_armed_timer() {
   static thread_local ScfTimer* slot = nullptr;

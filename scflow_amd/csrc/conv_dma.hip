@@ -16,6 +16,7 @@
 // Zero padding: the patch areas are zero-filled once per block and out-of-image positions are
 // never written afterwards (the gather table is chunk-invariant).
 #include "scf_common.h"
+#include <atomic>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -78,9 +79,7 @@ __device__ __forceinline__ int fast_div(int e, int d, float rd) {
   return q;
 }
 
-// C4 (experimental): the input is stored [N][C/4][H][W][4]; LDS cell (g, h) is then global cell
-// 2g + h of the chunk (channels 8g + 4h + s) and the patch is staged with dwordx4 DMA.
-template <int WM, int WN, bool C4 = false>
+template <int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BM = WM * 32;
@@ -135,15 +134,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
     const int e = tid + u * 256;
     bool ok = false;
     unsigned o = 0;
-    if (C4) {                          // e = float4 cell index: (gh, py, px)
-      if (u * 256 * 4 < PE) {
-        const int gh = fast_div(e, PHW, rPHW), r = e - gh * PHW;
-        const int py = fast_div(r, PW, rPW), px = r - py * PW;
-        const int iy = iy0 + py, ix = ix0 + px;
-        ok = e * 4 < PE && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        o = (unsigned)((gh * p.H + iy) * p.W + ix) * 16u;
-      }
-    } else if (u * 256 < PE) {
+    if (u * 256 < PE) {
       const int s = e & 3, q = e >> 2;
       const int gh = fast_div(q, PHW, rPHW), r = q - gh * PHW;
       const int py = fast_div(r, PW, rPW), pxs = r - py * PW;
@@ -195,13 +186,9 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
     // site counts re-materialised per call (one s_cmp per site): left to itself hipcc hoists the
     // 27 loop-invariant guards out of the chunk loop as 64-bit masks, spills them, and reloads
     // each with two v_readlane -- VALU slots the co-resident wave's MFMA stream leaves scarce
-    int npu = C4 ? (PE / 4 + 255) >> 8 : (PE + 255) >> 8, nwu = (WF4 + 255) >> 8;
+    int npu = (PE + 255) >> 8, nwu = (WF4 + 255) >> 8;
     asm volatile("" : "+s"(npu), "+s"(nwu));
-    if (C4) {                          // dwordx4 per cell; channel tails not supported here
-#pragma unroll
-      for (int u = 0; u < PU; ++u)
-        if (u < npu) dma_b128_v(base, toff[u], lds_addr(pb + (u * 256 + wave * 64) * 4));
-    } else if (nvalid >= KC) {         // chunk-invariant masks apply
+    if (nvalid >= KC) {                // chunk-invariant masks apply
 #pragma unroll
       for (int u = 0; u < PU; ++u)
         if (u < npu) dma_b32_v(base, toff[u], lds_addr(pb + u * 256 + wave * 64));
@@ -284,18 +271,21 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   scf_conv_epilogue_tile<WM, WN>(p, epi, acc, m0, half, pix, use_div);
 }
 
-template <int WM, int WN, bool C4 = false>
+template <int WM, int WN>
 static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
-  if (lds_bytes > 64 * 1024) {       // opt in to > 64 KiB of dynamic LDS once per instantiation
-    static bool raised = false;
-    if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WM, WN, C4>),
+  if (lds_bytes > 64 * 1024) {       // opt in to > 64 KiB of dynamic LDS: once per instantiation AND device
+    static std::atomic<unsigned long long> raised{0};      // bit d: done on device d
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return SCF_ELAUNCH;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(raised.load(std::memory_order_relaxed) & bit)) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WM, WN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, SCF_DMA_LDS_MAX) != hipSuccess)
         return SCF_ELAUNCH;
-      raised = true;
+      raised.fetch_or(bit, std::memory_order_relaxed);
     }
   }
-  scf_launch((conv_dma_kernel<WM, WN, C4>), dim3(nblk), dim3(256), lds_bytes, st, k);
+  scf_launch((conv_dma_kernel<WM, WN>), dim3(nblk), dim3(256), lds_bytes, st, k);
   return scf_launch_status();
 }
 
@@ -347,12 +337,6 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   k.nchunk = (k.Cin + KC - 1) / KC;
   if (info) { info[0] = WM; info[1] = WN; info[2] = (int)best_blk; info[3] = k.T * G * 4 * WM * WN; }
   if (dry_run) return SCF_OK;
-  if (k.in_c4) {                       // experimental layout: two tile shapes only
-    if (k.stride != 1 || (k.Cin % KC) != 0 || (k.C0 % KC) != 0) return SCF_EUNSUPPORTED;
-    if (WM == 2 && WN == 2) return launch_dma<2, 2, true>(k, (int)best_blk, best_lds, st);
-    if (WM == 2 && WN == 1) return launch_dma<2, 1, true>(k, (int)best_blk, best_lds, st);
-    return SCF_EUNSUPPORTED;
-  }
 #define SCF_CASE(M, Nn) if (WM == M && WN == Nn) return launch_dma<M, Nn>(k, (int)best_blk, best_lds, st);
   SCF_CASE(2, 2) SCF_CASE(3, 1) SCF_CASE(2, 1) SCF_CASE(1, 1)
 #undef SCF_CASE

@@ -16,7 +16,6 @@ struct ConvK {
   int fc_log2, tiles_x, tiles_y, mblocks, PH, PW, PWin;
   int wvec;
   int out_tile;              // 1: 8x4-float tiled output planes (correlation level 0)
-  int in_c4, out_c4;         // experimental NC/4HW4 activations (conv_dma.hip only)
   int ksplit;                // 32-pixel tile, the 4 waves split the k-steps (small grids)
   float* out; long long out_ns;
   const float* bias; const float* scale; const float* shift;
@@ -113,7 +112,8 @@ __device__ __forceinline__ void scf_epi_affine_group(const ConvK& p, const ConvE
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] += r[q];
   }
-  // ReLU as compare+select (keeps NaN, like the reference); per-row choice under act_split
+  // ReLU as compare+select: a NaN accumulator becomes 0 (the reference's F.relu would propagate
+  // it; activations are finite by construction).  Per-row choice under act_split
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int a = (p.act_split > 0 && cb + q >= p.act_split) ? p.act2 : p.act;
@@ -262,26 +262,6 @@ __device__ __forceinline__ void scf_conv_epilogue_tile(const ConvK& p, const Con
         bv[i][g] = p.bias ? *reinterpret_cast<const scf_f32x4*>(p.bias + m0 + i * 32 + 8 * g + 4 * half)
                           : scf_f32x4{0.f, 0.f, 0.f, 0.f};
     const bool relu = p.act == SCF_ACT_RELU;
-    if (p.out_c4) {                      // experimental: one float4 (4 consecutive channels) per store
-#pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        if (pix[j] < 0) continue;
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            scf_f32x4 v;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              float x = acc[i][j][4 * g + q] + bv[i][g][q];
-              v[q] = relu ? (x > 0.f ? x : 0.f) : x;
-            }
-            const int cell = (m0 + i * 32 + 8 * g + 4 * half) >> 2;
-            *reinterpret_cast<scf_f32x4*>(e.out + ((size_t)cell * e.HWo + pix[j]) * 4) = v;
-          }
-      }
-      return;
-    }
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       if (pix[j] < 0) continue;

@@ -422,7 +422,6 @@ static int conv_plan(const scf_conv_desc* d, ConvPlan* plan) {
   if (k.Ho <= 0 || k.Wo <= 0) return SCF_EINVAL;
   k.wp = d->wp; k.w_ns = d->w_nstride; k.Mld = d->Mld; k.Cout = d->Cout;
   k.wp16 = d->wp_f16;
-  k.in_c4 = d->in_c4; k.out_c4 = d->out_c4;
   k.wthin = d->wp_thin;
   k.wp4 = d->wp_a4; k.G4 = d->a4_groups; k.Mld4 = d->a4_mld;
   k.out_tile = d->out_tile8x4;
@@ -524,25 +523,14 @@ static bool want_f16x3(const scf_conv_desc* d) {
   return d->wp_f16 != nullptr && !d->out_tile8x4 && d->w_nstride == 0 && d->KH * d->KW > 1 && d->C0 + d->C1 >= 16;
 }
 
-static bool want_dma(const scf_conv_desc* d) {
-  static const bool off = [] { const char* e = getenv("SCF_CONV_DMA"); return e && e[0] == '0'; }();   // A/B knob
-  return !off && d->wp_a4 != nullptr && (d->stride == 1 || d->stride == 2) && d->w_nstride == 0 && d->a4_mld >= d->Cout;
+static bool want_dma(const scf_conv_desc* d) {      // a layer opts in by carrying the LDS-DMA packing
+  return d->wp_a4 != nullptr && (d->stride == 1 || d->stride == 2) && d->w_nstride == 0 && d->a4_mld >= d->Cout;
 }
 
 extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
   ConvPlan pl;
   const int rc = conv_plan(d, &pl);
   if (rc != SCF_OK) return rc;
-  if (d->in_c4 || d->out_c4) {
-    // experimental channel-interleaved activations: only the LDS-DMA kernel with the bias / ReLU
-    // epilogue understands them -- never fall through to a kernel that would misread the layout
-    const bool plain = d->mode == SCF_CONV_PLAIN && !d->res && !d->scale && d->act_split <= 0 &&
-                       (d->act == SCF_ACT_NONE || d->act == SCF_ACT_RELU) &&
-                       (d->out_div == 0.f || d->out_div == 1.f) && !d->out_tile8x4;
-    if (!(d->in_c4 && d->out_c4) || !plain || !want_dma(d) || (d->Cout % 64) != 0 || ((d->C0 + d->C1) % 4) != 0)
-      return SCF_EUNSUPPORTED;
-    return scf_conv_dma_dispatch(pl.k, d->N, false, nullptr, scf_stream(stream));
-  }
   {
     const int rt = scf_conv_thin_dispatch(pl.k, d->N, false, scf_stream(stream));
     if (rt != SCF_EUNSUPPORTED) return rt;
@@ -570,6 +558,50 @@ extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
   SCF_CASE(3, 1) SCF_CASE(4, 1)
 #undef SCF_CASE
   return SCF_EUNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------
+// ConvGRU.forward (raft_decoder.py:235-253) as one entry point: per pass the fused z|r
+// convolution (epilogue: z -> z buffer, r*h -> rh buffer) and the q convolution (epilogue:
+// tanh + state update in place).
+// ---------------------------------------------------------------------------------
+extern "C" int scf_sepconv_gru(float* hx, int64_t hx_nstride, int N, int Ch, int Cx, int H, int W,
+                               const scf_gru_pass* passes, int npass, float* z, float* rh,
+                               scf_stream_t stream) {
+  if (!hx || !passes || !z || !rh || N <= 0 || Ch <= 0 || Cx <= 0 || H <= 0 || W <= 0 || npass <= 0)
+    return SCF_EINVAL;
+  if (Ch % 8 != 0) return SCF_EUNSUPPORTED;      // the h | x boundary must not split a channel chunk
+  const int64_t hw = (int64_t)H * W;
+  for (int i = 0; i < npass; ++i) {
+    const scf_gru_pass& g = passes[i];
+    if (!g.wp_zr || !g.wp_q || g.KH <= 0 || g.KW <= 0) return SCF_EINVAL;
+    if (2 * g.pad_h != g.KH - 1 || 2 * g.pad_w != g.KW - 1) return SCF_EUNSUPPORTED;   // 'same' convolutions
+    scf_conv_desc d = {};
+    d.N = N; d.H = H; d.W = W;
+    d.KH = g.KH; d.KW = g.KW; d.stride = 1; d.pad_h = g.pad_h; d.pad_w = g.pad_w; d.KC = 8;
+    d.out_div = 1.f;
+    // z | r = sigmoid(conv([h | x])): z -> z, r*h -> rh
+    d.in0 = hx; d.C0 = Ch + Cx; d.in0_nstride = hx_nstride;
+    d.wp = g.wp_zr; d.Mld = (2 * Ch + 31) / 32 * 32; d.Cout = 2 * Ch; d.bias = g.bias_zr;
+    d.wp_a4 = g.wp_zr_a4; d.a4_groups = g.a4_groups; d.a4_mld = d.Mld; d.wp_f16 = g.wp_zr_f16;
+    d.out = z; d.out_nstride = Ch * hw;
+    d.mode = SCF_CONV_GRU_ZR; d.gru_h = hx; d.gru_h_nstride = hx_nstride;
+    d.gru_aux = rh; d.gru_aux_nstride = Ch * hw;
+    int rc = scf_conv2d(&d, stream);
+    if (rc != SCF_OK) return rc;
+    // q = tanh(conv([r*h | x])); h <- (1 - z) h + z q
+    d.in0 = rh; d.C0 = Ch; d.in0_nstride = Ch * hw;
+    d.in1 = hx + (int64_t)Ch * hw; d.C1 = Cx; d.in1_nstride = hx_nstride;
+    d.wp = g.wp_q; d.Mld = (Ch + 31) / 32 * 32; d.Cout = Ch; d.bias = g.bias_q;
+    d.wp_a4 = g.wp_q_a4; d.a4_mld = d.Mld; d.wp_f16 = g.wp_q_f16;
+    d.out = hx; d.out_nstride = hx_nstride;
+    d.mode = SCF_CONV_GRU_Q; d.gru_h = hx; d.gru_h_nstride = hx_nstride;
+    d.gru_aux = nullptr; d.gru_aux_nstride = 0;
+    d.gru_z = z; d.gru_z_nstride = Ch * hw;
+    rc = scf_conv2d(&d, stream);
+    if (rc != SCF_OK) return rc;
+  }
+  return SCF_OK;
 }
 
 // Dry run of the tile selection for a descriptor: info[0..3] = WM, WN, grid blocks, MFMA

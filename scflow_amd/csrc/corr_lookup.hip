@@ -1,4 +1,4 @@
-// Multi-scale correlation lookup (RAFT/SCFlow "CorrLookup") for gfx950.
+// Multi-scale correlation lookup (RAFT/SCFlow "CorrLookup") for gfx950 -- v7.
 //
 // Reference semantics: models/utils/corr_lookup.py:102-136 (+ bilinear_sample :31-67).
 //
@@ -7,21 +7,40 @@
 // (2r+1)^2 outputs (324 B); no byte is shared between queries, so the algorithmic
 // traffic is 4*(400+324)+8 = 2904 B/query.
 //
-// Work decomposition (wave64):
-//   block = 256 threads = 4 waves handling the same 32 consecutive queries;
-//   wave w owns pyramid level w (levels w, w+4, ... when L > 4).
-//   load phase : per query, the wave's 64 lanes fetch the (2r+2)^2 footprint elements in
-//                element order with global_load_lds (memory -> LDS, no VGPR staging, so all
-//                64 gathers of a wave are in flight at once); exactly the algorithmic bytes
-//                are requested; each query's window lands contiguously in LDS at an ODD
-//                per-query stride (bank-conflict free for the transposed read that follows);
-//                out-of-map taps: the staging area is zero-filled first and their lanes are
-//                switched off (zero padding without fetching anything).
-//   compute    : lane = (query, half); the two half-waves split the x-offsets; bilinear
-//                weights are per (query, level) constants because offsets are integers.
-//   store      : out[n, k, y, x]; each half-wave writes 32 consecutive queries of one
-//                channel = one full 128-B line.
+// What bounded v5 (round 1) was not memory but its own instruction stream: with gathers AND
+// stores removed it still ran 11.6 us at batch 32 (tools/lab/lookup_lab.hip) -- a branchy loop
+// with ~45 issue slots and 13 address VALU per (query, DMA), three v_readlane per query.  Two
+// lessons from the lab shape v7:
+//   * ONE DMA instruction must cover whole cache lines' worth of one query's window (lane =
+//     footprint element of ONE query).  A row-of-six-queries mapping (v6) needs a third of the
+//     instructions but asks the L1/L2 for every 128-byte line four times (once per window row)
+//     and lost 2-3 us on the request path.
+//   * the end-of-kernel write-back of the XCD L2s (up to 32 MB of dirty output lines) is part of
+//     the kernel's duration: write-through (sc1) stores drain during the kernel instead (-2 us).
+//
+//   block = 4 waves x the same 32 consecutive queries ("group"); a wave owns one pyramid level
+//   (levels w, w+4, ... when L > 4); blocks are persistent over groups.
+//   tables  : per level the query lanes (lane = query, the two half-waves split rows / columns)
+//             write a 20-entry u16 table per query to LDS: the offset (in floats) of each window
+//             row and of each window column inside the query's map, 0x8000 when outside it.
+//             This is where the layout lives (row-major, or 8x4-float tiles for level 0).
+//   gather  : lane = footprint element e = (row, col) of ONE query, two DMA instructions per
+//             query.  Per DMA: two ds_read_u16 with IMMEDIATE offsets (the query loop is
+//             unrolled), v_add_lshl (row + col -> byte offset), v_cmp (any 0x8000 -> lane off),
+//             the rest scalar.  Straight-line inline asm: no branches, no v_readlane.
+//             Zero padding = zero-filled staging + switched-off lanes: only in-map bytes move.
+//   small   : a level whose whole map fits in the footprint is staged whole (one DMA per query
+//             and 64 map elements); out-of-map rows are redirected to a shared zero row at
+//             read-back, out-of-map columns are clamped and lose their weights.
+//   emit    : lane = (query, half); per-lane row addresses + immediate column offsets for both
+//             layouts; bilinear weights are per (query, level) constants; each half-wave
+//             writes 32 consecutive queries of one channel = one full 128-B line, write-through.
 #include "scf_common.h"
+#include <type_traits>
+
+#ifndef SCF_LOOKUP_STORE_MODE
+#define SCF_LOOKUP_STORE_MODE 2      // sc1 = write-through, see lk_store
+#endif
 
 struct LookupParams {
   const float* lvl[SCF_MAX_LEVELS];
@@ -30,231 +49,370 @@ struct LookupParams {
   const float* flow;
   float* out;
   int N, h, w, L;
-  int woff[4];            // LDS offset (floats) of each wave's staging region
+  int woff[4];            // LDS offset (floats) of each wave slot's staging region
   int l0_tiled;           // level 0 stored in 8x4-float tiles (scf_corr_build_ex)
+  int ngroups;            // ceil(total_q / 32)
   long long total_q;
+#ifdef SCF_LOOKUP_TRACE
+  unsigned long long* trace;   // [groups][4 waves][8] s_memrealtime stamps (tools/lab/lookup_lab.hip)
+  int skip_dma, skip_store;    // ablations
+#endif
 };
 
-// window read-back + bilinear blend + store for one (wave, level).  SMALL: the level's whole
-// map is staged (stride S) and out-of-map taps are masked here; otherwise the zero-padded
-// (2r+2)^2 footprint is staged and read unmasked.
-template <int R, bool SMALL, int NP>
-__device__ __forceinline__ void lookup_emit(const float* f, int lw, int lh, int x0, int y0,
-                                            bool flat_x, bool flat_y, float nw, float ne, float sw,
-                                            float se, int part, char* obase, unsigned lane_off,
-                                            size_t cs, bool qvalid) {
-  constexpr int FW = 2 * R + 2, D = 2 * R + 1;
-  // The NP lane groups of a wave (64 / NP queries each) split the D x-offsets: group g takes
-  // columns [i0(g), i0(g+1)), i0(g) = ceil(g*D / NP).  The loop itself is wave-uniform (NI =
-  // the largest share; shorter shares are masked) so that store bases stay in SGPRs and only a
-  // 32-bit per-lane offset goes into the address VGPR.
+#ifdef SCF_LOOKUP_TRACE
+#define SCF_TRACE(slot)                                                                          \
+  do {                                                                                           \
+    if (p.trace && (threadIdx.x & 63) == 0)                                                      \
+      p.trace[((size_t)g * 4 + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define SCF_TRACE(slot) do { } while (0)
+#endif
+
+
+// explicit LDS (address space 3) pointers: 32 bits each, ds_read / ds_write without relying on
+// address-space inference (the per-lane row address arrays would otherwise be 64-bit flat pointers)
+typedef __attribute__((address_space(3))) float* lds_fp_t;
+typedef __attribute__((address_space(3))) const float* lds_cfp_t;
+typedef __attribute__((address_space(3))) unsigned short* lds_u16p_t;
+typedef __attribute__((address_space(3))) const unsigned short* lds_cu16p_t;
+
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+// a pointer the compiler keeps in SGPRs (wave-uniform by construction)
+__device__ __forceinline__ const void* lk_sgpr_ptr(const void* p) {
+  const unsigned long long u = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return (const void*)(((unsigned long long)hi << 32) | lo);
+}
+
+// One half of a query's footprint: voff = byte offset inside the query's map, or >= 0x20000 when
+// the tap is outside the map (a 0x8000 table entry): those lanes stay off.  Everything that
+// touches EXEC / M0 sits in one statement; the compiler does not count these loads (the caller
+// waits on vmcnt itself).
+__device__ __forceinline__ void lk_dma_tap(const void* sbase, unsigned voff, unsigned lds,
+                                           unsigned long long live) {
+  asm volatile("v_cmp_gt_u32_e32 vcc, 0x20000, %1\n\t"
+               "s_and_b64 exec, vcc, %3\n\t"
+               "s_mov_b32 m0, %2\n\t"
+               "s_nop 0\n\t"
+               "global_load_lds_dword %1, %0 nt\n\t"
+               "s_mov_b64 exec, -1"
+               : : "s"(sbase), "v"(voff), "s"(lds), "s"(live) : "memory", "vcc", "scc");   // s_and writes SCC
+}
+// contiguous variant with an explicit lane mask (whole small maps)
+__device__ __forceinline__ void lk_dma_mask(const void* sbase, unsigned voff, unsigned lds,
+                                            unsigned long long mask) {
+  asm volatile("s_mov_b64 exec, %3\n\t"
+               "s_mov_b32 m0, %2\n\t"
+               "s_nop 0\n\t"
+               "global_load_lds_dword %1, %0 nt\n\t"
+               "s_mov_b64 exec, -1"
+               : : "s"(sbase), "v"(voff), "s"(lds), "s"(mask) : "memory");
+}
+
+// window read-back + bilinear blend + store for one (wave, level).  rowp[r] = LDS address of
+// window row r at this lane's first column (out-of-map rows of a small level point at the zero
+// row); column `it` is an immediate offset (non-small) or a clamped per-lane offset (small).
+// output store with an explicit cache policy (SM): 0 plain (write-back: the lines stay dirty in
+// this XCD's L2 until the end-of-kernel write-back), 1 nt, 2 sc1 (write-through), 3 sc0 sc1,
+// 4 sc1 nt.  addr = running scalar channel base + 32-bit lane offset (scoped atomic stores would
+// take 64-bit vector addresses and spill).  No "memory" clobber: nothing reads the output back.
+template <int SM>
+__device__ __forceinline__ void lk_store(char* sbase, unsigned voff, float v) {
+  if constexpr (SM == 0) *(float*)(sbase + voff) = v;
+  else if constexpr (SM == 1) asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(voff), "v"(v), "s"(sbase));
+  else if constexpr (SM == 2) asm volatile("global_store_dword %0, %1, %2 sc1" : : "v"(voff), "v"(v), "s"(sbase));
+  else if constexpr (SM == 3) asm volatile("global_store_dword %0, %1, %2 sc0 sc1" : : "v"(voff), "v"(v), "s"(sbase));
+  else asm volatile("global_store_dword %0, %1, %2 sc1 nt" : : "v"(voff), "v"(v), "s"(sbase));
+}
+
+template <int R, bool SMALL, int SM>
+__device__ __forceinline__ void lookup_emit(const lds_cfp_t (&rowp)[2 * R + 2], int lw, int xfirst,
+                                            bool flat_x, float nw, float ne, float sw, float se,
+                                            int part, char* obase, unsigned lane_off, size_t cs,
+                                            bool qvalid) {
+  constexpr int FW = 2 * R + 2, D = 2 * R + 1, NP = 2;
+  // The two half-waves split the D x-offsets: half g takes columns [i0(g), i0(g+1)), i0(g) =
+  // ceil(g*D / 2).  The loop itself is wave-uniform (NI = the larger share; the shorter one is
+  // masked) so that store bases stay in SGPRs and only a 32-bit per-lane offset goes into the
+  // address VGPR.
   constexpr int NI = (D + NP - 1) / NP;
   const int i0 = (part * D + NP - 1) / NP;
   const int cnt = ((part + 1) * D + NP - 1) / NP - i0;
   const unsigned lane_off2 = lane_off + (unsigned)((size_t)i0 * D * cs);
-  int rowoff[FW];
-  unsigned rowok = 0;
-  if constexpr (SMALL) {
-#pragma unroll
-    for (int r = 0; r < FW; ++r) {
-      const int yy = flat_y ? 0 : y0 + r;
-      const bool ok = (unsigned)yy < (unsigned)lh;
-      rowoff[r] = ok ? yy * lw : 0;
-      rowok |= (ok ? 1u : 0u) << r;
-    }
-  }
-  const float* fbase = f + (SMALL ? 0 : i0);
-  auto column = [&](int it, float (&col)[FW]) {
+  // small: column validity (xfirst = map column of window column i0)
+  auto column = [&](int it, float (&col)[FW], float& cv) {
     if constexpr (SMALL) {
-      const int xx = flat_x ? 0 : x0 + i0 + it;
+      const int xx = flat_x ? 0 : xfirst + it;
       const bool cok = (unsigned)xx < (unsigned)lw;
-      const float* fc = fbase + (cok ? xx : 0);
+      const int xs = cok ? xx : 0;
+      cv = cok ? 1.f : 0.f;
 #pragma unroll
-      for (int r = 0; r < FW; ++r) {
-        float v = fc[rowoff[r]];
-        asm volatile("" : "+v"(v));      // keep the (always in-range) read unconditional
-        col[r] = (cok && ((rowok >> r) & 1u)) ? v : 0.f;
-      }
+      for (int r = 0; r < FW; ++r) col[r] = rowp[r][xs];
     } else {
+      cv = 1.f;
 #pragma unroll
-      for (int r = 0; r < FW; ++r) col[r] = fbase[r * FW + it];      // immediate offsets
+      for (int r = 0; r < FW; ++r) col[r] = rowp[r][it];      // immediate offsets
     }
   };
   float col[2][FW];
-  column(0, col[0]);
+  float cva, cvb;
+  column(0, col[0], cva);
 #pragma unroll
   for (int it = 0; it < NI; ++it) {
     float (&cA)[FW] = col[it & 1];
     float (&cB)[FW] = col[(it & 1) ^ 1];
-    column(it + 1, cB);
+    column(it + 1, cB, cvb);
+    float w0 = nw, w1 = ne, w2 = sw, w3 = se;
+    if constexpr (SMALL) {       // out-of-map columns: clamped reads, zero weights
+      w0 = nw * cva; w2 = sw * cva; w1 = ne * cvb; w3 = se * cvb;
+    }
     if (qvalid && it < cnt) {
       char* oc = obase + (size_t)(it * D) * cs;      // wave-uniform channel base (SGPRs)
 #pragma unroll
       for (int j = 0; j < D; ++j) {
-        const float v = cA[j] * nw + cB[j] * ne + cA[j + 1] * sw + cB[j + 1] * se;
-        *(float*)(oc + (size_t)j * cs + lane_off2) = v;
+        const float v = cA[j] * w0 + cB[j] * w1 + cA[j + 1] * w2 + cB[j + 1] * w3;
+        // a RUNNING scalar base (opaque to the optimiser: it would otherwise precompute all 81
+        // channel bases and spill them): one s_add_u32 / s_addc_u32 per store
+        asm volatile("" : "+s"(oc));
+        lk_store<SM>(oc, lane_off2, v);
+        oc += cs;
       }
     }
+    cva = cvb;
   }
 }
 
-template <int R, bool TILED0, int QB>
-__global__ __launch_bounds__(256, QB == 32 ? 4 : 8) void corr_lookup_kernel(LookupParams p) {
+template <int R, bool TILED0, int SM>
+__global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
   constexpr int FW = 2 * R + 2;       // footprint width
   constexpr int FS = FW * FW;         // footprint size
-  constexpr int FSP = FS | 1;         // odd LDS stride per query
+  constexpr int FSP = FS | 1;         // odd LDS stride per query (conflict-free lane = query reads)
   constexpr int D = 2 * R + 1;        // window width
-  constexpr int NP = 64 / QB;         // lane groups per wave (QB = queries per block: 32 or 16)
-  constexpr int NSET = (FS + 63) / 64;  // wave-loads per query footprint
-  constexpr int AUX_NT = 2;           // nt: every footprint byte is read exactly once
+  constexpr int QB = 32;              // queries per group
+  constexpr int NSET = (FS + 63) / 64;  // DMA instructions per query footprint
+  constexpr int TQ = 2 * FW;          // table entries (u16) per query: FW row + FW column offsets
   extern __shared__ __attribute__((aligned(16))) float lds_fp[];
-  typedef const __attribute__((address_space(1))) void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
+  typedef float __attribute__((ext_vector_type(4))) f4;
 
+#ifdef SCF_LOOKUP_TRACE
+  const bool skip_dma = p.skip_dma != 0, skip_store = p.skip_store != 0;
+#else
+  constexpr bool skip_dma = false, skip_store = false;
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
-  const int l32 = lane & (QB - 1), half = lane / QB;     // query within the block, lane group
-  const long long gq0 = (long long)blockIdx.x * QB;
+  const int l32 = lane & 31, half = lane >> 5;                // query within the group, half-wave
   const int hw = p.h * p.w;
   const int ktot = p.L * D * D;
-  const int n0 = (int)(gq0 / hw);     // sample of the block's first query (block-uniform)
-
-  // this lane's query (both half-waves hold the same 32 queries)
-  const long long gq = gq0 + l32;
-  const bool qvalid = gq < p.total_q;
-  int n = n0, q = 0;
-  float qx = 0.f, qy = 0.f;
-  if (qvalid) {
-    n = (int)(gq / hw);
-    q = (int)(gq - (long long)n * hw);
-    const int y = q / p.w, x = q - y * p.w;
-    const float* fl = p.flow + (long long)n * 2 * hw + q;
-    qx = (float)x + fl[0];
-    qy = (float)y + fl[hw];
-  }
-  // byte offset of this lane's query from the block-uniform base out[n0, k, 0, 0]
-  const unsigned lane_off = (unsigned)(((long long)(n - n0) * ktot * hw + q) * 4);
   const size_t cs = (size_t)hw * 4;   // channel stride in bytes
-  float* myfp = lds_fp + p.woff[wave];
+  const lds_fp_t myfp = (lds_fp_t)lds_fp + p.woff[wave];
 
-  // footprint element(s) this lane fetches for EVERY query: e = lane + 64*s
-  int erow[NSET], ecol[NSET];
+  // gather-lane roles: this lane fetches footprint elements e = lane + 64 s of EVERY query
+  const lds_u16p_t tbl = (lds_u16p_t)(myfp + QB * FSP);   // [QB][TQ]
+  lds_cu16p_t trow[NSET];
+  lds_cu16p_t tcol[NSET];
+  unsigned long long live[NSET];
 #pragma unroll
   for (int s = 0; s < NSET; ++s) {
     const int e = lane + 64 * s;
-    erow[s] = e / FW;
-    ecol[s] = e - erow[s] * FW;
+    const int er = e < FS ? e / FW : 0, ec = e < FS ? e - (e / FW) * FW : 0;
+    trow[s] = tbl + er;
+    tcol[s] = tbl + FW + ec;
+    live[s] = __ballot(e < FS);
   }
-  const int nq = (int)((p.total_q - gq0) < QB ? (p.total_q - gq0) : QB);   // block-uniform
 
-  for (int lvl = wave; lvl < p.L; lvl += 4) {
-    const int lh = p.lh[lvl], lw = p.lw[lvl];
-    const int msz = lh * lw;
-    // Reference quirk at degenerate sizes: coordinates are normalised with max(size-1, 1) and
-    // grid_sample(align_corners=True) de-normalises with (size-1), so along a size-1 axis
-    // EVERY tap lands exactly on index 0 (corr_lookup.py:64-67).
-    const bool flat_x = lw == 1, flat_y = lh == 1;
-    const float inv = 1.0f / (float)(1 << lvl);
-    float cx = flat_x ? (float)R : qx * inv;          // exact power-of-two scaling
-    float cy = flat_y ? (float)R : qy * inv;
-    cx = fminf(fmaxf(cx, -30000.f), 30000.f);         // far outside any map -> all taps 0
-    cy = fminf(fmaxf(cy, -30000.f), 30000.f);
-    if (!(cx == cx)) cx = -30000.f;                   // NaN flow: treat as out of range
-    if (!(cy == cy)) cy = -30000.f;
-    const float x0f = floorf(cx), y0f = floorf(cy);
-    const int x0 = (int)x0f - R, y0 = (int)y0f - R;
-    const char* lbase = (const char*)(p.lvl[lvl] + gq0 * msz);
+  auto flow_of = [&](int gg, float& fx_, float& fy_) {
+    const long long gq_ = (long long)gg * QB + l32;
+    fx_ = 0.f; fy_ = 0.f;
+    if (gq_ < p.total_q) {
+      const int n_ = (int)(gq_ / hw);
+      const int q_ = (int)(gq_ - (long long)n_ * hw);
+      const float* fl = p.flow + (long long)n_ * 2 * hw + q_;
+      fx_ = fl[0];
+      fy_ = fl[hw];
+    }
+  };
+  int g = blockIdx.x;
+  float fx = 0.f, fy = 0.f;
+  if (g < p.ngroups) flow_of(g, fx, fy);       // issued before any setup
 
-    // Staging is LDS-DMA (global_load_lds_dword): memory -> LDS without passing through VGPRs,
-    // so ALL of a wave's gathers are in flight together (a register-staged version was
-    // latency-bound at 4 queries in flight per wave).  One query per step: the map base and the
-    // window origin are wave-uniform (readlane -> SGPRs), each lane adds a 32-bit offset.
-    //
-    // Small maps (coarse levels: the whole map is no larger than the window footprint) are
-    // staged whole instead of as a zero-padded footprint: fewer LDS bytes per query (which is
-    // what lets 4 blocks share a CU and the grid finish in ONE wave of blocks at batch 32).
-    const bool small = (lh <= FW && lw <= FW);
-    const bool tiled = TILED0 && lvl == 0;
-    const int S = small ? (msz | 1) : FSP;            // odd per-query LDS stride
-    if (small) {
-#pragma unroll 4
-      for (int qq = 0; qq < QB; ++qq) {
-        if (qq < nq) {
-          const char* mb = lbase + (size_t)qq * msz * 4;
-#pragma unroll
-          for (int s = 0; s < NSET; ++s)
-            if (lane + 64 * s < msz)
-              __builtin_amdgcn_global_load_lds((gptr_t)(mb + (unsigned)(lane + 64 * s) * 4u),
-                                               (lptr_t)(myfp + qq * S + 64 * s), 4, 0, AUX_NT);
+  for (; g < p.ngroups; g += gridDim.x) {
+    SCF_TRACE(0);
+    const long long gq0 = (long long)g * QB;
+    const int n0 = (int)(gq0 / hw);     // sample of the group's first query (wave-uniform)
+    const long long gq = gq0 + l32;
+    const bool qvalid = gq < p.total_q;
+    int n = n0, q = 0;
+    if (qvalid) {
+      n = (int)(gq / hw);
+      q = (int)(gq - (long long)n * hw);
+    }
+    const int y = q / p.w, x = q - y * p.w;
+    const float qx = (float)x + fx, qy = (float)y + fy;
+    // byte offset of this lane's query from the group-uniform base out[n0, k, 0, 0]
+    const unsigned lane_off = (unsigned)(((long long)(n - n0) * ktot * hw + q) * 4);
+    const int nq = (int)((p.total_q - gq0) < QB ? (p.total_q - gq0) : QB);   // wave-uniform
+    const bool more = g + (int)gridDim.x < p.ngroups;
+    float fxn = 0.f, fyn = 0.f;
+#ifdef SCF_LOOKUP_TRACE
+    { float a = qx, b = qy; asm volatile("" : "+v"(a), "+v"(b)); SCF_TRACE(1); }
+#endif
+
+    for (int lvl = wave; lvl < p.L; lvl += 4) {
+      const int lh = p.lh[lvl], lw = p.lw[lvl];
+      const int msz = lh * lw;
+      // Reference quirk at degenerate sizes: coordinates are normalised with max(size-1, 1) and
+      // grid_sample(align_corners=True) de-normalises with (size-1), so along a size-1 axis
+      // EVERY tap lands exactly on index 0 (corr_lookup.py:64-67).
+      const bool flat_x = lw == 1, flat_y = lh == 1;
+      const float inv = 1.0f / (float)(1 << lvl);
+      float cx = flat_x ? (float)R : qx * inv;          // exact power-of-two scaling
+      float cy = flat_y ? (float)R : qy * inv;
+      cx = fminf(fmaxf(cx, -30000.f), 30000.f);         // far outside any map -> all taps 0
+      cy = fminf(fmaxf(cy, -30000.f), 30000.f);
+      if (!(cx == cx)) cx = -30000.f;                   // NaN flow: treat as out of range
+      if (!(cy == cy)) cy = -30000.f;
+      const float x0f = floorf(cx), y0f = floorf(cy);
+      const int x0 = (int)x0f - R, y0 = (int)y0f - R;
+      const char* lbase = (const char*)lk_sgpr_ptr(p.lvl[lvl] + gq0 * msz);
+      const bool small = (lh <= FW && lw <= FW);
+      const bool tiled = TILED0 && lvl == 0;
+      const int i0 = (half * D + 1) / 2;                // first x-offset of this half-wave
+      lds_cfp_t rowp[FW];
+      unsigned st0 = (unsigned)(uintptr_t)myfp;
+      asm volatile("" : "+s"(st0));                     // row / query LDS addresses: s_add from here
+
+      if (small) {
+        // ---- whole map per query, stride S (odd), + ONE shared zero row behind them ----
+        const int S = msz | 1;
+        const lds_fp_t zrow = myfp + QB * S;
+        if (lane < lw) zrow[lane] = 0.f;
+        const unsigned long long m0mask = msz >= 64 ? ~0ull : ((1ull << msz) - 1ull);
+        const unsigned long long m1mask = msz > 64 ? ((1ull << (msz - 64)) - 1ull) : 0ull;
+        const unsigned vlane4 = (unsigned)lane * 4u;
+        SCF_TRACE(2);
+        if (!skip_dma) {
+          for (int qq = 0; qq < nq; ++qq) {
+            const char* mb = lbase + (size_t)qq * msz * 4;
+            lk_dma_mask(mb, vlane4, st0 + (unsigned)(qq * S) * 4u, m0mask);
+            if (msz > 64) lk_dma_mask(mb + 256, vlane4, st0 + (unsigned)(qq * S + 64) * 4u, m1mask);
+          }
         }
-      }
-    } else {
-      // zero padding = zero-filled staging area + lanes of out-of-map taps switched off
-      for (int i = lane; i < QB * FSP / 4; i += 64)
-        ((float __attribute__((ext_vector_type(4)))*)myfp)[i] = 0.f;
-      // Per query (computed once, vectorised over the 32 queries in lanes): a bit mask of the
-      // in-map window columns (bits 0..FW-1) and rows (bits 16..16+FW-1), and the element
-      // offset of the window origin.  Per (lane, set) constants: that element's column/row bit
-      // pair and its offset from the origin.  A tap is fetched iff both of its bits are set, and
-      // (row-major maps) its address is scalar origin + per-lane constant: 2 VALU per gather.
-      auto span = [&](int o, int n) -> unsigned {      // window positions c with 0 <= o + c < n
-        const int lo = min(max(-o, 0), FW), hi = max(min(n - o, FW), 0);
-        return hi > lo ? (1u << hi) - (1u << lo) : 0u;
-      };
-      const unsigned qmask = (flat_x ? (1u << FW) - 1u : span(x0, lw)) |
-                             ((flat_y ? (1u << FW) - 1u : span(y0, lh)) << 16);
-      const int qorg = (flat_y ? 0 : y0 * lw) + (flat_x ? 0 : x0);
-      unsigned ebits[NSET], eoff[NSET];
+        const lds_cfp_t f = myfp + l32 * S;
 #pragma unroll
-      for (int s = 0; s < NSET; ++s) {
-        const bool live = NSET * 64 == FS || lane + 64 * s < FS;
-        ebits[s] = live ? (1u << ecol[s]) | (1u << (16 + erow[s])) : 0x80000000u;
-        eoff[s] = (unsigned)(((flat_y ? 0 : erow[s] * lw) + (flat_x ? 0 : ecol[s])) * 4);
-      }
-      __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): zeros land before the DMA data
-#pragma unroll 4
-      for (int qq = 0; qq < QB; ++qq) {
-        if (qq < nq) {
-          const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)qmask, qq);
-          const char* mb = lbase + (size_t)qq * msz * 4;
-          if (!TILED0 || !tiled) {
-            const char* org = mb + (long long)__builtin_amdgcn_readlane(qorg, qq) * 4;
+        for (int r = 0; r < FW; ++r) {
+          const int yy = flat_y ? 0 : y0 + r;
+          rowp[r] = (unsigned)yy < (unsigned)lh ? f + yy * lw : (lds_cfp_t)zrow;
+        }
+      } else {
+        // ---- zero-padded footprints, stride FSP; two DMA instructions per query ----
+        for (int i = lane; i < QB * FSP / 4; i += 64)
+          ((__attribute__((address_space(3))) f4*)myfp)[i] = f4{0.f, 0.f, 0.f, 0.f};
+        // offset tables: half-wave 0 writes this query's FW row offsets, half-wave 1 its FW column
+        // offsets (in floats, inside the query's map; 0x8000 = outside).  The map layout lives
+        // here and nowhere else: row-major, or 8x4-float tiles of 128 B for level 0.
+        {
+          const int c0 = half ? x0 : y0, lim = half ? lw : lh;
+          const bool flat = half ? flat_x : flat_y;
+          const int sh = half ? 3 : 2, msk = half ? 7 : 3;
+          const int mula = tiled ? (half ? 32 : lw * 4) : 0, mulb = tiled ? (half ? 1 : 8) : (half ? 1 : lw);
+          const lds_u16p_t tq = tbl + l32 * TQ + half * FW;
 #pragma unroll
-            for (int s = 0; s < NSET; ++s)
-              if ((ebits[s] & m) == ebits[s])
-                __builtin_amdgcn_global_load_lds((gptr_t)(org + eoff[s]),
-                                                 (lptr_t)(myfp + qq * FSP + 64 * s), 4, 0, AUX_NT);
-          } else {
-            const int sx0 = __builtin_amdgcn_readlane(x0, qq);
-            const int sy0 = __builtin_amdgcn_readlane(y0, qq);
+          for (int j = 0; j < FW; j += 2) {
+            unsigned pr = 0;
 #pragma unroll
-            for (int s = 0; s < NSET; ++s) {
-              const int xx = sx0 + ecol[s], yy = sy0 + erow[s];
-              // 24-bit multiply (full rate); lanes with out-of-range xx/yy are switched off
-              const int lin = __mul24(yy >> 2, lw * 4) + ((xx >> 3) << 5) + ((yy & 3) << 3) + (xx & 7);
-              if ((ebits[s] & m) == ebits[s])
-                __builtin_amdgcn_global_load_lds((gptr_t)(mb + (unsigned)lin * 4u),
-                                                 (lptr_t)(myfp + qq * FSP + 64 * s), 4, 0, AUX_NT);
+            for (int jj = 0; jj < 2; ++jj) {
+              const int v = flat ? 0 : c0 + j + jj;
+              const bool ok = qvalid && (unsigned)v < (unsigned)lim;
+              // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): |v| <= 30010, factors < 2^15
+              const int val = tiled ? __mul24(v >> sh, mula) + __mul24(v & msk, mulb) : __mul24(v, mulb);
+              pr |= (ok ? (unsigned)val : 0x8000u) << (16 * jj);
+            }
+            *(__attribute__((address_space(3))) unsigned*)(tq + j) = pr;
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): zeros and tables are in LDS
+        __builtin_amdgcn_wave_barrier();
+        SCF_TRACE(2);
+        if (!skip_dma) {
+          constexpr int QBATCH = 4;                      // table reads of a batch issue together
+#pragma unroll
+          for (int qb = 0; qb < QB; qb += QBATCH) {
+            unsigned tr_[QBATCH][NSET], tc_[QBATCH][NSET];
+#pragma unroll
+            for (int qi = 0; qi < QBATCH; ++qi)
+#pragma unroll
+              for (int s = 0; s < NSET; ++s) {
+                tr_[qi][s] = trow[s][(qb + qi) * TQ];     // immediate offsets
+                tc_[qi][s] = tcol[s][(qb + qi) * TQ];
+              }
+#pragma unroll
+            for (int qi = 0; qi < QBATCH; ++qi) {
+              const int qq = qb + qi;
+              const char* mb = lbase + (size_t)qq * msz * 4;
+#pragma unroll
+              for (int s = 0; s < NSET; ++s) {
+                const unsigned voff = (tr_[qi][s] + tc_[qi][s]) << 2;
+                lk_dma_tap(mb, voff, st0 + (unsigned)(qq * FSP + 64 * s) * 4u, live[s]);
+              }
             }
           }
         }
+        const lds_cfp_t f = myfp + l32 * FSP + i0;
+#pragma unroll
+        for (int r = 0; r < FW; ++r) rowp[r] = f + r * FW;
       }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the DMA data is in LDS
-    __builtin_amdgcn_wave_barrier();
+      SCF_TRACE(3);
+      // flow of this block's next group: issued behind the gathers, consumed after the stores
+      if (more && lvl + 4 >= p.L) flow_of(g + (int)gridDim.x, fxn, fyn);
 
-    // ---- read back + blend + store: lane = (query, half); halves split the x-offsets ----
-    const float tx = cx - x0f, ty = cy - y0f;
-    const float wx0 = (x0f + 1.f) - cx, wy0 = (y0f + 1.f) - cy;   // grid_sample: (x_se - x)
-    const float nw = wx0 * wy0, ne = tx * wy0, sw = wx0 * ty, se = tx * ty;
-    const float* f = myfp + l32 * S;
-    char* obase = (char*)p.out + ((size_t)n0 * ktot + (size_t)lvl * D * D) * cs;
-    if (small)
-      lookup_emit<R, true, NP>(f, lw, lh, x0, y0, flat_x, flat_y, nw, ne, sw, se, half, obase, lane_off, cs, qvalid);
-    else
-      lookup_emit<R, false, NP>(f, lw, lh, x0, y0, flat_x, flat_y, nw, ne, sw, se, half, obase, lane_off, cs, qvalid);
-    __builtin_amdgcn_wave_barrier();
+      // ---- blend weights; lane = (query, half); halves split the x-offsets ----
+      const float tx = cx - x0f, ty = cy - y0f;
+      const float wx0 = (x0f + 1.f) - cx, wy0 = (y0f + 1.f) - cy;   // grid_sample: (x_se - x)
+      const float nw = wx0 * wy0, ne = tx * wy0, sw = wx0 * ty, se = tx * ty;
+      char* obase = (char*)p.out + ((size_t)n0 * ktot + (size_t)lvl * D * D) * cs;
+      __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the DMA data is in LDS
+      __builtin_amdgcn_wave_barrier();
+      SCF_TRACE(4);
+      if (small)
+        lookup_emit<R, true, SM>(rowp, lw, x0 + i0, flat_x, nw, ne, sw, se, half, obase, lane_off, cs, qvalid && !skip_store);
+      else
+        lookup_emit<R, false, SM>(rowp, lw, 0, flat_x, nw, ne, sw, se, half, obase, lane_off, cs, qvalid && !skip_store);
+      __builtin_amdgcn_wave_barrier();
+#ifdef SCF_LOOKUP_TRACE
+      SCF_TRACE(5);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      SCF_TRACE(6);
+      if (p.trace && lane == 0)
+        p.trace[((size_t)g * 4 + wave) * 8 + 7] = ((unsigned long long)lvl << 32) | __builtin_amdgcn_s_getreg(4 | (31 << 11));
+#endif
+    }
+    fx = fxn;
+    fy = fyn;
   }
+}
+
+#ifdef SCF_LOOKUP_TRACE
+static unsigned long long* scf_lab_trace = nullptr;
+static int scf_lab_skip_dma = 0, scf_lab_skip_store = 0, scf_lab_rotate = -1, scf_lab_grid = 0, scf_lab_store_mode = 0;
+#endif
+
+// CUs of the current device (cached per device): the grid is persistent, blocks-per-CU x CUs
+static int lookup_cu_count() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
 }
 
 static int lookup_launch(const float* const* levels, const float* flow, float* out, int N, int h, int w,
@@ -262,6 +420,7 @@ static int lookup_launch(const float* const* levels, const float* flow, float* o
   if (level0_tiled && ((w & 7) || (h & 3) || h <= 2 * r + 2 || w <= 2 * r + 2)) return SCF_EUNSUPPORTED;
   if (!levels || !flow || !out || N <= 0 || h <= 0 || w <= 0 || L <= 0) return SCF_EINVAL;
   if (L > SCF_MAX_LEVELS) return SCF_EUNSUPPORTED;
+  if (r < 1 || r > 4) return SCF_EUNSUPPORTED;
   LookupParams p;
   int lh = h, lw = w;
   for (int l = 0; l < L; ++l) {
@@ -272,36 +431,59 @@ static int lookup_launch(const float* const* levels, const float* flow, float* o
     lh /= 2;
     lw /= 2;
   }
+  for (int l = L; l < SCF_MAX_LEVELS; ++l) { p.lvl[l] = nullptr; p.lh[l] = p.lw[l] = 0; }
   p.flow = flow;
   p.out = out;
   p.N = N; p.h = h; p.w = w; p.L = L;
   p.total_q = (long long)N * h * w;
   p.l0_tiled = level0_tiled ? 1 : 0;
-  // 32 queries per block (full 128-byte store lines).  16 per block (2048 blocks, 8 per CU, 64-byte
-  // store segments) was measured slower: 30.5 vs 24.6 us at batch 32.
-  constexpr int qb = 32;
-  const int nblk = (int)scf_cdiv(p.total_q, qb);
+  constexpr int qb = 32;   // 32 queries per group: full 128-byte store lines
+  const long long ngroups = scf_cdiv(p.total_q, qb);
+  if (ngroups > 0x7fffffffLL) return SCF_EUNSUPPORTED;
+  p.ngroups = (int)ngroups;
   // per-wave LDS region: wave w stages levels w, w+4, ...; a level whose whole map fits in the
-  // (2r+2)^2 footprint is staged whole (stride map|1), otherwise as a footprint (stride FS|1)
-  const int FWh = 2 * r + 2, FSPh = (FWh * FWh) | 1;
+  // (2r+2)^2 footprint is staged whole (stride map|1) + one shared zero row, otherwise as
+  // zero-padded footprints (stride FS|1) + the u16 offset tables (2*(2r+2) entries per query)
+  const int FW = 2 * r + 2, FSP = (FW * FW) | 1;
+  if ((long long)h * w > 32767) return SCF_EUNSUPPORTED;      // u16 offset tables (floats inside one map)
   int off = 0;
   for (int wv = 0; wv < 4; ++wv) {
     int need = 0;
     for (int l = wv; l < L; l += 4) {
-      const bool small = p.lh[l] <= FWh && p.lw[l] <= FWh;
-      const int S = small ? ((p.lh[l] * p.lw[l]) | 1) : FSPh;
-      need = need > qb * S ? need : qb * S;
+      const bool small = p.lh[l] <= FW && p.lw[l] <= FW;
+      const int fl = small ? qb * ((p.lh[l] * p.lw[l]) | 1) + p.lw[l] : qb * FSP + qb * FW;   // 2*FW u16 = FW floats
+      need = need > fl ? need : fl;
     }
     p.woff[wv] = off;
     off += (need + 3) & ~3;                            // 16-byte aligned regions (b128 zero fill)
   }
   const size_t lds = (size_t)off * sizeof(float);
-#define SCF_LK2(R_, T_, Q_)                                                                         \
-  scf_launch((corr_lookup_kernel<R_, T_, Q_>), dim3(nblk), dim3(256), lds, scf_stream(stream), p)
+  if (lds > 64 * 1024) return SCF_EUNSUPPORTED;
+  int per_cu = (int)((160 * 1024) / (lds + 512));
+  per_cu = per_cu > 4 ? 4 : per_cu < 1 ? 1 : per_cu;    // launch bounds: 4 blocks (16 waves) per CU
+  long long nblk = (long long)lookup_cu_count() * per_cu;
+  if (nblk > ngroups) nblk = ngroups;
+#ifdef SCF_LOOKUP_TRACE
+  p.trace = scf_lab_trace; p.skip_dma = scf_lab_skip_dma; p.skip_store = scf_lab_skip_store;
+  if (scf_lab_grid > 0) nblk = scf_lab_grid;
+#endif
+#define SCF_LK2(R_, T_, S_)                                                                         \
+  scf_launch((corr_lookup_kernel<R_, T_, S_>), dim3((unsigned)nblk), dim3(256), lds, scf_stream(stream), p)
 #define SCF_LK(R_)                                                                                 \
   case R_:                                                                                         \
-    if (level0_tiled) { SCF_LK2(R_, true, 32); } else { SCF_LK2(R_, false, 32); }                  \
+    if (level0_tiled) { SCF_LK2(R_, true, SCF_LOOKUP_STORE_MODE); } else { SCF_LK2(R_, false, SCF_LOOKUP_STORE_MODE); } \
     break;
+#ifdef SCF_LOOKUP_TRACE
+  if (r == 4 && level0_tiled && scf_lab_store_mode > 0) {      // lab: A/B of the store policy
+    switch (scf_lab_store_mode) {
+      case 1: SCF_LK2(4, true, 1); break;
+      case 2: SCF_LK2(4, true, 2); break;
+      case 3: SCF_LK2(4, true, 3); break;
+      default: SCF_LK2(4, true, 4); break;
+    }
+    return scf_launch_status();
+  }
+#endif
   switch (r) {
     SCF_LK(4) SCF_LK(3) SCF_LK(2) SCF_LK(1)
     default: return SCF_EUNSUPPORTED;

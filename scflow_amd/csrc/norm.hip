@@ -25,9 +25,9 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 // plane; VEC4 float4 per thread cached in registers.
 // ---------------------------------------------------------------------------------
 template <int VEC4>
-__global__ __launch_bounds__(256) void instance_norm_kernel(const float* __restrict__ x,
-                                                            const float* __restrict__ res,
-                                                            float* __restrict__ out, int HW,
+__global__ __launch_bounds__(256) void instance_norm_kernel(const float* x,      // x / res may alias out (in place):
+                                                            const float* res,    // no __restrict__
+                                                            float* out, int HW,
                                                             float eps, int relu) {
   __shared__ float red[4];
   const long long pl = blockIdx.x;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void instance_norm_kernel(const float* __restr
         const float4 r = rp[idx];
         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
       }
-      if (relu) {
+      if (relu) {        // NaN -> 0 (v_max), like the convolution epilogue's compare+select
         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
       }
       op[idx] = o;
@@ -77,9 +77,9 @@ __global__ __launch_bounds__(256) void instance_norm_kernel(const float* __restr
 }
 
 // generic fallback (any HW): three sweeps, the 2nd/3rd hit L2
-__global__ __launch_bounds__(256) void instance_norm_generic_kernel(const float* __restrict__ x,
-                                                                    const float* __restrict__ res,
-                                                                    float* __restrict__ out, int HW,
+__global__ __launch_bounds__(256) void instance_norm_generic_kernel(const float* x,     // may alias out
+                                                                    const float* res,
+                                                                    float* out, int HW,
                                                                     float eps, int relu) {
   __shared__ float red[4];
   const long long pl = blockIdx.x;
@@ -110,10 +110,10 @@ extern "C" int scf_instance_norm(const float* x, const float* res, float* out, i
   const dim3 grid((unsigned)planes), blk(256);
   const bool vec = (HW % 4 == 0) && ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)res) & 15) == 0);
   const int n4 = HW / 4;
-  if (vec && n4 <= 256) hipLaunchKernelGGL(instance_norm_kernel<1>, grid, blk, 0, st, x, res, out, HW, eps, relu);
-  else if (vec && n4 <= 1024) hipLaunchKernelGGL(instance_norm_kernel<4>, grid, blk, 0, st, x, res, out, HW, eps, relu);
-  else if (vec && n4 <= 4096) hipLaunchKernelGGL(instance_norm_kernel<16>, grid, blk, 0, st, x, res, out, HW, eps, relu);
-  else hipLaunchKernelGGL(instance_norm_generic_kernel, grid, blk, 0, st, x, res, out, HW, eps, relu);
+  if (vec && n4 <= 256) scf_launch(instance_norm_kernel<1>, grid, blk, 0, st, x, res, out, HW, eps, relu);
+  else if (vec && n4 <= 1024) scf_launch(instance_norm_kernel<4>, grid, blk, 0, st, x, res, out, HW, eps, relu);
+  else if (vec && n4 <= 4096) scf_launch(instance_norm_kernel<16>, grid, blk, 0, st, x, res, out, HW, eps, relu);
+  else scf_launch(instance_norm_generic_kernel, grid, blk, 0, st, x, res, out, HW, eps, relu);
   return scf_launch_status();
 }
 
@@ -154,7 +154,7 @@ extern "C" int scf_group_norm_relu(const float* x, const float* gamma, const flo
                                    int N, int C, int HW, int G, float eps, scf_stream_t stream) {
   if (!x || !gamma || !beta || !out || N <= 0 || C <= 0 || HW <= 0 || G <= 0) return SCF_EINVAL;
   if (C % G != 0) return SCF_EUNSUPPORTED;
-  hipLaunchKernelGGL(group_norm_relu_kernel, dim3(N * G), dim3(256), 0, scf_stream(stream), x, gamma,
+  scf_launch(group_norm_relu_kernel, dim3(N * G), dim3(256), 0, scf_stream(stream), x, gamma,
                      beta, out, C, HW, G, eps);
   return scf_launch_status();
 }
@@ -214,7 +214,7 @@ extern "C" int scf_linear(const float* x, const float* W, const float* b, float*
   constexpr int NB = 8;
   const dim3 grid((O + 3) / 4, (N + NB - 1) / NB);
   if (grid.y > 65535) return SCF_EUNSUPPORTED;
-  hipLaunchKernelGGL(linear_kernel<NB>, grid, dim3(256), 0, scf_stream(stream), x, W, b, y, N, K, O,
+  scf_launch(linear_kernel<NB>, grid, dim3(256), 0, scf_stream(stream), x, W, b, y, N, K, O,
                      act);
   return scf_launch_status();
 }

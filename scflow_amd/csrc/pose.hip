@@ -99,7 +99,7 @@ extern "C" int scf_reproject_flow(const float* depth, const float* K, const floa
   if (!depth || !K || !R0 || !t0 || !R || !t || !flow || N <= 0 || H <= 0 || W <= 0) return SCF_EINVAL;
   if (N > 65535) return SCF_EUNSUPPORTED;
   const int bx = (int)(scf_cdiv((int64_t)H * W, 256) < 64 ? scf_cdiv((int64_t)H * W, 256) : 64);
-  hipLaunchKernelGGL(reproject_flow_kernel, dim3(bx, N), dim3(256), 0, scf_stream(stream), depth, K,
+  scf_launch(reproject_flow_kernel, dim3(bx, N), dim3(256), 0, scf_stream(stream), depth, K,
                      R0, t0, R, t, flow, H, W, invalid_num);
   return scf_launch_status();
 }
@@ -132,7 +132,7 @@ extern "C" int scf_unproject_depth(const float* depth, const float* K, const flo
   if (!depth || !K || !R0 || !t0 || !pts || N <= 0 || H <= 0 || W <= 0) return SCF_EINVAL;
   if (N > 65535) return SCF_EUNSUPPORTED;
   const int bx = (int)(scf_cdiv((int64_t)H * W, 256) < 64 ? scf_cdiv((int64_t)H * W, 256) : 64);
-  hipLaunchKernelGGL(unproject_depth_kernel, dim3(bx, N), dim3(256), 0, scf_stream(stream), depth,
+  scf_launch(unproject_depth_kernel, dim3(bx, N), dim3(256), 0, scf_stream(stream), depth,
                      K, R0, t0, pts, H, W);
   return scf_launch_status();
 }
@@ -187,7 +187,7 @@ extern "C" int scf_pose_update(const float* rot_all, const float* trans_all, con
   if (!rot_all || !trans_all || !label || !R_in || !t_in || !d_rot || !d_trans || !R_out || !t_out ||
       N <= 0 || num_class <= 0)
     return SCF_EINVAL;
-  hipLaunchKernelGGL(pose_update_kernel, dim3((N + 63) / 64), dim3(64), 0, scf_stream(stream),
+  scf_launch(pose_update_kernel, dim3((N + 63) / 64), dim3(64), 0, scf_stream(stream),
                      rot_all, trans_all, (const long long*)label, num_class, label_mode, R_in, t_in,
                      d_rot, d_trans, R_out, t_out, N);
   return scf_launch_status();
@@ -248,7 +248,7 @@ extern "C" int scf_filter_flow_by_mask(float* flow, const float* mask, int N, in
   if (!flow || !mask || N <= 0 || H <= 0 || W <= 0) return SCF_EINVAL;
   const long long total = (long long)N * H * W;
   const int grid = (int)(scf_cdiv(total, 256) < 262144 ? scf_cdiv(total, 256) : 262144);
-  hipLaunchKernelGGL(filter_flow_by_mask_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), flow, mask,
+  scf_launch(filter_flow_by_mask_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), flow, mask,
                      N, H, W, invalid_num, align_corners);
   return scf_launch_status();
 }
@@ -347,7 +347,7 @@ extern "C" int scf_pose_error(const double* verts, int nv, const double* gt_r, c
   if (!verts || !gt_r || !gt_t || !pred_r || !pred_t || !K || !sample_idx || !err3d || !err2d)
     return SCF_EINVAL;
   if (nv <= 0 || nsel <= 0) return SCF_EINVAL;
-  hipLaunchKernelGGL(pose_error_kernel, dim3(nsel), dim3(256), 0, scf_stream(stream), verts, nv, gt_r,
+  scf_launch(pose_error_kernel, dim3(nsel), dim3(256), 0, scf_stream(stream), verts, nv, gt_r,
                      gt_t, pred_r, pred_t, K, sample_idx, symmetric, err3d, err2d);
   return scf_launch_status();
 }

@@ -45,7 +45,7 @@ extern "C" int scf_resize_bilinear(const float* a, const float* b, float* out, i
   const float sw = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
   const long long total = (long long)planes * Hout * Wout;
   const int grid = (int)(scf_cdiv(total, 256) < 262144 ? scf_cdiv(total, 256) : 262144);
-  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), a, b,
+  scf_launch(resize_bilinear_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), a, b,
                      out, (long long)planes, Hin, Win, Hout, Wout, sh, sw, mul);
   return scf_launch_status();
 }
@@ -73,7 +73,7 @@ extern "C" int scf_avgpool2x2(const float* x, float* out, int64_t planes, int Hi
   const int Ho = Hin / 2, Wo = Win / 2;
   const long long total = (long long)planes * Ho * Wo;
   const int grid = (int)(scf_cdiv(total, 256) < 262144 ? scf_cdiv(total, 256) : 262144);
-  hipLaunchKernelGGL(avgpool2x2_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), x, out,
+  scf_launch(avgpool2x2_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), x, out,
                      (long long)planes, Hin, Win, Ho, Wo);
   return scf_launch_status();
 }
@@ -104,7 +104,7 @@ extern "C" int scf_avgpool2x2_tiled_in(const float* x, float* out, int64_t plane
   const int Ho = Hin / 2, Wo = Win / 2;
   const long long total = (long long)planes * Ho * Wo;
   const int grid = (int)(scf_cdiv(total, 256) < 262144 ? scf_cdiv(total, 256) : 262144);
-  hipLaunchKernelGGL(avgpool2x2_tiled_in_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), x, out,
+  scf_launch(avgpool2x2_tiled_in_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), x, out,
                      (long long)planes, Hin, Win, Ho, Wo);
   return scf_launch_status();
 }
@@ -125,7 +125,7 @@ extern "C" int scf_copy_strided(const float* src, int64_t src_nstride, float* ds
   if (!src || !dst || N <= 0 || count <= 0) return SCF_EINVAL;
   const long long total = (long long)N * count;
   const int grid = (int)(scf_cdiv(total, 256) < 262144 ? scf_cdiv(total, 256) : 262144);
-  hipLaunchKernelGGL(copy_strided_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), src,
+  scf_launch(copy_strided_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), src,
                      (long long)src_nstride, dst, (long long)dst_nstride, N, (long long)count);
   return scf_launch_status();
 }
@@ -198,7 +198,7 @@ extern "C" int scf_convex_upsample(const float* x, const float* mask, float* out
   const size_t lds = (size_t)C * 8 * 32 * 8 * sizeof(float);
   if (lds > 64 * 1024) return SCF_EUNSUPPORTED;
   const dim3 grid((w + 31) / 32, h, N);
-  hipLaunchKernelGGL(convex_upsample_kernel<8>, grid, dim3(256), lds, scf_stream(stream), x, mask,
+  scf_launch(convex_upsample_kernel<8>, grid, dim3(256), lds, scf_stream(stream), x, mask,
                      out, C, h, w, x_mul, mask_mul);
   return scf_launch_status();
 }

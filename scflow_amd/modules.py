@@ -37,7 +37,14 @@ def _act_code(act_cfg: Optional[dict]) -> int:
 
 
 class HipModule(nn.Module):
-    """nn.Module whose kernel-layout parameter cache follows .to()/load_state_dict()."""
+    """nn.Module with a kernel-layout copy of its parameters (``packed``).
+
+    The copy is keyed on the identity AND version of every tensor it was built from
+    (``(data_ptr, _version)`` of ``_pack_sources()``), so it follows every way weights can
+    change: ``.to()``, ``load_state_dict`` on this module or on any wrapper / parent (mmcv's
+    ``load_checkpoint`` recurses through ``_load_from_state_dict`` and never calls this
+    class's ``load_state_dict``), ``param.data.copy_`` and ``nn.init`` -- all of them bump
+    ``_version`` or replace the storage."""
 
     def _drop_packed(self) -> None:
         for m in self.modules():
@@ -57,12 +64,33 @@ class HipModule(nn.Module):
     def _pack(self):
         raise NotImplementedError
 
+    def _pack_sources(self):
+        """the tensors ``_pack`` reads (default: this module's own parameters and buffers and
+        those of its non-HipModule children, e.g. nn.Conv2d / norm leaves)."""
+        out = []
+        stack = [self]
+        while stack:
+            m = stack.pop()
+            out.extend(m._parameters.values())
+            out.extend(m._buffers.values())
+            for c in m._modules.values():
+                if c is not None and (m is not self or not isinstance(c, HipModule)):
+                    if not isinstance(c, HipModule):
+                        stack.append(c)
+        return [t for t in out if t is not None]
+
+    def _pack_key(self):
+        return tuple((t.data_ptr(), t._version) for t in self._pack_sources())
+
     @property
     def packed(self):
-        if self.__dict__.get('_packed') is None:
+        d = self.__dict__
+        key = self._pack_key()
+        if d.get('_packed') is None or d.get('_packed_key') != key:
             with torch.no_grad():
-                self.__dict__['_packed'] = self._pack()
-        return self.__dict__['_packed']
+                d['_packed'] = self._pack()
+            d['_packed_key'] = key
+        return d['_packed']
 
 
 class ConvBlock(HipModule):
@@ -238,13 +266,11 @@ class CorrLookup(HipModule):
         return ops.corr_lookup(corr_pyramid, flow, self.r, level0_tiled=level0_tiled)
 
 
-def _use_tiled_level0(feat: Tensor, radius: int) -> bool:
+def _use_tiled_level0(feat: Tensor, radius: int, allow: bool = True) -> bool:
     """the decoders keep the pyramid to themselves, so they are free to pick the tiled level-0
-    layout whenever the map shape allows it (SCF_LOOKUP_TILED=0 forces the reference layout)."""
-    import os
-    if os.environ.get('SCF_LOOKUP_TILED', '1') == '0':
-        return False
-    return ops.tiled_level0_ok(feat.shape[-2], feat.shape[-1], radius)
+    layout whenever the map shape allows it (``decoder.tiled_level0 = False`` forces the
+    reference layout: A/B measurements in tools/)."""
+    return allow and ops.tiled_level0_ok(feat.shape[-2], feat.shape[-1], radius)
 
 
 class MotionEncoder(HipModule):
@@ -305,16 +331,14 @@ class ConvGRU(HipModule):
         return packs
 
     def forward_inplace(self, hx: Tensor) -> Tensor:
-        """hx: (N, h_ch + x_ch, h, w) = [h | x]; h is updated in place."""
+        """hx: (N, h_ch + x_ch, h, w) = [h | x]; h is updated in place.  One C-ABI call
+        (``scf_sepconv_gru``: the launch sequence lives in the library)."""
         hc = self.h_channels
         n, _, h, w = hx.shape
         z = torch.empty((n, hc, h, w), dtype=torch.float32, device=hx.device)
         rh = torch.empty((n, hc, h, w), dtype=torch.float32, device=hx.device)
-        hv, xv = hx[:, :hc], hx[:, hc:]
-        for pzr, pq in self.packed:
-            ops.conv2d(pzr, hx, out=z, mode=CONV_GRU_ZR, gru_h=hv, gru_aux=rh)
-            ops.conv2d(pq, rh, xv, out=hv, mode=CONV_GRU_Q, gru_h=hv, gru_z=z)
-        return hv
+        ops.sepconv_gru(self.packed, hx, hc, z, rh)
+        return hx[:, :hc]
 
     def forward(self, h: Tensor, x: Tensor) -> Tensor:
         """raft_decoder.py:235-253 signature (copies h, x into one buffer)."""
@@ -445,6 +469,7 @@ class SCFlowDecoder(HipModule):
                                                 ConvBlock(128, 64, 3, padding=1, act_cfg=act_cfg))
         self.mask_encoder = nn.Sequential(ConvBlock(1, 64, 3, padding=1, act_cfg=act_cfg),
                                           ConvBlock(64, 32, 3, padding=1, act_cfg=act_cfg))
+        self.tiled_level0 = True      # decoder-internal pyramid layout (see _use_tiled_level0)
 
     def _pack(self):
         # the two XHead hidden layers read the same h: one 512-row convolution
@@ -454,7 +479,8 @@ class SCFlowDecoder(HipModule):
 
     def forward(self, feat_render: Tensor, feat_real: Tensor, h_feat: Tensor, cxt_feat: Tensor,
                 ref_rotation: Tensor, ref_translation: Tensor, depth: Tensor, internel_k: Tensor,
-                label: Tensor, init_flow: Tensor, invalid_flow_num: float):
+                label: Tensor, init_flow: Tensor, invalid_flow_num: float,
+                _consume_state: bool = False):
         """scflow_decoder.py:150-251 (inference).  Returns the reference's 7-tuple of
         per-iteration lists."""
         hc, cc = self.h_channels, self.cxt_channels
@@ -464,10 +490,12 @@ class SCFlowDecoder(HipModule):
         dev = depth.device
         f32 = dict(dtype=torch.float32, device=dev)
 
-        tiled = _use_tiled_level0(feat_render, self.radius)
+        tiled = _use_tiled_level0(feat_render, self.radius, self.tiled_level0)
         pyramid = self.corr_block(feat_render, feat_real, level0_tiled=tiled)      # :172
-        # GRU buffer [h | cxt | motion(126) | flow(2)]; reuse the caller's if it already is one
-        hx = _as_gru_buffer(h_feat, cxt_feat, hc + cc + 128)
+        # GRU buffer [h | cxt | motion(126) | flow(2)]: the caller's own buffer only when the
+        # refiner says it may be consumed (_consume_state); the public forward never mutates
+        # its inputs (the reference decoder does not either)
+        hx = _as_gru_buffer(h_feat, cxt_feat, hc + cc + 128, _consume_state)
         rot, trans = ref_rotation.contiguous(), ref_translation.contiguous()
         rot0, trans0 = rot, trans
         flow = init_flow
@@ -527,6 +555,7 @@ class _RAFTDecoderBase(HipModule):
         self.flow_pred = XHead(self.h_channels, [256], 2, x='flow')
         self.mask_pred = XHead(self.h_channels, [256], self.mask_channels, x='mask')
         self.convex_upsample_flow = convex_unsample_flow
+        self.tiled_level0 = True      # decoder-internal pyramid layout (see _use_tiled_level0)
         if self.mask_channels != 9 * (2 ** (num_levels - 1)) ** 2:
             raise NotImplementedError('convex up-sampling kernel: 9 x 8 x 8 mask (radius 4, 4 levels)')
 
@@ -553,10 +582,11 @@ class RAFTDecoder(_RAFTDecoderBase):
     """decoder/raft_decoder.py:299-457."""
 
     def forward(self, feat1: Tensor, feat2: Tensor, flow: Tensor, h_feat: Tensor,
-                cxt_feat: Tensor) -> List[Tensor]:
-        tiled = _use_tiled_level0(feat1, self.radius)
+                cxt_feat: Tensor, _consume_state: bool = False) -> List[Tensor]:
+        tiled = _use_tiled_level0(feat1, self.radius, self.tiled_level0)
         pyramid = self.corr_block(feat1, feat2, level0_tiled=tiled)
-        hx = _as_gru_buffer(h_feat, cxt_feat, self.h_channels + self.cxt_channels + 128)
+        hx = _as_gru_buffer(h_feat, cxt_feat, self.h_channels + self.cxt_channels + 128,
+                            _consume_state)
         scale = float(2 ** (self.num_levels - 1))
         flow = flow.contiguous()
         outs = []
@@ -576,10 +606,11 @@ class RAFTDecoderMask(_RAFTDecoderBase):
         self.occlusion_pred = XHead(self.h_channels, [256], 1, x='mask')
 
     def forward(self, feat1: Tensor, feat2: Tensor, flow: Tensor, h_feat: Tensor,
-                cxt_feat: Tensor):
-        tiled = _use_tiled_level0(feat1, self.radius)
+                cxt_feat: Tensor, _consume_state: bool = False):
+        tiled = _use_tiled_level0(feat1, self.radius, self.tiled_level0)
         pyramid = self.corr_block(feat1, feat2, level0_tiled=tiled)
-        hx = _as_gru_buffer(h_feat, cxt_feat, self.h_channels + self.cxt_channels + 128)
+        hx = _as_gru_buffer(h_feat, cxt_feat, self.h_channels + self.cxt_channels + 128,
+                            _consume_state)
         scale = float(2 ** (self.num_levels - 1))
         flow = flow.contiguous()
         flows, occs = [], []
@@ -592,13 +623,16 @@ class RAFTDecoderMask(_RAFTDecoderBase):
         return flows, occs
 
 
-def _as_gru_buffer(h_feat: Tensor, cxt_feat: Tensor, total: int) -> Tensor:
-    """[h | cxt | ...] buffer of ``total`` channels: zero-copy when h_feat / cxt_feat already
-    are adjacent channel slices of such a buffer (SCFlowRefiner.extract_feat makes them so)."""
+def _as_gru_buffer(h_feat: Tensor, cxt_feat: Tensor, total: int, consume: bool = False) -> Tensor:
+    """[h | cxt | ...] buffer of ``total`` channels.  The GRU updates h in place and the motion
+    features land next to cxt, so the buffer is private to one decoder run: a fresh copy of the
+    inputs, unless the caller hands its own buffer over (``consume``: the refiner's get_pose /
+    get_flow, whose extract_feat output is used exactly once) and h_feat / cxt_feat already are
+    adjacent channel slices of such a buffer (zero-copy)."""
     n, hc, h, w = h_feat.shape
     cc = cxt_feat.shape[1]
     base = h_feat._base
-    if (base is not None and base is cxt_feat._base and base.dim() == 4 and base.is_contiguous()
+    if (consume and base is not None and base is cxt_feat._base and base.dim() == 4 and base.is_contiguous()
             and tuple(base.shape) == (n, total, h, w)
             and h_feat.data_ptr() == base.data_ptr()
             and cxt_feat.data_ptr() == base.data_ptr() + hc * h * w * 4

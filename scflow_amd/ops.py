@@ -25,7 +25,7 @@ from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_GRU_Q, CONV_G
 
 Tensor = torch.Tensor
 
-__all__ = ['PackedConv', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision',
+__all__ = ['PackedConv', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision',
            'get_conv_precision', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
            'instance_norm', 'group_norm_relu', 'linear', 'pose_update', 'reproject_flow',
            'unproject_depth', 'resize_bilinear', 'convex_upsample', 'avgpool2x2', 'copy_channels',
@@ -43,6 +43,12 @@ def _dev(t: Tensor, name: str) -> None:
                                   'fallback)')
     if t.dtype != torch.float32:
         raise _lib.ScflowHipError(f'{name}: expected float32, got {t.dtype}')
+    # launches go to the CURRENT device's current stream: a tensor on another GPU would be
+    # touched through peer access (or fault) from the wrong device's stream
+    if t.device.index != torch.cuda.current_device():
+        raise _lib.ScflowHipError(
+            f'{name} lives on cuda:{t.device.index} but the current device is '
+            f'cuda:{torch.cuda.current_device()}: wrap the call in torch.cuda.device(tensor.device)')
 
 
 def _dense(t: Tensor, name: str) -> int:
@@ -125,7 +131,7 @@ def choose_a4_groups(cin: int, kh: int, kw: int, stride: int) -> int:
     return 2 if t <= 5 else 1
 
 
-def pack_conv_weight_a4(weight: Tensor, groups: int, c4: bool = False) -> Tuple[Tensor, int]:
+def pack_conv_weight_a4(weight: Tensor, groups: int) -> Tuple[Tensor, int]:
     """(Cout, Cin, KH, KW) -> [chunk][tap][g][h][Mld][4] (conv_dma.hip): channel
     chunk*8G + 8g + 2s + h at float s of cell (g, h); zero-padded channels and couts."""
     cout, cin, kh, kw = weight.shape
@@ -134,9 +140,6 @@ def pack_conv_weight_a4(weight: Tensor, groups: int, c4: bool = False) -> Tuple[
     mld = (cout + 31) // 32 * 32
     w = torch.zeros((mld, nchunk * kc, t), dtype=torch.float32, device=weight.device)
     w[:cout, :cin] = weight.reshape(cout, cin, t).float()
-    if c4:      # experimental NC/4HW4 inputs: channel chunk*8G + 8g + 4h + s at float s of cell (g, h)
-        w = w.reshape(mld, nchunk, groups, 2, 4, t).permute(1, 5, 2, 3, 0, 4)
-        return w.contiguous().reshape(-1), mld
     # channel index -> (chunk, g, s, h)
     w = w.reshape(mld, nchunk, groups, 4, 2, t).permute(1, 5, 2, 4, 0, 3)
     return w.contiguous().reshape(-1), mld
@@ -318,6 +321,33 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
 _CONV_EVENTS = None
 
 
+def sepconv_gru(packs, hx: Tensor, h_channels: int, z: Tensor, rh: Tensor) -> None:
+    """ConvGRU.forward (raft_decoder.py:235-253) on hx = [h | x], h updated in place:
+    ``scf_sepconv_gru``.  ``packs``: [(PackedConv of cat(conv_z, conv_r), PackedConv of conv_q)]
+    per pass.  With convolution timers armed (bench.py) the same launches are issued one by one
+    through ``conv2d`` so that each carries its own timer."""
+    if _CONV_EVENTS is not None:
+        hv, xv = hx[:, :h_channels], hx[:, h_channels:]
+        for pzr, pq in packs:
+            conv2d(pzr, hx, out=z, mode=CONV_GRU_ZR, gru_h=hv, gru_aux=rh)
+            conv2d(pq, rh, xv, out=hv, mode=CONV_GRU_Q, gru_h=hv, gru_z=z)
+        return
+    p, n, c, h, w, sn = _nchw(hx, 'hx')
+    arr = (_lib.GruPass * len(packs))()
+    f16 = _CONV_PRECISION == 'f16x3'
+    for g, (pzr, pq) in zip(arr, packs):
+        g.KH, g.KW, g.pad_h, g.pad_w = pzr.kh, pzr.kw, pzr.pad_h, pzr.pad_w
+        g.wp_zr, g.bias_zr = pzr.wp.data_ptr(), pzr.bias.data_ptr()
+        g.wp_q, g.bias_q = pq.wp.data_ptr(), pq.bias.data_ptr()
+        if pzr.wp4 is not None and pq.wp4 is not None and pzr.g4 == pq.g4:
+            g.wp_zr_a4, g.wp_q_a4, g.a4_groups = pzr.wp4.data_ptr(), pq.wp4.data_ptr(), pzr.g4
+        if f16 and pzr.wp16 is not None and pq.wp16 is not None:
+            g.wp_zr_f16, g.wp_q_f16 = pzr.wp16.data_ptr(), pq.wp16.data_ptr()
+    _lib.check(_lib.load().scf_sepconv_gru(p, sn, n, h_channels, c - h_channels, h, w, arr, len(packs),
+                                           _dense(z, 'z'), _dense(rh, 'rh'), _stream()),
+               'scf_sepconv_gru')
+
+
 def _read_timers(timers):
     lib = _lib.load()
     out = []
@@ -406,14 +436,11 @@ def corr_lookup(pyramid: Sequence[Tensor], flow: Tensor, radius: int = 4,
     if out is None:
         out = torch.empty((n, k, h, w), dtype=torch.float32, device=flow.device)
     arr = (C.c_void_p * L)(*[_dense(t, 'level') for t in pyramid])
-    if _LOOKUP_EVENTS is not None:      # bench.py: a HIP start/stop event pair bound to this launch
-        lib = _lib.load()
-        tm = C.c_void_p()
-        _lib.check(lib.scf_timer_create(C.byref(tm)), 'scf_timer_create')
-        _lib.check(lib.scf_corr_lookup_timed(arr, pf, _dense(out, 'out'), n, h, w, radius, L,
-                                             1 if level0_tiled else 0, tm, _stream()),
+    if _LOOKUP_TIMERS is not None:      # bench.py: a HIP start/stop event pair bound to this launch
+        _lib.check(_lib.load().scf_corr_lookup_timed(arr, pf, _dense(out, 'out'), n, h, w, radius, L,
+                                                     1 if level0_tiled else 0,
+                                                     _LOOKUP_TIMERS.take(), _stream()),
                    'scf_corr_lookup_timed')
-        _LOOKUP_EVENTS.append(tm)
         return out
     _lib.check(_lib.load().scf_corr_lookup_ex(arr, pf, _dense(out, 'out'), n, h, w, radius, L,
                                               1 if level0_tiled else 0, _stream()),
@@ -421,20 +448,83 @@ def corr_lookup(pyramid: Sequence[Tensor], flow: Tensor, radius: int = 4,
     return out
 
 
-_LOOKUP_EVENTS = None
+class _TimerPool:
+    """launch-bound timers (scf_timer_*), created up front so that a timed loop only takes one
+    from the pool; ``read()`` returns the durations of the timers used since the last reset."""
+
+    def __init__(self, reserve: int) -> None:
+        self.timers, self.used = [], 0
+        self._grow(max(int(reserve), 1))
+
+    def _grow(self, n: int) -> None:
+        lib = _lib.load()
+        for _ in range(n):
+            tm = C.c_void_p()
+            _lib.check(lib.scf_timer_create(C.byref(tm)), 'scf_timer_create')
+            self.timers.append(tm)
+
+    def take(self):
+        if self.used == len(self.timers):     # pool exhausted: grow (outside the fast path by design)
+            self._grow(len(self.timers))
+        tm = self.timers[self.used]
+        self.used += 1
+        return tm
+
+    def read(self):
+        lib = _lib.load()
+        out = []
+        for tm in self.timers[:self.used]:
+            us = C.c_float()
+            _lib.check(lib.scf_timer_elapsed_us(tm, C.byref(us)), 'scf_timer_elapsed_us')
+            out.append(float(us.value))
+        return out
+
+    def reset(self) -> None:
+        self.used = 0
+
+    def destroy(self) -> None:
+        lib = _lib.load()
+        for tm in self.timers:
+            lib.scf_timer_destroy(tm)
+        self.timers, self.used = [], 0
 
 
-def lookup_timing(enable: bool):
+_LOOKUP_TIMERS: Optional[_TimerPool] = None
+
+
+def lookup_timing(enable: bool, reserve: int = 64):
     """enable=True: every corr-lookup launch from now on carries a timer (HIP start / stop events
-    bound to the launch on its stream: the kernel's own duration).  enable=False: stop,
-    synchronise and return the per-launch durations in microseconds."""
-    global _LOOKUP_EVENTS
+    bound to the launch on its stream: the kernel's own duration); ``reserve`` timers are created
+    now, before any timed loop.  enable=False: stop, synchronise and return the per-launch
+    durations in microseconds since the last ``lookup_timing_reset``."""
+    global _LOOKUP_TIMERS
     if enable:
-        _LOOKUP_EVENTS = []
+        if _LOOKUP_TIMERS is not None:
+            _LOOKUP_TIMERS.destroy()
+        _LOOKUP_TIMERS = _TimerPool(reserve)
         return None
-    timers, _LOOKUP_EVENTS = _LOOKUP_EVENTS or [], None
+    pool, _LOOKUP_TIMERS = _LOOKUP_TIMERS, None
+    if pool is None:
+        return []
     torch.cuda.synchronize()
-    return _read_timers(timers)
+    out = pool.read()
+    pool.destroy()
+    return out
+
+
+def lookup_timing_reset() -> None:
+    """forget the launches recorded so far (the timers are reused)."""
+    if _LOOKUP_TIMERS is not None:
+        torch.cuda.synchronize()
+        _LOOKUP_TIMERS.reset()
+
+
+def lookup_timing_read():
+    """synchronise and return the durations (us) recorded since the last reset."""
+    if _LOOKUP_TIMERS is None:
+        return []
+    torch.cuda.synchronize()
+    return _LOOKUP_TIMERS.read()
 
 
 # ------------------------------------------------------------- norms etc.

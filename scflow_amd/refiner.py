@@ -96,7 +96,8 @@ class SCFlowRefiner(HipModule):
             init_flow = torch.zeros((n, 2, H, W), dtype=torch.float32, device=feat_render.device)
         return self.decoder(feat_render, feat_real, h_feat, cxt_feat, ref_rotation,
                             ref_translation, depth.contiguous(), internel_k.contiguous(),
-                            label=label, init_flow=init_flow, invalid_flow_num=0.)
+                            label=label, init_flow=init_flow, invalid_flow_num=0.,
+                            _consume_state=True)      # h / cxt are ours: update them in place
 
     def forward_single_pass(self, data: Dict, data_batch: Optional[Dict] = None,
                             return_loss: bool = False) -> Dict:
@@ -104,6 +105,11 @@ class SCFlowRefiner(HipModule):
         'adapt_intrinsic' pipeline of the config; cv2 EPnP otherwise -- out of scope)."""
         labels = data['labels']
         per_img = data['per_img_patch_num']
+        # the reference's index_select (pose_head.py:209) raises on an out-of-range class id;
+        # the pose-update kernel cannot raise (it clamps), so the check lives at this entry
+        nc = self.decoder.pose_pred.num_class
+        if labels.numel() and (int(labels.min()) < 0 or int(labels.max()) >= nc):
+            raise IndexError(f'label out of range [0, {nc}): min {int(labels.min())}, max {int(labels.max())}')
         iters = self.decoder.iters
         self.decoder.iters = self.test_iter_num
         try:
@@ -156,7 +162,7 @@ class _FlowRefinerBase(HipModule):
         if init_flow is None:
             b, _, h, w = feat_real.shape
             init_flow = torch.zeros((b, 2, h, w), dtype=torch.float32, device=feat_real.device)
-        return self.decoder(feat_render, feat_real, init_flow, h_feat, cxt_feat)
+        return self.decoder(feat_render, feat_real, init_flow, h_feat, cxt_feat, _consume_state=True)
 
     def solve_pose(self, *a, **k):
         raise NotImplementedError('RANSAC-PnP (cv2) pose solve is outside the HIP hot path')

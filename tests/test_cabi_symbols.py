@@ -41,14 +41,45 @@ def test_version_and_error_strings():
 def test_conv_desc_layout_matches_c():
     """sizeof(scf_conv_desc) from a C compile must equal the ctypes mirror."""
     import ctypes, subprocess, tempfile
-    src = '#include "scflow_hip.h"\n#include <stdio.h>\nint main(){printf("%zu\\n", sizeof(scf_conv_desc));return 0;}\n'
+    src = ('#include "scflow_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu\\n", '
+           'sizeof(scf_conv_desc), sizeof(scf_gru_pass));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, 't.c')
         open(c, 'w').write(src)
         exe = os.path.join(d, 't')
         subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe], check=True)
-        size = int(subprocess.run([exe], capture_output=True, text=True, check=True).stdout)
+        size, gsize = map(int, subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split())
     assert size == ctypes.sizeof(_lib.ConvDesc)
+    assert gsize == ctypes.sizeof(_lib.GruPass)
+
+
+def test_c_weight_packers_match_host_packers():
+    """scf_pack_conv_weight / _a4 (what a C or ctypes caller uses) == the torch packers the
+    Python modules use, bit for bit; bad arguments are refused."""
+    import ctypes as C
+    import torch
+    from scflow_amd import ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    for cout, cin, kh, kw in ((40, 20, 3, 3), (256, 384, 1, 5), (33, 70, 5, 1), (2, 3, 7, 7), (64, 64, 1, 1)):
+        w = torch.randn((cout, cin, kh, kw), generator=g).contiguous()
+        for kc in (2, 8, 32):
+            want, mld = ops.pack_conv_weight(w, kc)
+            n = lib.scf_pack_conv_weight_size(cout, cin, kh, kw, kc)
+            assert n == want.numel() and mld == (cout + 31) // 32 * 32
+            out = torch.full((n,), float('nan'))
+            assert lib.scf_pack_conv_weight(w.data_ptr(), cout, cin, kh, kw, kc, out.data_ptr()) == 0
+            assert torch.equal(out, want.reshape(-1))
+        for grp in (1, 2, 4):
+            want, _ = ops.pack_conv_weight_a4(w, grp)
+            n = lib.scf_pack_conv_weight_a4_size(cout, cin, kh, kw, grp)
+            assert n == want.numel()
+            out = torch.full((n,), float('nan'))
+            assert lib.scf_pack_conv_weight_a4(w.data_ptr(), cout, cin, kh, kw, grp, out.data_ptr()) == 0
+            assert torch.equal(out, want.reshape(-1))
+    assert lib.scf_pack_conv_weight_size(4, 4, 3, 3, 5) < 0
+    assert lib.scf_pack_conv_weight_a4_size(4, 4, 3, 3, 3) < 0
+    assert lib.scf_pack_conv_weight(None, 4, 4, 3, 3, 8, None) < 0
 
 
 def test_ops_reject_cpu_tensors():

@@ -426,32 +426,67 @@ def test_conv2d_f16x3_gru_and_segments():
     close(hxd[:, :128], want, atol=3e-5, what='h_new f16x3')
 
 
-def test_conv2d_experimental_c4_layout_matches_nchw():
-    """EXPERIMENTAL scf_conv_desc.in_c4 / out_c4 (channel-interleaved activations, DESIGN.md
-    section 7 lever 1): same numbers as the NCHW path after converting the layout back."""
+# ----------------------------------------------------------- whole GRU cell over the C ABI
+@pytest.mark.parametrize('n,h,w,kind', [(2, 8, 8, 'SeqConv'), (32, 32, 32, 'SeqConv'), (1, 60, 80, 'SeqConv'),
+                                         (2, 16, 16, 'Conv')])
+def test_sepconv_gru_c_entry(n, h, w, kind):
+    """scf_sepconv_gru (ConvGRU.forward, raft_decoder.py:235-253) with weights packed by the C
+    host packers (what INTEGRATION.md's ctypes stub does) == the per-convolution launch sequence
+    bit for bit, and == torch within fp32 round-off."""
     import ctypes as C
     from scflow_amd import _lib
-    n, cin, cout, H, W = 32, 128, 256, 32, 32
-    x, w, b = rnd((n, cin, H, W), 60).to(DEV), rnd((cout, cin, 3, 3), 61, 0.03).to(DEV), rnd((cout,), 62).to(DEV)
-    pc = ops.PackedConv.from_weight(w, b, padding=1)
-    ref = ops.conv2d(pc, x, act=ops.ACT_RELU)
-    w4 = ops.pack_conv_weight_a4(w, pc.g4, c4=True)[0]
-    x4 = x.view(n, cin // 4, 4, H, W).permute(0, 1, 3, 4, 2).contiguous()
-    out4 = torch.empty((n, cout // 4, H, W, 4), device=DEV)
-    d = _lib.ConvDesc()
-    d.in0, d.C0, d.C1, d.in0_nstride = x4.data_ptr(), cin, 0, cin * H * W
-    d.N, d.H, d.W = n, H, W
-    d.wp, d.w_nstride, d.Mld, d.Cout = pc.wp.data_ptr(), 0, pc.mld, cout
-    d.KH, d.KW, d.stride, d.pad_h, d.pad_w, d.KC = 3, 3, 1, 1, 1, pc.kc
-    d.out, d.out_nstride = out4.data_ptr(), cout * H * W
-    d.bias, d.out_div, d.act = b.data_ptr(), 1.0, ops.ACT_RELU
-    d.wp_a4, d.a4_groups, d.a4_mld = w4.data_ptr(), pc.g4, pc.mld
-    d.in_c4, d.out_c4 = 1, 1
-    _lib.check(_lib.load().scf_conv2d(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'c4')
-    got = out4.permute(0, 1, 4, 2, 3).reshape(n, cout, H, W)
-    close(got, ref.cpu(), atol=3e-5, what='c4 layout')
-    # anything the experimental layout does not cover is refused, never silently misread
-    d.act = ops.ACT_SIGMOID
-    assert _lib.load().scf_conv2d(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)) < 0
-    d.act, d.out_c4 = ops.ACT_RELU, 0
-    assert _lib.load().scf_conv2d(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)) < 0
+    lib = _lib.load()
+    ks = {'SeqConv': [((1, 5), (0, 2)), ((5, 1), (2, 0))], 'Conv': [((3, 3), (1, 1))]}[kind]
+    ch, cx = 128, 256
+    hx = rnd((n, ch + cx, h, w), 70)
+    hx[:, :ch] = torch.tanh(hx[:, :ch])
+    want_h, x = hx[:, :ch].clone(), hx[:, ch:]
+    packs, keep = [], []
+    passes = (_lib.GruPass * len(ks))()
+    for i, (g, (k, pad)) in enumerate(zip(passes, ks)):
+        wz, wr, wq = (rnd((ch, ch + cx, *k), 71 + 10 * i + s, 0.03) for s in range(3))
+        bz, br, bq = (rnd((ch,), 74 + 10 * i + s, 0.1) for s in range(3))
+        hxc = torch.cat([want_h, x], 1)
+        z = torch.sigmoid(F.conv2d(hxc, wz, bz, padding=pad))
+        r = torch.sigmoid(F.conv2d(hxc, wr, br, padding=pad))
+        q = torch.tanh(F.conv2d(torch.cat([r * want_h, x], 1), wq, bq, padding=pad))
+        want_h = (1 - z) * want_h + z * q
+        wzr, bzr = torch.cat([wz, wr]).contiguous(), torch.cat([bz, br])
+        packs.append((ops.PackedConv.from_weight(wzr.to(DEV), bzr.to(DEV), padding=pad),
+                      ops.PackedConv.from_weight(wq.to(DEV), bq.to(DEV), padding=pad)))
+        grp = 2 if k[0] * k[1] <= 5 else 1
+        bufs = []
+        for wt in (wzr, wq.contiguous()):
+            co, ci, kh, kw = wt.shape
+            a = torch.empty(lib.scf_pack_conv_weight_size(co, ci, kh, kw, 8))
+            assert lib.scf_pack_conv_weight(wt.data_ptr(), co, ci, kh, kw, 8, a.data_ptr()) == 0
+            b4 = torch.empty(lib.scf_pack_conv_weight_a4_size(co, ci, kh, kw, grp))
+            assert lib.scf_pack_conv_weight_a4(wt.data_ptr(), co, ci, kh, kw, grp, b4.data_ptr()) == 0
+            bufs += [a.to(DEV), b4.to(DEV)]
+        bufs += [bzr.to(DEV), bq.to(DEV)]
+        keep += bufs
+        g.KH, g.KW, g.pad_h, g.pad_w = k[0], k[1], pad[0], pad[1]
+        g.wp_zr, g.wp_zr_a4, g.wp_q, g.wp_q_a4 = (t.data_ptr() for t in bufs[:4])
+        g.bias_zr, g.bias_q, g.a4_groups = bufs[4].data_ptr(), bufs[5].data_ptr(), grp
+    # (a) raw C entry with C-packed weights
+    hxa = hx.to(DEV)
+    za, rha = torch.empty((n, ch, h, w), device=DEV), torch.empty((n, ch, h, w), device=DEV)
+    rc = lib.scf_sepconv_gru(hxa.data_ptr(), hxa.stride(0), n, ch, cx, h, w, passes, len(ks),
+                             za.data_ptr(), rha.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    # (b) ops.sepconv_gru (the modules' path) and (c) the launch-by-launch path (timers armed)
+    hxb, hxc_ = hx.to(DEV), hx.to(DEV)
+    zb, rhb = torch.empty_like(za), torch.empty_like(za)
+    ops.sepconv_gru(packs, hxb, ch, zb, rhb)
+    ops.conv_timing(True)
+    try:
+        ops.sepconv_gru(packs, hxc_, ch, zb, rhb)
+    finally:
+        ops.conv_timing(False)
+    assert torch.equal(hxa, hxb) and torch.equal(hxb, hxc_)
+    close(hxa[:, :ch], want_h, atol=5e-5, what='h_new')
+    close(hxa[:, ch:], x, atol=0, what='x untouched')
+    # argument checks
+    assert lib.scf_sepconv_gru(None, 0, n, ch, cx, h, w, passes, 1, za.data_ptr(), rha.data_ptr(), None) < 0
+    assert lib.scf_sepconv_gru(hxa.data_ptr(), hxa.stride(0), n, 100, cx, h, w, passes, 1, za.data_ptr(),
+                               rha.data_ptr(), None) < 0

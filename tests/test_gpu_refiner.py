@@ -197,3 +197,55 @@ def test_full_refiner_f16x3_epe(golden_dir, model):
     assert worst <= 5e-4, f'EPE {worst:.2e}'
     close(got[2][-1], want[2][-1], atol=1e-5, what='final rotation')
     close(got[3][-1], want[3][-1], atol=2e-2, rtol=5e-5, what='final translation (mm)')
+
+
+def test_decoder_forward_does_not_mutate_its_inputs(golden_dir, model):
+    """the public decoder.forward must leave h_feat / cxt_feat alone (the reference
+    decoder never mutates its inputs): extract_feat once, decode twice -> identical results."""
+    inp = {k: v.to(DEV) for k, v in scflow_amd.make_inputs(2, 256, 256, seed=21).items()}
+    model.decoder.iters = 2
+    fr, fl, hf, cf = model.extract_feat(inp['render_images'], inp['real_images'])
+    h0, c0 = hf.clone(), cf.clone()
+    flow0 = torch.zeros((2, 2, 256, 256), device=DEV)
+    args = (fr, fl, hf, cf, inp['ref_rotation'], inp['ref_translation'], inp['depth'],
+            inp['internel_k'])
+    a = model.decoder(*args, label=inp['label'], init_flow=flow0, invalid_flow_num=0.)
+    assert torch.equal(hf, h0) and torch.equal(cf, c0)
+    b = model.decoder(*args, label=inp['label'], init_flow=flow0, invalid_flow_num=0.)
+    for sa, sb in zip(a, b):
+        for ta, tb in zip(sa, sb):
+            assert torch.equal(ta, tb)
+    # get_pose (which hands its own buffers over) gives the same numbers
+    c = model.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'],
+                       inp['ref_translation'], inp['depth'], inp['internel_k'], inp['label'])
+    for sa, sc in zip(a, c):
+        for ta, tc in zip(sa, sc):
+            assert torch.equal(ta, tc)
+
+
+def test_repacks_after_in_place_weight_change(golden_dir):
+    """kernel-layout weights must follow every way a parameter can change, including
+    param.data.copy_ and a PARENT's load_state_dict (mmcv's load_checkpoint route)."""
+    m = scflow_amd.build_refiner(scflow_amd.scflow_model_cfg(iters=1))
+    sd = scflow_amd.fill_state_dict(_shapes(golden_dir), seed=0)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    inp = {k: v.to(DEV) for k, v in scflow_amd.make_inputs(1, 256, 256, seed=3).items()}
+    run = lambda: m.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'],
+                             inp['ref_translation'], inp['depth'], inp['internel_k'], inp['label'])
+    a = run()[1][-1].clone()
+    sd2 = scflow_amd.fill_state_dict(_shapes(golden_dir), seed=5)
+    wrapper = torch.nn.Sequential(m)                     # a parent module: its loader recurses
+    wrapper.load_state_dict({'0.' + k: v for k, v in sd2.items()}, strict=True)
+    b = run()[1][-1].clone()
+    assert not torch.equal(a, b)
+    ref = scflow_amd.build_refiner(scflow_amd.scflow_model_cfg(iters=1))
+    ref.load_state_dict(sd2, strict=True)
+    ref = ref.to(DEV)
+    want = ref.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'],
+                        inp['ref_translation'], inp['depth'], inp['internel_k'], inp['label'])[1][-1]
+    assert torch.equal(b, want)
+    with torch.no_grad():                                # direct in-place edit of one parameter
+        m.decoder.flow_pred.predict_layer.weight.mul_(0.5)
+    c = run()[1][-1]
+    assert not torch.equal(b, c)

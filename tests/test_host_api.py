@@ -113,11 +113,49 @@ def test_checkpoint_ingestion(tmp_path, golden_dir):
     path = os.path.join(tmp_path, 'ckpt.pth')
     torch.save({'state_dict': mm, 'meta': {}}, path)
     _ = model.render_encoder.packed
-    res = load_checkpoint(model, path, strict=True, from_mmflow=True)
-    assert not res.missing_keys and not res.unexpected_keys
+    missing, unexpected, mismatched = load_checkpoint(model, path, strict=True, from_mmflow=True)
+    assert not missing and not unexpected and not mismatched
     assert model.render_encoder.__dict__['_packed'] is None       # kernel-layout cache dropped
     for k, v in model.state_dict().items():
         assert torch.equal(v, sd[k]), k
+
+
+def test_checkpoint_ingestion_real_raft_layout():
+    """the checkpoint the reference config's init_cfg points at is an mmflow RAFT one:
+    ONE encoder, a 576-channel convex-up-sampling ``mask_pred`` head under the key SCFlow uses
+    for its 1-channel mask head, no pose head / delta-flow / mask encoders.  mmcv's loader (the
+    reference's train.py / test.py) warns and skips; so does load_checkpoint(from_mmflow=True)."""
+    from scflow_amd.checkpoint import load_checkpoint
+    raft = scflow_amd.build_refiner(dict(
+        type='RAFTRefinerFlow', cxt_channels=128, h_channels=128, seperate_encoder=False,
+        encoder=dict(type='RAFTEncoder', in_channels=3, out_channels=256, net_type='Basic',
+                     norm_cfg=dict(type='IN')),
+        cxt_encoder=dict(type='RAFTEncoder', in_channels=3, out_channels=256, net_type='Basic',
+                         norm_cfg=dict(type='BN')),
+        decoder=dict(type='RAFTDecoder', net_type='Basic', num_levels=4, radius=4, iters=12,
+                     corr_lookup_cfg=dict(align_corners=True), gru_type='SeqConv',
+                     act_cfg=dict(type='ReLU'))))
+    rsd = scflow_amd.fill_state_dict({k: v.shape for k, v in raft.state_dict().items()}, seed=4)
+    mm = {k.replace('render_encoder', 'encoder'): v for k, v in rsd.items()
+          if not k.startswith('real_encoder.')}
+    assert mm['decoder.mask_pred.predict_layer.weight'].shape[0] == 576
+    model = scflow_amd.build_refiner(scflow_amd.scflow_model_cfg())
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    with pytest.raises(RuntimeError):                      # torch raises on the size mismatch ...
+        load_checkpoint(model, mm, strict=True, from_mmflow=True)
+    missing, unexpected, mismatched = load_checkpoint(model, mm, from_mmflow=True)   # ... mmcv-like: skip
+    assert sorted(k for k, _, _ in mismatched) == ['decoder.mask_pred.predict_layer.bias',
+                                                   'decoder.mask_pred.predict_layer.weight']
+    assert not unexpected
+    assert all(k.startswith(('decoder.pose_pred.', 'decoder.delta_flow_encoder.', 'decoder.mask_encoder.',
+                             'decoder.mask_pred.predict_layer.')) for k in missing)
+    after = model.state_dict()
+    for k, v in after.items():
+        if k in missing:
+            assert torch.equal(v, before[k]), k             # untouched
+        else:
+            src = k.replace('real_encoder', 'render_encoder')
+            assert torch.equal(v, rsd[src]), k
 
 
 # ------------------------------------------------------------ weight packings (host logic)
@@ -193,9 +231,8 @@ def test_weight_packings_are_permutations_of_the_weights():
             nz = p.reshape(-1)
             assert torch.equal(torch.sort(nz[nz != 0]).values, ref[ref != 0])
         for g in (1, 2, 4):
-            for c4 in (False, True):
-                p, _ = ops.pack_conv_weight_a4(w, g, c4=c4)
-                assert torch.equal(torch.sort(p[p != 0]).values, ref[ref != 0])
+            p, _ = ops.pack_conv_weight_a4(w, g)
+            assert torch.equal(torch.sort(p[p != 0]).values, ref[ref != 0])
         h16 = ops.pack_conv_weight_f16x3(w).float()
         hi, lo = h16[:, 0], h16[:, 1]
         # hi + lo * 2^-11 reproduces every weight to ~22 bits
@@ -203,3 +240,23 @@ def test_weight_packings_are_permutations_of_the_weights():
         assert abs(tot - float(w.abs().sum())) <= 2e-6 * float(w.abs().sum()) + 1e-6
 
     check()
+
+
+def test_packed_weights_follow_every_kind_of_weight_change():
+    """the kernel-layout copy is keyed on (data_ptr, _version) of its source tensors,
+    so in-place edits and a PARENT module's load_state_dict (mmcv's load_checkpoint route, which
+    never calls HipModule.load_state_dict) both invalidate it.  CPU: packing is plain torch."""
+    from scflow_amd.modules import ConvBlock
+    blk = ConvBlock(16, 8, 3, padding=1)
+    p0 = blk.packed
+    assert blk.packed is p0                                  # cached while nothing changes
+    with torch.no_grad():
+        blk.conv.weight.mul_(2.0)                            # in place: _version bumps
+    p1 = blk.packed
+    assert p1 is not p0 and torch.allclose(p1.wp, 2.0 * p0.wp)
+    parent = torch.nn.Sequential(blk)                        # a wrapper's loader recurses past the override
+    parent.load_state_dict({'0.conv.weight': torch.ones(8, 16, 3, 3), '0.conv.bias': torch.zeros(8)})
+    p2 = blk.packed
+    assert p2 is not p1 and float(p2.wp.max()) == 1.0 and float(p2.bias.abs().max()) == 0.0
+    torch.nn.init.constant_(blk.conv.bias, 0.25)
+    assert float(blk.packed.bias.min()) == 0.25

@@ -148,6 +148,35 @@ def test_raft_flow_refiner_480x640_config5(golden_dir):
     _close(occs[-1], wo[-1], atol=1e-4, what='occlusion')
 
 
+@pytest.mark.gpu
+def test_config4_full_size_480x640_12iters_batch8():
+    """BASELINE configs[4] at its stated size: RAFTRefinerFlowMask, 480x640, 12 iterations, batch 8
+    (VERDICT r1 item 2).  (a) N=1 x 12 iterations: parity vs the CPU oracle, EPE <= 1e-3 px;
+    (b) N=8: finite outputs, sample 0 equal to the N=1 run bit for bit (per-sample independence)
+    and batch-permutation equivariance."""
+    m = scflow_amd.build_refiner(scflow_amd.raft_model_cfg(iters=12))
+    sd = scflow_amd.fill_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed=9)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(4)
+    rend, real = torch.rand((8, 3, 480, 640), generator=g), torch.rand((8, 3, 480, 640), generator=g)
+    f1, o1 = m.get_flow(rend[:1].to(DEV), real[:1].to(DEV))
+    assert len(f1) == 12 and f1[-1].shape == (1, 2, 480, 640) and o1[-1].shape == (1, 1, 480, 640)
+    with torch.no_grad():
+        fr, fl, hf, cf = oracle.extract_feat(rend[:1], real[:1], sd)
+        wf, wo = oracle.raft_decoder_mask(fr, fl, torch.zeros((1, 2, 60, 80)), hf, cf, sd, iters=12)
+    for it in (0, 5, 11):
+        epe = oracle.end_point_error(f1[it].cpu(), wf[it])
+        assert epe <= 1e-3, f'iter {it}: EPE {epe:.2e}'
+    _close(o1[-1], wo[-1], atol=2e-4, what='occlusion')
+    f8, o8 = m.get_flow(rend.to(DEV), real.to(DEV))
+    assert f8[-1].shape == (8, 2, 480, 640) and bool(torch.isfinite(f8[-1]).all()) and bool(torch.isfinite(o8[-1]).all())
+    assert torch.equal(f8[-1][:1], f1[-1]) and torch.equal(o8[-1][:1], o1[-1])
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4])
+    fp, op = m.get_flow(rend[perm].to(DEV), real[perm].to(DEV))
+    assert torch.equal(fp[-1], f8[-1][perm.to(DEV)]) and torch.equal(op[-1], o8[-1][perm.to(DEV)])
+
+
 # ------------------------------------------------ ground-truth flow generation (8(f) row 3)
 def test_oracle_gt_flow_matches_reference_fixture(golden_dir):
     g = np.load(os.path.join(golden_dir, 'gt_flow.npz'))
