@@ -184,11 +184,17 @@ class BlockTimer:
     def run(self, before_block=None, after_block=None):
         t0 = time.perf_counter()
         done = 0
-        while done < self.warmup or (time.perf_counter() - t0) < self.min_warmup_seconds:
+        for _ in range(self.warmup):
             self.step()
             done += 1
-            if done >= self.warmup and done % 4 == 0:
-                self.fence()                 # keep the host from running far ahead of the clock
+        # time-based part: every rank must run the SAME number of steps (a step may contain a
+        # collective), so the decision to continue is itself all-reduced, once per 4 steps
+        self.fence()
+        while self.allmax(time.perf_counter() - t0) < self.min_warmup_seconds:
+            for _ in range(4):
+                self.step()
+                done += 1
+            self.fence()                     # also keeps the host from running far ahead
         self.fence()
         blocks, total = [], 0.0
         while True:
@@ -485,8 +491,13 @@ def main():
                 'note': f'2*C*(h*w)^2 flops per pair, C=256, h=w=32, {args.batch} pairs; the launch also '
                         'writes the 4*(h*w)^2 B volume per pair'}
         if conv_launches:
-            c_us = sum(u for u, _ in conv_launches)
-            c_fl = sum(f for _, f in conv_launches)
+            c_us = sum(e[0] for e in conv_launches)
+            c_fl = sum(e[1] for e in conv_launches)
+            by_shape = {}
+            for us, fl, tag in conv_launches:
+                a = by_shape.setdefault(tag, [0, 0.0, 0.0])
+                a[0] += 1; a[1] += us; a[2] += fl
+            top = sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:14]
             result['roofline_conv'] = {
                 'kernel': 'conv_dma_kernel / conv_mfma_kernel (all convolution launches of one step)',
                 'bound': 'mfma', 'achieved': round(c_fl / (c_us * 1e-6) / 1e12, 1),
@@ -495,6 +506,8 @@ def main():
                 'launches_timed': len(conv_launches), 'conv_us_per_step': round(c_us, 1),
                 'share_of_step': round(c_us * 1e-6 / (dt / args.steps), 3),
                 'algorithmic_flops_per_step': c_fl,
+                'top_layers': [{'layer': k, 'launches': v[0], 'us': round(v[1], 1),
+                                'tflops': round(v[2] / v[1] / 1e6, 1)} for k, v in top],
                 'note': 'v_mfma_f32_32x32x2_f32 (exact fp32), dense peak 256 CU x 256 flop/clk x 2.4 GHz; '
                         'flops = 2*Cin*KH*KW*Cout*Ho*Wo*N per launch; HIP start/stop events bound to each launch'}
 

@@ -177,6 +177,9 @@ int scf_pack_conv_weight_a4(const float* w, int Cout, int Cin, int KH, int KW, i
  *   wp_q  : KC = 8 packing of conv_q.weight (Ch, Ch+Cx, KH, KW);  bias_zr [2*Ch], bias_q [Ch]
  *   wp_*_a4 (+ a4_groups: 2 for (1,5)/(5,1), 1 for 3x3) select the LDS-DMA kernel (optional, faster)
  *   wp_*_f16 select the split-fp16 3xMFMA kernel (optional, see scf_conv_desc.wp_f16)
+ *   wp_*_k32 : KC = 32 packings of the same tensors (optional): used instead of the KC = 8 ones
+ *              when the grid is so small (batch 1) that the register-staged kernel with its
+ *              smallest tile runs and an 8-channel chunk is too short to hide its prefetch
  * --------------------------------------------------------------------------------- */
 typedef struct scf_gru_pass {
   int32_t KH, KW, pad_h, pad_w;
@@ -184,6 +187,7 @@ typedef struct scf_gru_pass {
   const float* wp_q; const float* bias_q;
   const float* wp_zr_a4; const float* wp_q_a4; int32_t a4_groups;
   const void* wp_zr_f16; const void* wp_q_f16;
+  const float* wp_zr_k32; const float* wp_q_k32;
 } scf_gru_pass;
 
 int scf_sepconv_gru(float* hx, int64_t hx_nstride, int N, int Ch, int Cx, int H, int W,

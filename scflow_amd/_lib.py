@@ -55,6 +55,7 @@ class GruPass(C.Structure):
         ('wp_zr', _fp), ('bias_zr', _fp), ('wp_q', _fp), ('bias_q', _fp),
         ('wp_zr_a4', _fp), ('wp_q_a4', _fp), ('a4_groups', C.c_int32),
         ('wp_zr_f16', _fp), ('wp_q_f16', _fp),
+        ('wp_zr_k32', _fp), ('wp_q_k32', _fp),
     ]
 
 

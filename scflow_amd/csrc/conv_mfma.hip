@@ -565,6 +565,21 @@ extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
 // convolution (epilogue: z -> z buffer, r*h -> rh buffer) and the q convolution (epilogue:
 // tanh + state update in place).
 // ---------------------------------------------------------------------------------
+extern "C" int scf_conv2d_query(const scf_conv_desc* d, int32_t* info);
+
+// Short-chunk regime (the register-staged kernel with its smallest tile, WM = WN = 1): with KC = 8
+// the MFMA phase of a chunk is shorter than the L2 round trip its prefetch has to hide, so the
+// KC = 32 packing is used when the caller provides one and it fits (same rule as ops.conv2d).
+static void gru_choose_packing(scf_conv_desc& d, const float* wp8, const float* wp32) {
+  d.wp = wp8; d.KC = 8;
+  if (!wp32 || (d.C1 > 0 && (d.C0 % 32) != 0)) return;
+  int32_t info[4];
+  if (scf_conv2d_query(&d, info) == SCF_OK && info[0] * info[1] == 1 && info[3] >= 0 && info[3] * 64 < 6000) {
+    d.wp = wp32; d.KC = 32;
+    if (scf_conv2d_query(&d, info) != SCF_OK) { d.wp = wp8; d.KC = 8; }
+  }
+}
+
 extern "C" int scf_sepconv_gru(float* hx, int64_t hx_nstride, int N, int Ch, int Cx, int H, int W,
                                const scf_gru_pass* passes, int npass, float* z, float* rh,
                                scf_stream_t stream) {
@@ -582,22 +597,24 @@ extern "C" int scf_sepconv_gru(float* hx, int64_t hx_nstride, int N, int Ch, int
     d.out_div = 1.f;
     // z | r = sigmoid(conv([h | x])): z -> z, r*h -> rh
     d.in0 = hx; d.C0 = Ch + Cx; d.in0_nstride = hx_nstride;
-    d.wp = g.wp_zr; d.Mld = (2 * Ch + 31) / 32 * 32; d.Cout = 2 * Ch; d.bias = g.bias_zr;
+    d.Mld = (2 * Ch + 31) / 32 * 32; d.Cout = 2 * Ch; d.bias = g.bias_zr;
     d.wp_a4 = g.wp_zr_a4; d.a4_groups = g.a4_groups; d.a4_mld = d.Mld; d.wp_f16 = g.wp_zr_f16;
     d.out = z; d.out_nstride = Ch * hw;
     d.mode = SCF_CONV_GRU_ZR; d.gru_h = hx; d.gru_h_nstride = hx_nstride;
     d.gru_aux = rh; d.gru_aux_nstride = Ch * hw;
+    gru_choose_packing(d, g.wp_zr, g.wp_zr_k32);
     int rc = scf_conv2d(&d, stream);
     if (rc != SCF_OK) return rc;
     // q = tanh(conv([r*h | x])); h <- (1 - z) h + z q
     d.in0 = rh; d.C0 = Ch; d.in0_nstride = Ch * hw;
     d.in1 = hx + (int64_t)Ch * hw; d.C1 = Cx; d.in1_nstride = hx_nstride;
-    d.wp = g.wp_q; d.Mld = (Ch + 31) / 32 * 32; d.Cout = Ch; d.bias = g.bias_q;
+    d.Mld = (Ch + 31) / 32 * 32; d.Cout = Ch; d.bias = g.bias_q;
     d.wp_a4 = g.wp_q_a4; d.a4_mld = d.Mld; d.wp_f16 = g.wp_q_f16;
     d.out = hx; d.out_nstride = hx_nstride;
     d.mode = SCF_CONV_GRU_Q; d.gru_h = hx; d.gru_h_nstride = hx_nstride;
     d.gru_aux = nullptr; d.gru_aux_nstride = 0;
     d.gru_z = z; d.gru_z_nstride = Ch * hw;
+    gru_choose_packing(d, g.wp_q, g.wp_q_k32);
     rc = scf_conv2d(&d, stream);
     if (rc != SCF_OK) return rc;
   }
@@ -638,6 +655,8 @@ extern "C" int scf_conv2d_query(const scf_conv_desc* d, int32_t* info) {
 // ---------------------------------------------------------------------------------
 extern "C" int scf_avgpool2x2_tiled_in(const float* x, float* out, int64_t planes, int Hin, int Win,
                                        scf_stream_t stream);
+int scf_corr_gemm_dispatch(const float* feat1, const float* feat2, float* lvl0, float* lvl1, int N, int C,
+                           int h, int w, int tiled, hipStream_t st);
 
 extern "C" int scf_corr_build_ex(const float* feat1, const float* feat2, float* const* levels, int N,
                                  int C, int h, int w, int L, int level0_tiled, scf_stream_t stream) {
@@ -647,6 +666,28 @@ extern "C" int scf_corr_build_ex(const float* feat1, const float* feat2, float* 
   for (int l = 0; l < L; ++l)
     if (!levels[l]) return SCF_EINVAL;
   const int hw = h * w;
+  // dedicated GEMM kernel (corr_gemm.hip): level 0, and level 1 from the same fragments when the
+  // tiled layout is used; generic shapes fall through to the convolution kernel + separate pools
+  {
+    float* l1 = (level0_tiled && L >= 2 && h >= 2 && w >= 2) ? levels[1] : nullptr;
+    int rg = scf_corr_gemm_dispatch(feat1, feat2, levels[0], l1, N, C, h, w, level0_tiled, scf_stream(stream));
+    if (rg == SCF_OK) {
+      int lh = h, lw = w;
+      for (int l = 1; l < L; ++l) {
+        if (lh < 2 || lw < 2) return SCF_EINVAL;
+        if (!(l == 1 && l1)) {
+          rg = (l == 1 && level0_tiled)
+                   ? scf_avgpool2x2_tiled_in(levels[0], levels[1], (int64_t)N * hw, lh, lw, stream)
+                   : scf_avgpool2x2(levels[l - 1], levels[l], (int64_t)N * hw, lh, lw, stream);
+          if (rg != SCF_OK) return rg;
+        }
+        lh /= 2;
+        lw /= 2;
+      }
+      return SCF_OK;
+    }
+    if (rg != SCF_EUNSUPPORTED) return rg;
+  }
   scf_conv_desc d = {};
   d.in0 = feat2; d.C0 = C; d.in0_nstride = (int64_t)C * hw;
   d.N = N; d.H = h; d.W = w;

@@ -484,6 +484,21 @@ static int lookup_launch(const float* const* levels, const float* flow, float* o
     return scf_launch_status();
   }
 #endif
+#ifdef SCF_LOOKUP_EXPERIMENT      /* TEMPORARY (never in the product build): store policy A/B inside the pipeline */
+  {
+    static const int sm = [] { const char* e = getenv("SCF_LK_SM"); return e ? atoi(e) : -1; }();
+    if (sm >= 0 && r == 4 && level0_tiled) {
+      switch (sm) {
+        case 0: SCF_LK2(4, true, 0); break;
+        case 1: SCF_LK2(4, true, 1); break;
+        case 2: SCF_LK2(4, true, 2); break;
+        case 3: SCF_LK2(4, true, 3); break;
+        default: SCF_LK2(4, true, 4); break;
+      }
+      return scf_launch_status();
+    }
+  }
+#endif
   switch (r) {
     SCF_LK(4) SCF_LK(3) SCF_LK(2) SCF_LK(1)
     default: return SCF_EUNSUPPORTED;

@@ -321,6 +321,9 @@ class ConvGRU(HipModule):
             for k, p in zip(self._kernel[net_type], self._padding[net_type])])
         self.conv_z, self.conv_r, self.conv_q = mk('Sigmoid'), mk('Sigmoid'), mk('Tanh')
 
+    def _pack_sources(self):          # the packing reads the ConvBlock children's tensors
+        return [t for m in (*self.conv_z, *self.conv_r, *self.conv_q) for t in (m.conv.weight, m.conv.bias)]
+
     def _pack(self):
         packs = []
         for z, r, q in zip(self.conv_z, self.conv_r, self.conv_q):
@@ -470,6 +473,10 @@ class SCFlowDecoder(HipModule):
         self.mask_encoder = nn.Sequential(ConvBlock(1, 64, 3, padding=1, act_cfg=act_cfg),
                                           ConvBlock(64, 32, 3, padding=1, act_cfg=act_cfg))
         self.tiled_level0 = True      # decoder-internal pyramid layout (see _use_tiled_level0)
+
+    def _pack_sources(self):
+        a, b = self.flow_pred.layers[0].conv, self.mask_pred.layers[0].conv
+        return [a.weight, a.bias, b.weight, b.bias]
 
     def _pack(self):
         # the two XHead hidden layers read the same h: one 512-row convolution

@@ -312,7 +312,8 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
             _lib.check(lib.scf_conv2d(C.byref(d), _stream()), 'scf_conv2d')
         finally:
             lib.scf_timer_arm(None)
-        _CONV_EVENTS.append((tm, 2.0 * pc.cin * pc.kh * pc.kw * pc.cout * ho * wo * n))
+        _CONV_EVENTS.append((tm, 2.0 * pc.cin * pc.kh * pc.kw * pc.cout * ho * wo * n,
+                             f'{pc.cin}->{pc.cout} {pc.kh}x{pc.kw}/s{pc.stride} @{ho}x{wo} N{n}'))
         return out
     _lib.check(_lib.load().scf_conv2d(C.byref(d), _stream()), 'scf_conv2d')
     return out
@@ -343,6 +344,8 @@ def sepconv_gru(packs, hx: Tensor, h_channels: int, z: Tensor, rh: Tensor) -> No
             g.wp_zr_a4, g.wp_q_a4, g.a4_groups = pzr.wp4.data_ptr(), pq.wp4.data_ptr(), pzr.g4
         if f16 and pzr.wp16 is not None and pq.wp16 is not None:
             g.wp_zr_f16, g.wp_q_f16 = pzr.wp16.data_ptr(), pq.wp16.data_ptr()
+        if pzr.wp_alt is not None and pq.wp_alt is not None:
+            g.wp_zr_k32, g.wp_q_k32 = pzr.wp_alt.data_ptr(), pq.wp_alt.data_ptr()
     _lib.check(_lib.load().scf_sepconv_gru(p, sn, n, h_channels, c - h_channels, h, w, arr, len(packs),
                                            _dense(z, 'z'), _dense(rh, 'rh'), _stream()),
                'scf_sepconv_gru')
@@ -361,14 +364,14 @@ def _read_timers(timers):
 
 def conv_timing(enable: bool):
     """like ``lookup_timing`` for the convolution launches: enable=False returns a list of
-    (microseconds, algorithmic flops = 2*Cin*KH*KW*Cout*Ho*Wo*N) per launch."""
+    (microseconds, algorithmic flops = 2*Cin*KH*KW*Cout*Ho*Wo*N, shape tag) per launch."""
     global _CONV_EVENTS
     if enable:
         _CONV_EVENTS = []
         return None
     evs, _CONV_EVENTS = _CONV_EVENTS or [], None
     torch.cuda.synchronize()
-    return list(zip(_read_timers([t for t, _ in evs]), [fl for _, fl in evs]))
+    return list(zip(_read_timers([e[0] for e in evs]), [e[1] for e in evs], [e[2] for e in evs]))
 
 
 def time_first_kernel(fn) -> float:

@@ -464,6 +464,12 @@ def test_sepconv_gru_c_entry(n, h, w, kind):
             assert lib.scf_pack_conv_weight_a4(wt.data_ptr(), co, ci, kh, kw, grp, b4.data_ptr()) == 0
             bufs += [a.to(DEV), b4.to(DEV)]
         bufs += [bzr.to(DEV), bq.to(DEV)]
+        for wt in (wzr, wq.contiguous()):                 # KC = 32 packings (small-grid regime)
+            co, ci, kh, kw = wt.shape
+            a32 = torch.empty(lib.scf_pack_conv_weight_size(co, ci, kh, kw, 32))
+            assert lib.scf_pack_conv_weight(wt.data_ptr(), co, ci, kh, kw, 32, a32.data_ptr()) == 0
+            bufs.append(a32.to(DEV))
+        g.wp_zr_k32, g.wp_q_k32 = bufs[6].data_ptr(), bufs[7].data_ptr()
         keep += bufs
         g.KH, g.KW, g.pad_h, g.pad_w = k[0], k[1], pad[0], pad[1]
         g.wp_zr, g.wp_zr_a4, g.wp_q, g.wp_q_a4 = (t.data_ptr() for t in bufs[:4])
@@ -483,7 +489,10 @@ def test_sepconv_gru_c_entry(n, h, w, kind):
         ops.sepconv_gru(packs, hxc_, ch, zb, rhb)
     finally:
         ops.conv_timing(False)
-    assert torch.equal(hxa, hxb) and torch.equal(hxb, hxc_)
+    da, db, dc = (float((t[:, :ch].cpu() - want_h).abs().max()) for t in (hxa, hxb, hxc_))
+    assert torch.equal(hxa, hxb) and torch.equal(hxb, hxc_), \
+        f'max |h - torch|: C entry/C packers {da:.2e}, ops.sepconv_gru {db:.2e}, launch by launch {dc:.2e}; ' \
+        f'|b - c| {float((hxb - hxc_).abs().max()):.2e}'
     close(hxa[:, :ch], want_h, atol=5e-5, what='h_new')
     close(hxa[:, ch:], x, atol=0, what='x untouched')
     # argument checks

@@ -260,3 +260,22 @@ def test_packed_weights_follow_every_kind_of_weight_change():
     assert p2 is not p1 and float(p2.wp.max()) == 1.0 and float(p2.bias.abs().max()) == 0.0
     torch.nn.init.constant_(blk.conv.bias, 0.25)
     assert float(blk.packed.bias.min()) == 0.25
+
+
+def test_composite_modules_repack_when_a_child_block_changes():
+    """the GRU (stacked z|r weights) and the decoder (stacked flow|mask head) pack tensors that live
+    in ConvBlock children: their cache key must cover those tensors too."""
+    from scflow_amd.modules import ConvGRU
+    gru = ConvGRU(16, 32, 'SeqConv')
+    p0 = gru.packed
+    assert gru.packed is p0
+    with torch.no_grad():
+        gru.conv_r[1].conv.weight.zero_()
+    p1 = gru.packed
+    assert p1 is not p0 and float(p1[1][0].wp.abs().sum()) < float(p0[1][0].wp.abs().sum())
+    dec = scflow_amd.build_decoder(scflow_amd.scflow_model_cfg()['decoder'])
+    h0 = dec.packed
+    with torch.no_grad():
+        dec.mask_pred.layers[0].conv.bias.fill_(3.0)
+    h1 = dec.packed
+    assert h1 is not h0 and float(h1.bias[256:].min()) == 3.0 and float(h1.bias[:256].max()) < 3.0
