@@ -79,11 +79,35 @@ __device__ __forceinline__ int fast_div(int e, int d, float rd) {
   return q;
 }
 
-template <int WM, int WN>
+// s_waitcnt vmcnt(n) for a wave-uniform RUN-TIME n (the instruction takes an immediate)
+template <int V>
+__device__ __forceinline__ void wait_vmcnt_imm() {
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (V & 15) | ((V >> 4) << 14));
+}
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+#define SCF_W4(b) case b: wait_vmcnt_imm<b>(); break; case b + 1: wait_vmcnt_imm<b + 1>(); break; \
+                  case b + 2: wait_vmcnt_imm<b + 2>(); break; case b + 3: wait_vmcnt_imm<b + 3>(); break;
+  switch (n) {
+    SCF_W4(0) SCF_W4(4) SCF_W4(8) SCF_W4(12) SCF_W4(16) SCF_W4(20) SCF_W4(24) SCF_W4(28)
+    SCF_W4(32) SCF_W4(36) SCF_W4(40) SCF_W4(44) SCF_W4(48) SCF_W4(52) SCF_W4(56) SCF_W4(60)
+    default: wait_vmcnt_imm<0>(); break;
+  }
+#undef SCF_W4
+}
+
+// NST   : chunk buffers in the LDS ring.  2 = chunk c+1 streams in while chunk c is on the matrix
+//         cores (large grids: co-resident blocks hide each other's latency).  Small grids (batch 1:
+//         one block per CU, nothing else to hide a ~2 us memory round trip per chunk) use a deeper
+//         ring: NST-1 chunks in flight per block.
+// KSP   : K-split tile for small grids: 32 channels x ONE 32-pixel fragment per block (4x the
+//         blocks of the smallest pixel-split tile); the four waves take every fourth (tap, group)
+//         step of each chunk and combine their partial sums through LDS in a fixed order.
+template <int WM, int WN, int NST = 2, bool KSP = false>
 __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  static_assert(!KSP || (WM == 1 && WN == 1), "K-split tile is one 32x32 fragment");
   constexpr int BM = WM * 32;
-  constexpr int NFRAG = WN * 4;
+  constexpr int NFRAG = KSP ? 1 : WN * 4;
   constexpr int PU = SCF_DMA_PU;
 
   __builtin_amdgcn_s_setprio(3);       // setup / staging / epilogue instructions go first
@@ -117,8 +141,8 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   const int PE = KC * PHW;             // patch floats per chunk
   const int bufsz = WF4 * 4 + PE;      // floats per buffer (multiple of 4)
 
-  // ---- zero both patch areas (padding positions stay zero for the whole kernel) ----
-  for (int b = 0; b < 2; ++b) {
+  // ---- zero every patch area (padding positions stay zero for the whole kernel) ----
+  for (int b = 0; b < NST; ++b) {
     f32x4* z = reinterpret_cast<f32x4*>(lds + b * bufsz + WF4 * 4);
     for (int i = tid; i < PE / 4; i += 256) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -160,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   const int fr = l32 >> p.fc_log2, fc = l32 & (FC - 1);
   int boff[WN];                        // float4 index of this lane's pixel, fragment j, tap (0,0)
 #pragma unroll
-  for (int j = 0; j < WN; ++j) boff[j] = ((wave * WN + j) * FR + fr) * st * PW + fc + half * PHW;
+  for (int j = 0; j < WN; ++j) boff[j] = ((KSP ? 0 : (wave * WN + j)) * FR + fr) * st * PW + fc + half * PHW;
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -209,18 +233,48 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
       if (u < nwu) dma_b128_v(wsrc, woff[u], lds_addr(wb + (u * 256 + wave * 64) * 4));
   };
 
-  __syncthreads();                     // zero fill complete before any DMA data can land
-  stage(0, 0);
+  // DMA instructions this wave issues per chunk (the same for every chunk): vmcnt bookkeeping
+  const int cnt = __builtin_amdgcn_readfirstlane(((PE + 255) >> 8) + ((WF4 + 255) >> 8));
 
+  __syncthreads();                     // zero fill complete before any DMA data can land
+#pragma unroll
+  for (int c = 0; c < NST - 1; ++c)
+    if (c < p.nchunk) stage(c, c);
+
+  int buf = 0;                         // ring slot of the current chunk
   for (int chunk = 0; chunk < p.nchunk; ++chunk) {
     __builtin_amdgcn_s_setprio(3);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's DMA has landed
+    // this wave's DMA of THIS chunk has landed; up to NST-2 later chunks stay in flight
+    if (NST == 2) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
+    } else {
+      const int later = min(NST - 2, p.nchunk - 1 - chunk);
+      wait_vmcnt_le(later * cnt);
+    }
     __syncthreads();                                   // everyone's has; previous MFMA phase done
-    if (chunk + 1 < p.nchunk) stage(chunk + 1, (chunk + 1) & 1);
+    if (chunk + NST - 1 < p.nchunk) stage(chunk + NST - 1, buf == 0 ? NST - 1 : buf - 1);
     __builtin_amdgcn_s_setprio(0);                     // the MFMA stream yields to the other waves
 
-    const f32x4* wl = reinterpret_cast<const f32x4*>(lds + (chunk & 1) * bufsz) + half * BM + l32;
-    const f32x4* pl = reinterpret_cast<const f32x4*>(lds + (chunk & 1) * bufsz + WF4 * 4);
+    const f32x4* wl = reinterpret_cast<const f32x4*>(lds + buf * bufsz) + half * BM + l32;
+    const f32x4* pl = reinterpret_cast<const f32x4*>(lds + buf * bufsz + WF4 * 4);
+    if (++buf == NST) buf = 0;
+    if (KSP) {
+      // wave w takes the (tap, group) steps it == w (mod 4): one ds_read_b128 pair feeds 4 MFMAs
+      // G is 1, 2 or 4: four steps ahead is the same group g, 4 / G taps further
+      const int gshift = G == 4 ? 2 : G == 2 ? 1 : 0, g = wave & (G - 1), tstep = 4 >> gshift;
+      int ky = 0, kx = wave >> gshift;
+      while (kx >= p.KW) { kx -= p.KW; ++ky; }
+      for (int it = wave; it < NIT; it += 4) {
+        const f32x4 aa = wl[it * 2 * BM];
+        const f32x4 bb = pl[g * 2 * PHW + ky * PW + (st == 1 ? kx : (kx & 1) * PWh + (kx >> 1)) + boff[0]];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[s4], bb[s4], acc[0][0], 0, 0, 0);
+        kx += tstep;
+        while (kx >= p.KW) { kx -= p.KW; ++ky; }
+      }
+      continue;
+    }
     f32x4 a[2][WM], b[2][WN];
     int lg = 0, lky = 0, lkx = 0;                     // (tap, group) of the next operand load
     auto load = [&](f32x4 (&aa)[WM], f32x4 (&bb)[WN], int it) {
@@ -255,6 +309,33 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
     }
   }
 
+  if (KSP) {
+    // ---- cross-wave reduction (fixed order) + epilogue: wave w finalises accumulator rows 4w..4w+3 ----
+    __builtin_amdgcn_s_setprio(3);
+    __syncthreads();                          // every wave is done reading the ring
+    float* red = lds;                         // [4 waves][16 regs][64 lanes] = 16 KB
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[0][0][r];
+    __syncthreads();
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = 4 * wave + q;
+      v[q] = ((red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) +
+              red[(2 * 16 + r) * 64 + lane]) + red[(3 * 16 + r) * 64 + lane];
+    }
+    const int oy = ty0 + fr, ox = tx0 + fc;
+    if (oy < p.Ho && ox < p.Wo) {
+      const ConvEpi epi = scf_conv_epi(p, n);
+      const int pixk = p.out_tile ? (((oy >> 2) * (p.Wo >> 3) + (ox >> 3)) * 32 + (oy & 3) * 8 + (ox & 7))
+                                  : oy * p.Wo + ox;
+      // accumulator register r <-> channel row (r & 3) + 8 (r >> 2) + 4 half: registers 4w..4w+3 are
+      // the four consecutive rows 8w + 4 half .. + 3
+      scf_conv_epilogue_group(p, epi, v, m0 + 8 * wave + 4 * half, pixk, p.out_div != 1.0f);
+    }
+    return;
+  }
+
   // ---- epilogue: C/D layout col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*half ----
   __builtin_amdgcn_s_setprio(3);
   const ConvEpi epi = scf_conv_epi(p, n);
@@ -271,7 +352,9 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   scf_conv_epilogue_tile<WM, WN>(p, epi, acc, m0, half, pix, use_div);
 }
 
-template <int WM, int WN>
+#define SCF_DMA_LDS_DEEP (144 * 1024)  // deep rings on small grids: one block per CU
+
+template <int WM, int WN, int NST = 2, bool KSP = false>
 static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
   if (lds_bytes > 64 * 1024) {       // opt in to > 64 KiB of dynamic LDS: once per instantiation AND device
     static std::atomic<unsigned long long> raised{0};      // bit d: done on device d
@@ -279,19 +362,23 @@ static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st
     if (hipGetDevice(&dev) != hipSuccess) return SCF_ELAUNCH;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(raised.load(std::memory_order_relaxed) & bit)) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WM, WN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, SCF_DMA_LDS_MAX) != hipSuccess)
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WM, WN, NST, KSP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              NST == 2 ? SCF_DMA_LDS_MAX : SCF_DMA_LDS_DEEP) != hipSuccess)
         return SCF_ELAUNCH;
       raised.fetch_or(bit, std::memory_order_relaxed);
     }
   }
-  scf_launch((conv_dma_kernel<WM, WN>), dim3(nblk), dim3(256), lds_bytes, st, k);
+  scf_launch((conv_dma_kernel<WM, WN, NST, KSP>), dim3(nblk), dim3(256), lds_bytes, st, k);
   return scf_launch_status();
 }
 
 // Tile selection + launch.  k comes from conv_plan() (geometry fields are overwritten here).
-// SCF_EUNSUPPORTED -> the caller falls back to the register-staged kernel (strided layers,
-// thin inputs, tiny grids, shapes that exceed the DMA kernel's staging budget).
+// SCF_EUNSUPPORTED -> the caller falls back to the register-staged kernel (thin inputs, 7x7,
+// shapes that exceed the DMA kernel's staging budget).
+//   large grids  (>= 512 blocks): pixel-split tiles, double buffer (co-resident blocks overlap)
+//   small grids  : the same tiles with a 4-deep ring while they still give >= 256 blocks, else
+//                  the K-split tile (32 channels x 32 pixels) with a ring as deep as LDS allows
 int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st) {
   if (!k.wp4 || (k.stride != 1 && k.stride != 2) || k.w_ns != 0) return SCF_EUNSUPPORTED;
   const int G = k.G4;
@@ -325,19 +412,67 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
       if (blk >= 512) break;
     }
   }
-  if (best < 0 || best_blk < 256 || best_blk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
-  const int WM = cand[best][0], WN = cand[best][1];
-  const int TR = WN * 4 * FR;
-  k.PH = (TR - 1) * k.stride + k.KH;
+  const bool large = best >= 0 && best_blk >= 512;
+#ifdef SCF_NO_SMALL_GRID           /* experiment builds only: round-1 behaviour */
+  if (best < 0 || best_blk < 256 || k.T == 1) return SCF_EUNSUPPORTED;
+#endif
+  if (k.T == 1 && large) return SCF_EUNSUPPORTED;     // dense 1x1 on a full grid: the KC = 32 register-staged
+                                                      // kernel is faster (chunks too short for this pipeline)
+  k.nchunk = (k.Cin + KC - 1) / KC;
+  int WM = 1, WN = 1, NST = 2;
+  bool ksp = false;
+  long long nblk = 0;
+  size_t ldsb = 0;
+  if (best >= 0 && best_blk >= 256) {                  // pixel-split tile
+    WM = cand[best][0]; WN = cand[best][1];
+    nblk = best_blk;
+    ldsb = best_lds;
+    if (!large) {                                      // small grid: deeper ring when it fits one block per CU
+      if (best_lds * 2 <= SCF_DMA_LDS_DEEP && k.nchunk >= 4) { NST = 4; ldsb = best_lds * 2; }
+      else if (best_lds / 2 * 3 <= SCF_DMA_LDS_DEEP && k.nchunk >= 3) { NST = 3; ldsb = best_lds / 2 * 3; }
+      if (!((WM == 1 && WN == 1) || (WM == 2 && WN == 1))) {       // deep rings are instantiated for these tiles
+        NST = 2; ldsb = best_lds;
+      }
+    }
+    const int TR = WN * 4 * FR;
+    k.PH = (TR - 1) * k.stride + k.KH;
+    k.tiles_y = (k.Ho + TR - 1) / TR;
+  } else {                                             // K-split tile: one 32-pixel fragment per block
+    const int PH = (FR - 1) * k.stride + k.KH, PWin = (FC - 1) * k.stride + k.KW;
+    const int PW = k.stride == 1 ? PWin : ((PWin + 1) / 2) * 2;
+    const long long PE = (long long)KC * PH * PW, WF4 = (long long)k.T * G * 2 * 32;
+    if (PE > 256 * SCF_DMA_PU || WF4 > 256 * 7) return SCF_EUNSUPPORTED;
+    const size_t stage_b = (size_t)(WF4 * 4 + PE) * sizeof(float);
+    NST = k.nchunk >= 6 && stage_b * 6 <= SCF_DMA_LDS_DEEP ? 6 : k.nchunk >= 4 && stage_b * 4 <= SCF_DMA_LDS_DEEP ? 4 : 2;
+    ldsb = stage_b * NST;
+    if (ldsb < 16 * 1024) ldsb = 16 * 1024;            // cross-wave reduction area
+    if (ldsb > SCF_DMA_LDS_DEEP) return SCF_EUNSUPPORTED;
+    ksp = true;
+    nblk = (long long)N * ((k.Ho + FR - 1) / FR) * ((k.Wo + FC - 1) / FC) * frags_m;
+    k.PH = PH;
+    k.tiles_y = (k.Ho + FR - 1) / FR;
+  }
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
   k.PWin = (FC - 1) * k.stride + k.KW;                       // input columns a tile needs
   k.PW = k.stride == 1 ? k.PWin : ((k.PWin + 1) / 2) * 2;     // LDS row pitch
-  k.tiles_y = (k.Ho + TR - 1) / TR;
   k.tiles_x = (k.Wo + FC - 1) / FC;
   k.mblocks = (frags_m + WM - 1) / WM;
-  k.nchunk = (k.Cin + KC - 1) / KC;
-  if (info) { info[0] = WM; info[1] = WN; info[2] = (int)best_blk; info[3] = k.T * G * 4 * WM * WN; }
+  if (info) { info[0] = WM; info[1] = WN; info[2] = (int)nblk; info[3] = k.T * G * 4 * WM * WN / (ksp ? 4 : 1); }
   if (dry_run) return SCF_OK;
-#define SCF_CASE(M, Nn) if (WM == M && WN == Nn) return launch_dma<M, Nn>(k, (int)best_blk, best_lds, st);
+  if (ksp) {
+    if (NST == 6) return launch_dma<1, 1, 6, true>(k, (int)nblk, ldsb, st);
+    if (NST == 4) return launch_dma<1, 1, 4, true>(k, (int)nblk, ldsb, st);
+    return launch_dma<1, 1, 2, true>(k, (int)nblk, ldsb, st);
+  }
+  if (NST == 4) {
+    if (WM == 1) return launch_dma<1, 1, 4>(k, (int)nblk, ldsb, st);
+    return launch_dma<2, 1, 4>(k, (int)nblk, ldsb, st);
+  }
+  if (NST == 3) {
+    if (WM == 1) return launch_dma<1, 1, 3>(k, (int)nblk, ldsb, st);
+    return launch_dma<2, 1, 3>(k, (int)nblk, ldsb, st);
+  }
+#define SCF_CASE(M, Nn) if (WM == M && WN == Nn) return launch_dma<M, Nn>(k, (int)nblk, ldsb, st);
   SCF_CASE(2, 2) SCF_CASE(3, 1) SCF_CASE(2, 1) SCF_CASE(1, 1)
 #undef SCF_CASE
   return SCF_EUNSUPPORTED;

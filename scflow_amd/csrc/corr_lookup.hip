@@ -253,14 +253,14 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
       q = (int)(gq - (long long)n * hw);
     }
     const int y = q / p.w, x = q - y * p.w;
-    const float qx = (float)x + fx, qy = (float)y + fy;
+    const float xf = (float)x, yf = (float)y;
     // byte offset of this lane's query from the group-uniform base out[n0, k, 0, 0]
     const unsigned lane_off = (unsigned)(((long long)(n - n0) * ktot * hw + q) * 4);
     const int nq = (int)((p.total_q - gq0) < QB ? (p.total_q - gq0) : QB);   // wave-uniform
     const bool more = g + (int)gridDim.x < p.ngroups;
     float fxn = 0.f, fyn = 0.f;
 #ifdef SCF_LOOKUP_TRACE
-    { float a = qx, b = qy; asm volatile("" : "+v"(a), "+v"(b)); SCF_TRACE(1); }
+    { float a = fx, b = fy; asm volatile("" : "+v"(a), "+v"(b)); SCF_TRACE(1); }
 #endif
 
     for (int lvl = wave; lvl < p.L; lvl += 4) {
@@ -270,7 +270,17 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
       // grid_sample(align_corners=True) de-normalises with (size-1), so along a size-1 axis
       // EVERY tap lands exactly on index 0 (corr_lookup.py:64-67).
       const bool flat_x = lw == 1, flat_y = lh == 1;
+      const bool small = (lh <= FW && lw <= FW);
+      const bool tiled = TILED0 && lvl == 0;
+      // the staging area is cleared BEFORE the first use of the flow (whose load is still in flight)
+      if (small) {
+        if (lane < lw) (myfp + QB * (msz | 1))[lane] = 0.f;            // the shared zero row
+      } else {
+        for (int i = lane; i < QB * FSP / 4; i += 64)
+          ((__attribute__((address_space(3))) f4*)myfp)[i] = f4{0.f, 0.f, 0.f, 0.f};
+      }
       const float inv = 1.0f / (float)(1 << lvl);
+      const float qx = xf + fx, qy = yf + fy;           // first use of the flow
       float cx = flat_x ? (float)R : qx * inv;          // exact power-of-two scaling
       float cy = flat_y ? (float)R : qy * inv;
       cx = fminf(fmaxf(cx, -30000.f), 30000.f);         // far outside any map -> all taps 0
@@ -280,8 +290,6 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
       const float x0f = floorf(cx), y0f = floorf(cy);
       const int x0 = (int)x0f - R, y0 = (int)y0f - R;
       const char* lbase = (const char*)lk_sgpr_ptr(p.lvl[lvl] + gq0 * msz);
-      const bool small = (lh <= FW && lw <= FW);
-      const bool tiled = TILED0 && lvl == 0;
       const int i0 = (half * D + 1) / 2;                // first x-offset of this half-wave
       lds_cfp_t rowp[FW];
       unsigned st0 = (unsigned)(uintptr_t)myfp;
@@ -291,7 +299,6 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
         // ---- whole map per query, stride S (odd), + ONE shared zero row behind them ----
         const int S = msz | 1;
         const lds_fp_t zrow = myfp + QB * S;
-        if (lane < lw) zrow[lane] = 0.f;
         const unsigned long long m0mask = msz >= 64 ? ~0ull : ((1ull << msz) - 1ull);
         const unsigned long long m1mask = msz > 64 ? ((1ull << (msz - 64)) - 1ull) : 0ull;
         const unsigned vlane4 = (unsigned)lane * 4u;
@@ -311,8 +318,6 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
         }
       } else {
         // ---- zero-padded footprints, stride FSP; two DMA instructions per query ----
-        for (int i = lane; i < QB * FSP / 4; i += 64)
-          ((__attribute__((address_space(3))) f4*)myfp)[i] = f4{0.f, 0.f, 0.f, 0.f};
         // offset tables: half-wave 0 writes this query's FW row offsets, half-wave 1 its FW column
         // offsets (in floats, inside the query's map; 0x8000 = outside).  The map layout lives
         // here and nowhere else: row-major, or 8x4-float tiles of 128 B for level 0.

@@ -289,18 +289,29 @@ class MotionEncoder(HipModule):
         self.out_net = nn.Sequential(ConvBlock(256, 126, 3, padding=1, act_cfg=act_cfg))
         self.out_channels = [126]
 
-    def forward(self, corr: Tensor, flow: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    def forward(self, corr: Tensor, flow: Tensor, out: Optional[Tensor] = None,
+                overlap: bool = False, cf: Optional[Tensor] = None) -> Tensor:
         """raft_decoder.py:152-166.  -> (N, 128, h, w) = [out_net(126) | flow(2)], optionally
-        written into ``out`` (a channel slice of the GRU input buffer)."""
+        written into ``out`` (a channel slice of the GRU input buffer).  ``overlap`` (small
+        batches): the flow branch runs on the side stream, from the caller's ``ops.fork_point()``;
+        the caller then also passes ``cf`` (N, 256, h, w), allocated BEFORE that fork point (the
+        side branch writes it: see SCFlowRefiner.extract_feat for the allocator rule)."""
         n, _, h, w = flow.shape
         dev = flow.device
         if out is None:
             out = torch.empty((n, 128, h, w), dtype=torch.float32, device=dev)
-        cf = torch.empty((n, 256, h, w), dtype=torch.float32, device=dev)
+        if cf is None:
+            if overlap:
+                raise ValueError('overlap=True needs a cf buffer allocated before the fork point')
+            cf = torch.empty((n, 256, h, w), dtype=torch.float32, device=dev)
+        br = ops.side_stream(overlap)
+        with br:
+            f1 = self.flow_net[0](flow)
+            self.flow_net[1](f1, out=cf[:, 192:])
+            del f1
         c1 = self.corr_net[0](corr)
         self.corr_net[1](c1, out=cf[:, :192])
-        f1 = self.flow_net[0](flow)
-        self.flow_net[1](f1, out=cf[:, 192:])
+        br.join()
         self.out_net[0](cf, out=out[:, :126])
         ops.copy_channels(flow, out[:, 126:128])
         return out
@@ -509,26 +520,42 @@ class SCFlowDecoder(HipModule):
         outs = ([], [], [], [], [], [], [])
         dm = torch.empty((n, 96, h, w), **f32)
         heads = torch.empty((n, 512, h, w), **f32)
+        # small batches: independent branches side by side
+        ov_flow, ov_mask, ov_up = (ops.small_work(n, H, W, b) for b in ('flow', 'mask', 'upsample'))
         for _ in range(self.iters):
             flow_lr = ops.resize_bilinear(flow, (h, w), mul=1.0 / scale)           # :196-197
+            cf = torch.empty((n, 256, h, w), **f32)      # before the fork (the side branch writes it)
+            if ov_flow:
+                ops.fork_point()             # the motion encoder's flow branch starts here
             corr = self.corr_lookup(pyramid, flow_lr, level0_tiled=tiled)          # :198
-            self.encoder(corr, flow_lr, out=hx[:, hc + cc:])                       # :206
+            self.encoder(corr, flow_lr, out=hx[:, hc + cc:], overlap=ov_flow, cf=cf)   # :206
             hv = self.gru.forward_inplace(hx)                                      # :207-208
             ops.conv2d(self.packed, hv, out=heads, act=ACT_RELU)
             d_flow = self.flow_pred.predict(heads[:, :256])                        # :210
             mask = self.mask_pred.predict(heads[:, 256:], act=ACT_SIGMOID)         # :212-213
+            br = ops.side_stream(ov_mask)
+            with br:
+                m1 = self.mask_encoder[0](mask)                                    # :217
+                self.mask_encoder[1](m1, out=dm[:, 64:])
+                del m1
             d1 = self.delta_flow_encoder[0](d_flow)                                # :216
             self.delta_flow_encoder[1](d1, out=dm[:, :64])
-            m1 = self.mask_encoder[0](mask)                                        # :217
-            self.mask_encoder[1](m1, out=dm[:, 64:])
+            br.join()
+            # the two full-resolution outputs do not feed the pose head: side branch (outputs are
+            # allocated here, on the main stream, because they escape the branch)
+            flow_pred = torch.empty((n, 2, H, W), **f32)
+            up_mask = torch.empty((n, 1, H, W), **f32)
+            br = ops.side_stream(ov_up)
+            with br:
+                ops.resize_bilinear(flow_lr, (H, W), mul=float(scale), b=d_flow, out=flow_pred)  # :222-224
+                ops.resize_bilinear(mask, (H, W), out=up_mask)                     # :226-227
             rot_all, trans_all = self.pose_pred.features(hv, dm)                   # :218-219
             d_rot, d_trans, rot, trans = ops.pose_update(                          # :230-236
                 rot_all, trans_all, label, self.pose_pred.num_class, rot, trans,
                 self.pose_pred.label_mode)
-            flow_pred = ops.resize_bilinear(flow_lr, (H, W), mul=float(scale), b=d_flow)  # :222-224
-            up_mask = ops.resize_bilinear(mask, (H, W))                            # :226-227
             flow = ops.reproject_flow(depth, internel_k, rot0, trans0, rot, trans,  # :239-243
                                       invalid_flow_num)
+            br.join()
             for lst, v in zip(outs, (flow, flow_pred, rot, trans, up_mask, d_rot, d_trans)):
                 lst.append(v)
         return outs

@@ -77,6 +77,66 @@ def _opt(t: Optional[Tensor], name: str) -> Optional[int]:
     return None if t is None else _dense(t, name)
 
 
+# ------------------------------------------------- small-batch stream overlap
+# At batch 1 every kernel of the path fills a fraction of the chip (a 32x32 map is 8-32 blocks on 256
+# CUs), so independent branches are put on a second HIP stream and run side by side; hipGraph
+# capture records the fork / join as graph dependencies.  Large batches keep one stream.
+_SIDE = {}
+_FORK = {}
+
+
+OVERLAP_BRANCHES = {'context', 'flow', 'mask', 'upsample'}      # tools/lab switches these off one by one
+
+
+def small_work(n: int, h: int, w: int, branch: Optional[str] = None) -> bool:
+    """whether a batch of n (h, w) images is small enough for branch-level concurrency to pay
+    (``branch``: and that branch is enabled)."""
+    return n * h * w <= 4 * 256 * 256 and (branch is None or branch in OVERLAP_BRANCHES)
+
+
+def fork_point() -> None:
+    """mark the point of the current stream from which the next ``side_stream`` block may start."""
+    ev = torch.cuda.Event()
+    ev.record()
+    _FORK[torch.cuda.current_device()] = ev
+
+
+class side_stream:
+    """``br = side_stream(enabled); with br: <branch>`` enqueues the block on this device's second
+    stream, ordered after the last ``fork_point()`` (or after everything enqueued so far);
+    ``br.join()`` -- called once the OTHER branch has been enqueued on the main stream -- makes the
+    main stream wait for it.  Tensors the branch writes into are allocated before the block;
+    tensors it allocates itself must not escape it.  ``enabled=False``: plain in-order execution."""
+
+    def __init__(self, enabled: bool = True) -> None:
+        self.enabled, self.ctx, self.side = enabled, None, None
+
+    def __enter__(self):
+        if not self.enabled:
+            return self
+        dev = torch.cuda.current_device()
+        self.side = _SIDE.get(dev)
+        if self.side is None:
+            self.side = _SIDE[dev] = torch.cuda.Stream(device=dev)
+        ev = _FORK.pop(dev, None)
+        if ev is not None:
+            self.side.wait_event(ev)
+        else:
+            self.side.wait_stream(torch.cuda.current_stream())
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self) -> None:
+        if self.enabled and self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+
 # ------------------------------------------------------------------ conv
 def choose_kc(cin: int, kh: int, kw: int, stride: int = 1) -> int:
     """channels staged per LDS round (scf_conv2d accepts 2, 8, 32): 32 for dense 1x1
@@ -126,8 +186,10 @@ def pack_conv_weight_f16x3(weight: Tensor) -> Tensor:
 def choose_a4_groups(cin: int, kh: int, kw: int, stride: int) -> int:
     """8G channels per staged chunk of the LDS-DMA kernel (0: layer not eligible)."""
     t = kh * kw
-    if stride not in (1, 2) or cin < 8 or t >= 25 or t == 1:   # 1x1: chunks too short for the DMA pipeline
-        return 0                                                 # (measured 54 vs 62-70 TF/s)
+    if stride not in (1, 2) or cin < 8 or t >= 25:
+        return 0
+    if t == 1:      # dense 1x1: 32-channel chunks; used on SMALL grids only (deep-ring K-split tile) --
+        return 4 if cin >= 32 else 0      # on full grids the dispatcher keeps the KC = 32 register-staged kernel
     return 2 if t <= 5 else 1
 
 

@@ -17,7 +17,7 @@ import torch
 
 from . import ops
 from .modules import HipModule
-from .ops import ACT_RELU, ACT_TANH
+from .ops import ACT_RELU, ACT_TANH, small_work
 from .registry import REFINERS, build_decoder, build_encoder
 
 Tensor = torch.Tensor
@@ -67,6 +67,17 @@ class SCFlowRefiner(HipModule):
         tanh(h) | relu(cxt) straight into the first 256 channels of the GRU input buffer."""
         n, _, H, W = render_images.shape
         dev = render_images.device
+        ops._dev(render_images, 'render_images')        # GPU fp32 on the current device, or raise
+        ops._dev(real_images, 'real_images')
+        hc, cc = self.h_channels, self.cxt_channels
+        sc = int(round(1 / self.context.scale))
+        # allocated BEFORE the fork: the side branch writes it while the main stream keeps going, so
+        # its memory must not be a block the allocator recycles from main-stream temporaries that
+        # are enqueued after the fork (they could still be running when the side branch writes)
+        hx = torch.empty((n, hc + cc + 128, H // sc, W // sc), dtype=torch.float32, device=dev)
+        ov_ctx = small_work(n, H, W, 'context')
+        if ov_ctx:
+            ops.fork_point()                            # the context encoder may start from here
         if self.seperate_encoder:
             render_feat = self.render_encoder(render_images.contiguous())
             real_feat = self.real_encoder(real_images.contiguous())
@@ -76,11 +87,12 @@ class SCFlowRefiner(HipModule):
             ops.copy_channels(real_images, both[n:])
             feats = self.render_encoder(both)
             render_feat, real_feat = feats[:n], feats[n:]
-        hc, cc = self.h_channels, self.cxt_channels
-        sc = int(round(1 / self.context.scale))
-        hx = torch.empty((n, hc + cc + 128, H // sc, W // sc), dtype=torch.float32, device=dev)
-        self.context(render_images.contiguous(), out=hx[:, :hc + cc], head_act=ACT_TANH,
-                     head_act2=ACT_RELU, head_split=hc)
+        rend = render_images.contiguous()
+        br = ops.side_stream(ov_ctx)                    # small batches: next to the feature encoder
+        with br:
+            self.context(rend, out=hx[:, :hc + cc], head_act=ACT_TANH,
+                         head_act2=ACT_RELU, head_split=hc)
+        br.join()
         return render_feat, real_feat, hx[:, :hc], hx[:, hc:hc + cc]
 
     # ------------------------------------------------------------------ pose

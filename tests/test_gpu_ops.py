@@ -499,3 +499,58 @@ def test_sepconv_gru_c_entry(n, h, w, kind):
     assert lib.scf_sepconv_gru(None, 0, n, ch, cx, h, w, passes, 1, za.data_ptr(), rha.data_ptr(), None) < 0
     assert lib.scf_sepconv_gru(hxa.data_ptr(), hxa.stride(0), n, 100, cx, h, w, passes, 1, za.data_ptr(),
                                rha.data_ptr(), None) < 0
+
+
+# ----------------------------------------------------------- small grids: deep LDS-DMA rings, K-split tile
+SMALL_GRID_CASES = [
+    # n, cin, cout, k, stride, pad, H, W
+    (1, 384, 256, (1, 5), 1, (0, 2), 32, 32),      # GRU z|r at batch 1: K-split tile, 6-deep ring
+    (1, 384, 128, (5, 1), 1, (2, 0), 32, 32),
+    (1, 128, 512, (3, 3), 1, 1, 32, 32),           # heads at batch 1
+    (1, 324, 256, (1, 1), 1, 0, 32, 32),           # dense 1x1, ragged last chunk (324 = 10*32 + 4)
+    (1, 64, 64, (3, 3), 1, 1, 128, 128),           # encoder at batch 1: pixel-split tile, 4-deep ring
+    (1, 96, 96, (3, 3), 1, 1, 64, 64),
+    (1, 64, 96, (3, 3), 2, 1, 128, 128),           # stride 2
+    (2, 224, 128, (3, 3), 2, 1, 32, 32),           # pose head conv 1
+    (1, 128, 128, (3, 3), 2, 1, 8, 8),             # pose head conv 3: 4 blocks
+    (1, 256, 192, (3, 3), 1, 1, 12, 20),           # ragged tiles
+    (3, 40, 33, (3, 3), 1, 1, 9, 7),               # ragged everything
+]
+
+
+@pytest.mark.parametrize('case', SMALL_GRID_CASES)
+def test_conv2d_small_grid_kernels(case):
+    """batch-1-sized grids run on the LDS-DMA kernel's deep-ring / K-split variants: same numbers as
+    torch within fp32 round-off, with bias + ReLU, a residual, and the two-segment GRU-Q form."""
+    import ctypes as C
+    from scflow_amd import _lib
+    n, cin, cout, k, stride, pad, H, W = case
+    x = rnd((n, cin, H, W), 80)
+    w = rnd((cout, cin, *k), 81, 0.05)
+    b = rnd((cout,), 82, 0.2)
+    pc = ops.PackedConv.from_weight(w.to(DEV), b.to(DEV), stride=stride, padding=pad)
+    want = torch.relu(F.conv2d(x, w, b, stride=stride, padding=pad))
+    xd = x.to(DEV)
+    got = ops.conv2d(pc, xd, act=ops.ACT_RELU)
+    close(got, want, atol=3e-5 * max(1.0, float(want.abs().max())), what='bias+relu')
+    # the library really took the LDS-DMA path (info[3] < 0 with the a4 packing present)
+    d = _lib.ConvDesc()
+    d.in0, d.C0, d.in0_nstride = xd.data_ptr(), cin, cin * H * W
+    d.N, d.H, d.W = n, H, W
+    d.wp, d.Mld, d.Cout, d.KC = pc.wp.data_ptr(), pc.mld, cout, pc.kc
+    d.KH, d.KW, d.stride, d.pad_h, d.pad_w = pc.kh, pc.kw, stride, pc.pad_h, pc.pad_w
+    d.out, d.out_nstride, d.out_div = got.data_ptr(), got.stride(0), 1.0
+    d.wp_a4, d.a4_groups, d.a4_mld = pc.wp4.data_ptr(), pc.g4, pc.mld
+    info = (C.c_int32 * 4)()
+    assert _lib.load().scf_conv2d_query(C.byref(d), info) == 0 and info[3] < 0, list(info)
+    # residual + no activation, output into a channel slice
+    ho, wo = want.shape[-2:]
+    res = rnd((n, cout, ho, wo), 83)
+    big = torch.zeros((n, cout + 5, ho, wo), device=DEV)
+    ops.conv2d(pc, xd, out=big[:, 3:3 + cout], res=res.to(DEV))
+    close(big[:, 3:3 + cout], F.conv2d(x, w, b, stride=stride, padding=pad) + res,
+          atol=3e-5 * max(1.0, float(want.abs().max())), what='residual into slice')
+    assert float(big[:, :3].abs().max()) == 0 and float(big[:, 3 + cout:].abs().max()) == 0
+    # same result as the register-staged kernel (no DMA packing) within round-off
+    pc0 = ops.PackedConv.from_weight(w.to(DEV), b.to(DEV), stride=stride, padding=pad, dma_packing=False)
+    close(ops.conv2d(pc0, xd, act=ops.ACT_RELU), want, atol=3e-5 * max(1.0, float(want.abs().max())), what='register-staged')

@@ -1,15 +1,18 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): rocprofv3 evidence for bench.py, written under gpurun_out/.
 # usage: tools/collect_profiles.sh <tag>
+# Counter passes are their own runs (--pmc with --kernel-trace only, one counter per pass).
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batch1 --no-alt"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_f32 -o f32 -- $B --precision f32 > $OUT/bench_f32.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_f16x3 -o f16x3 -- $B --precision f16x3 > $OUT/bench_f16x3.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- $B > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- $B > /dev/null 2>&1
+B="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --min-seconds 0.3 --min-warmup-seconds 0.1 --no-cpu-baseline --no-batch1 --no-alt"
+# every profiler pass is time-bounded: a faulting child under rocprofv3 otherwise hangs until the box limit
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_f32 -o f32 -- $B --precision f32 > $OUT/bench_f32.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_f16x3 -o f16x3 -- $B --precision f16x3 --no-config4 > $OUT/bench_f16x3.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- $B > /dev/null 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- $B > /dev/null 2>&1
+# calibration of both counters on the lookup's access types: tools/lab/calib_run.sh (own, time-bounded call)
 rm -f $OUT/*/*_kernel_trace.csv.bak
-ls -R $OUT | head -30
+find $OUT -name "*.csv" | head -40

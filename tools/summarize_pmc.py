@@ -1,49 +1,129 @@
-"""Turn the two rocprofv3 PMC passes over bench.py (FETCH_SIZE, WRITE_SIZE) into
-profiles/lookup_pmc.json: HBM bytes per corr-lookup launch.
+"""Turn the rocprofv3 PMC passes over bench.py (FETCH_SIZE, WRITE_SIZE; separate runs) into
+profiles/lookup_pmc.json: HBM bytes per corr-lookup launch, at batch 32 (256x256) and for the
+configs[4] launches (8 x 60 x 80 queries) of the same run.
 
-gfx950 corrections (MI355X_MICROARCH.md, HBM section): both counters are in KiB; FETCH_SIZE
-reports half of the bytes of a coalesced read stream -> doubled; the factor is re-checked here on
-instance_norm_kernel<16> (plain variant), whose traffic is exactly one read + one write of its
-tensor."""
-import csv, json, re, sys, collections
+Both counters are in KiB.  FETCH_SIZE under-reports by a pattern-dependent factor on gfx950
+(MI355X_MICROARCH.md, HBM section: exactly 1/2 for wide coalesced reads, "other widths
+uncalibrated"), so the factor is MEASURED on the lookup's own access type with
+tools/lab/fetch_calib.hip (dword global_load_lds `nt` gathers and `sc1` dword stores over a 1 GiB
+buffer with known byte counts):
+
+    python tools/summarize_pmc.py <pmc_fetch.csv> <pmc_write.csv> <out.json> <tag> \
+        [stats.csv] [calib_fetch.csv calib_write.csv]
+"""
+import collections
+import csv
+import json
+import re
+import sys
 
 fetch_csv, write_csv, out_json, tag = sys.argv[1:5]
 stats_csv = sys.argv[5] if len(sys.argv) > 5 else None      # --kernel-trace --stats pass (no PMC)
+calib_f = sys.argv[6] if len(sys.argv) > 7 else None
+calib_w = sys.argv[7] if len(sys.argv) > 7 else None
+
+
+def rows(path, counter):
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] == counter:
+            yield r
 
 
 def per_kernel(path, counter):
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
-        if r['Counter_Name'] == counter:
-            agg[re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '')].append(float(r['Counter_Value']))
+    for r in rows(path, counter):
+        agg[re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '')].append(float(r['Counter_Value']))
     return agg
 
+
+GIB = float(1 << 30)
+calibration = None
+fetch_factor, write_factor = 2.0, 1.0      # the guide's figures, replaced by measured ones below
+if calib_f and calib_w:
+    cf, cw = per_kernel(calib_f, 'FETCH_SIZE'), per_kernel(calib_w, 'WRITE_SIZE')
+    true_bytes = {'calib_f4_stream': GIB, 'calib_dma<4, 1, 1>': GIB, 'calib_dma<64, 1, 1>': GIB / 16,
+                  'calib_dma<128, 1, 1>': GIB / 32, 'calib_dma<4, 10, 32>': GIB * 40 / 128}
+    calibration = {}
+    for k, tb in true_bytes.items():
+        rep = min(cf[k]) * 1024
+        calibration[k] = {'bytes_requested': tb, 'fetch_size_reported_bytes': rep,
+                          'requested_per_reported': round(tb / rep, 3),
+                          'reported_bytes_per_64B_sector_touched': None}
+    # sectors touched: contig -> all; sector64 -> all 64-B sectors; line128 -> half of them;
+    # 40 B of a 128-B line -> the first sector only
+    sectors = {'calib_dma<4, 1, 1>': GIB / 64, 'calib_dma<64, 1, 1>': GIB / 64, 'calib_dma<128, 1, 1>': GIB / 128,
+               'calib_dma<4, 10, 32>': GIB / 128, 'calib_f4_stream': GIB / 64}
+    for k, ns in sectors.items():
+        calibration[k]['reported_bytes_per_64B_sector_touched'] = round(calibration[k]['fetch_size_reported_bytes'] / ns, 2)
+    for k in ('calib_store<0>', 'calib_store<1>'):
+        rep = min(cw[k]) * 1024
+        calibration[k] = {'bytes_written': GIB, 'write_size_reported_bytes': rep, 'written_per_reported': round(GIB / rep, 3)}
+    # the lookup reads whole 64-byte sectors' worth of useful dwords per gather: its counting factor
+    # is the one of the contiguous dword LDS-DMA pattern
+    fetch_factor = calibration['calib_dma<4, 1, 1>']['requested_per_reported']
+    write_factor = calibration['calib_store<1>']['written_per_reported']
 
 f = per_kernel(fetch_csv, 'FETCH_SIZE')
 w = per_kernel(write_csv, 'WRITE_SIZE')
 lk = [k for k in f if 'corr_lookup' in k][0]
-inorm = [k for k in f if 'instance_norm_kernel<16>' in k][0]
-cal_w = min(w[inorm]) * 1024                      # exact: one write of the tensor
-cal_f = min(f[inorm]) * 1024                      # plain variant: one read of the same tensor
-factor = cal_w / cal_f
-fetch = sum(f[lk]) / len(f[lk]) * 1024 * 2
-write = sum(w[lk]) / len(w[lk]) * 1024
+
+
+fv, wv = f[lk], w[lk]
+# launches of the main workload come first (8 per step); the configs[4] block follows (12 per step)
+def main_and_c4(vals, grids):
+    main = [v for v, g in zip(vals, grids) if g == 1024]
+    c4 = [v for v, g in zip(vals, grids) if g != 1024]
+    return main, c4
+
+
+def grids_of(path, counter):
+    return [int(r['Grid_Size']) // int(r['Workgroup_Size']) for r in rows(path, counter) if 'corr_lookup' in r['Kernel_Name']]
+
+
+fm, f4 = main_and_c4(fv, grids_of(fetch_csv, 'FETCH_SIZE'))
+wm, w4 = main_and_c4(wv, grids_of(write_csv, 'WRITE_SIZE'))
+fetch = sum(fm) / len(fm) * 1024 * fetch_factor
+write = sum(wm) / len(wm) * 1024 * write_factor
 out = {
-    'kernel': lk, 'launches': len(f[lk]),
+    'kernel': lk, 'launches': len(fm),
     'fetch_bytes_per_launch': round(fetch), 'write_bytes_per_launch': round(write),
     'traffic_bytes_per_launch': round(fetch + write),
     'algorithmic_bytes_per_launch': 2904 * 32 * 1024,
-    'fetch_size_calibration': {'kernel': inorm, 'write_bytes': cal_w, 'raw_fetch_bytes': cal_f,
-                               'bytes_per_reported_byte': round(factor, 3)},
+    'fetch_counting_factor': fetch_factor, 'write_counting_factor': write_factor,
+    'calibration': calibration,
     'source': f'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py batch 32, '
-              f'{tag}; KiB units, FETCH_SIZE x2 (gfx950 correction, calibration factor measured '
-              f'{factor:.2f})',
+              f'{tag}; KiB units; counting factors measured on the kernel\'s own access types '
+              f'(tools/lab/fetch_calib.hip): FETCH x{fetch_factor}, WRITE x{write_factor}',
 }
+if f4 and w4:
+    out['config4'] = {'launches': len(f4),
+                      'fetch_bytes_per_launch': round(sum(f4) / len(f4) * 1024 * fetch_factor),
+                      'write_bytes_per_launch': round(sum(w4) / len(w4) * 1024 * write_factor),
+                      'algorithmic_bytes_per_launch': 2904 * 8 * 60 * 80}
+    out['config4']['traffic_bytes_per_launch'] = out['config4']['fetch_bytes_per_launch'] + out['config4']['write_bytes_per_launch']
 if stats_csv:
-    for r in csv.DictReader(open(stats_csv)):
-        if 'corr_lookup' in r['Name']:
-            out['rocprof_kernel_trace'] = {'calls': int(r['Calls']), 'avg_us': round(float(r['AverageNs']) / 1e3, 2),
-                                           'min_us': round(float(r['MinNs']) / 1e3, 2),
-                                           'max_us': round(float(r['MaxNs']) / 1e3, 2)}
+    # a --kernel-trace per-dispatch CSV (preferred: separates the batch-32 launches from the configs[4]
+    # ones by grid size) or a --stats summary CSV
+    rd = list(csv.DictReader(open(stats_csv)))
+    if rd and 'Start_Timestamp' in rd[0]:
+        nblk = lambda r: int(r['Grid_Size_X']) // int(r['Workgroup_Size_X'])
+        d32 = [(float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e3 for r in rd
+               if 'corr_lookup' in r['Kernel_Name'] and nblk(r) == 1024]
+        d4 = [(float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e3 for r in rd
+              if 'corr_lookup' in r['Kernel_Name'] and nblk(r) != 1024]
+        if d32:
+            out['rocprof_kernel_trace'] = {'calls': len(d32), 'avg_us': round(sum(d32) / len(d32), 2),
+                                           'min_us': round(min(d32), 2), 'max_us': round(max(d32), 2),
+                                           'note': 'batch-32 launches (grid 1024) of the traced bench.py run'}
+        if d4 and 'config4' in out:
+            out['config4']['rocprof_kernel_trace'] = {'calls': len(d4), 'avg_us': round(sum(d4) / len(d4), 2),
+                                                      'min_us': round(min(d4), 2), 'max_us': round(max(d4), 2)}
+    else:
+        for r in rd:
+            if 'corr_lookup' in r['Name']:
+                out['rocprof_kernel_trace'] = {'calls': int(r['Calls']), 'avg_us': round(float(r['AverageNs']) / 1e3, 2),
+                                               'min_us': round(float(r['MinNs']) / 1e3, 2),
+                                               'max_us': round(float(r['MaxNs']) / 1e3, 2),
+                                               'note': 'all launches of the kernel in the traced run (batch-32 steps AND the configs[4] block)'}
 json.dump(out, open(out_json, 'w'), indent=1)
 print(json.dumps(out, indent=1))
