@@ -140,6 +140,12 @@ typedef struct scf_conv_desc {
                                            floats, channel = chunk*8G + 8g + 2s + h at float s      */
   int32_t a4_groups;                    /* G in {1,2,4}: 8G channels per staged chunk              */
   int32_t a4_mld;                       /* Cout rounded up to 32                                    */
+  const float* wp_a4s;                  /* optional: the same a4 packing with MORE channels per chunk
+                                           (a4s_groups = 4 for 1x1 / 1x5 / 5x1, 2 for 3x3), used on
+                                           SMALL grids (batch 1): there one block runs per CU, a chunk's
+                                           fixed cost (barrier, staging issue) dominates 8-channel chunks,
+                                           and LDS is free for a deep ring of bigger ones                */
+  int32_t a4s_groups;
   const float* wp_thin;                 /* optional third packing for Cout <= 4 layers (vector-ALU
                                            kernel): [Cin][KH*KW][CO] floats, CO = 1, 2 or 4 (Cout
                                            rounded up), zero padded                                */
@@ -177,6 +183,7 @@ int scf_pack_conv_weight_a4(const float* w, int Cout, int Cin, int KH, int KW, i
  *   wp_q  : KC = 8 packing of conv_q.weight (Ch, Ch+Cx, KH, KW);  bias_zr [2*Ch], bias_q [Ch]
  *   wp_*_a4 (+ a4_groups: 2 for (1,5)/(5,1), 1 for 3x3) select the LDS-DMA kernel (optional, faster)
  *   wp_*_f16 select the split-fp16 3xMFMA kernel (optional, see scf_conv_desc.wp_f16)
+ *   wp_*_a4s (+ a4s_groups) : small-grid a4 packings (see scf_conv_desc.wp_a4s), optional
  *   wp_*_k32 : KC = 32 packings of the same tensors (optional): used instead of the KC = 8 ones
  *              when the grid is so small (batch 1) that the register-staged kernel with its
  *              smallest tile runs and an 8-channel chunk is too short to hide its prefetch
@@ -188,6 +195,7 @@ typedef struct scf_gru_pass {
   const float* wp_zr_a4; const float* wp_q_a4; int32_t a4_groups;
   const void* wp_zr_f16; const void* wp_q_f16;
   const float* wp_zr_k32; const float* wp_q_k32;
+  const float* wp_zr_a4s; const float* wp_q_a4s; int32_t a4s_groups;
 } scf_gru_pass;
 
 int scf_sepconv_gru(float* hx, int64_t hx_nstride, int N, int Ch, int Cx, int H, int W,

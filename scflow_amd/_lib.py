@@ -43,6 +43,8 @@ class ConvDesc(C.Structure):
         ('wp_a4', _fp),
         ('a4_groups', C.c_int32),
         ('a4_mld', C.c_int32),
+        ('wp_a4s', _fp),
+        ('a4s_groups', C.c_int32),
         ('wp_thin', _fp),
         ('out_tile8x4', C.c_int32),
     ]
@@ -56,6 +58,7 @@ class GruPass(C.Structure):
         ('wp_zr_a4', _fp), ('wp_q_a4', _fp), ('a4_groups', C.c_int32),
         ('wp_zr_f16', _fp), ('wp_q_f16', _fp),
         ('wp_zr_k32', _fp), ('wp_q_k32', _fp),
+        ('wp_zr_a4s', _fp), ('wp_q_a4s', _fp), ('a4s_groups', C.c_int32),
     ]
 
 

@@ -24,6 +24,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #include "conv_kernels.h"
 
 #define SCF_DMA_PU 20   // patch gathers per thread per chunk (256 * 20 floats)
+#define SCF_DMA_WU 7    // weight float4 per thread per chunk
+#define SCF_DMA_PU_KSP 24   // K-split tile (small grids: 32-channel chunks, one wave per SIMD: registers are free)
+#define SCF_DMA_WU_KSP 9
 #define SCF_DMA_LDS_MAX (80 * 1024)   // two blocks per CU (160 KB)
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   static_assert(!KSP || (WM == 1 && WN == 1), "K-split tile is one 32x32 fragment");
   constexpr int BM = WM * 32;
   constexpr int NFRAG = KSP ? 1 : WN * 4;
-  constexpr int PU = SCF_DMA_PU;
+  constexpr int PU = KSP ? SCF_DMA_PU_KSP : SCF_DMA_PU;
 
   __builtin_amdgcn_s_setprio(3);       // setup / staging / epilogue instructions go first
   const int tid = threadIdx.x, lane = tid & 63;
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
     toff[u] = ok ? o : 0xFFFFFFFFu;
   }
   // weights: float4 e = tid + 256u of the chunk's [NIT*2 rows][BM] slab out of [rows][Mld4]
-  constexpr int WU = 7;
+  constexpr int WU = KSP ? SCF_DMA_WU_KSP : SCF_DMA_WU;
   unsigned woff[WU];
 #pragma unroll
   for (int u = 0; u < WU; ++u) {
@@ -193,6 +196,9 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
     for (int j = 0; j < WN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x16 acc2;                         // K-split tile: second accumulator (odd steps of this wave)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
 
   const float* in0n = p.in0 + (long long)n * p.in0_ns;
   const float* in1n = p.in1 ? p.in1 + (long long)n * p.in1_ns : nullptr;
@@ -260,18 +266,35 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
     if (++buf == NST) buf = 0;
     if (KSP) {
       // wave w takes the (tap, group) steps it == w (mod 4): one ds_read_b128 pair feeds 4 MFMAs
-      // G is 1, 2 or 4: four steps ahead is the same group g, 4 / G taps further
+      // G is 1, 2 or 4: four steps ahead is the same group g, 4 / G taps further.  The operands of
+      // the next step are read while this step's MFMAs run, and consecutive steps alternate between
+      // two accumulators (one wave per SIMD here: a single dependent MFMA chain would leave the
+      // matrix pipe waiting for its own result).
       const int gshift = G == 4 ? 2 : G == 2 ? 1 : 0, g = wave & (G - 1), tstep = 4 >> gshift;
       int ky = 0, kx = wave >> gshift;
       while (kx >= p.KW) { kx -= p.KW; ++ky; }
-      for (int it = wave; it < NIT; it += 4) {
-        const f32x4 aa = wl[it * 2 * BM];
-        const f32x4 bb = pl[g * 2 * PHW + ky * PW + (st == 1 ? kx : (kx & 1) * PWh + (kx >> 1)) + boff[0]];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[s4], bb[s4], acc[0][0], 0, 0, 0);
+      const f32x4* pg = pl + g * 2 * PHW + boff[0];
+      auto opnd = [&](int it, f32x4& aa, f32x4& bb) {
+        aa = wl[it * 2 * BM];
+        bb = pg[ky * PW + (st == 1 ? kx : (kx & 1) * PWh + (kx >> 1))];
         kx += tstep;
         while (kx >= p.KW) { kx -= p.KW; ++ky; }
+      };
+      f32x4 a0, b0, a1, b1;
+      int it = wave;
+      if (it < NIT) opnd(it, a0, b0);
+      while (it < NIT) {
+        if (it + 4 < NIT) opnd(it + 4, a1, b1);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s4], b0[s4], acc[0][0], 0, 0, 0);
+        it += 4;
+        if (it >= NIT) break;
+        if (it + 4 < NIT) opnd(it + 4, a0, b0);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s4], b1[s4], acc2, 0, 0, 0);
+        it += 4;
       }
       continue;
     }
@@ -315,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
     __syncthreads();                          // every wave is done reading the ring
     float* red = lds;                         // [4 waves][16 regs][64 lanes] = 16 KB
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[0][0][r];
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[0][0][r] + acc2[r];
     __syncthreads();
     float v[4];
 #pragma unroll
@@ -380,13 +403,12 @@ static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st
 //   small grids  : the same tiles with a 4-deep ring while they still give >= 256 blocks, else
 //                  the K-split tile (32 channels x 32 pixels) with a ring as deep as LDS allows
 int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st) {
-  if (!k.wp4 || (k.stride != 1 && k.stride != 2) || k.w_ns != 0) return SCF_EUNSUPPORTED;
-  const int G = k.G4;
-  if (G != 1 && G != 2 && G != 4) return SCF_EUNSUPPORTED;
-  const int KC = 8 * G;
-  if (k.in1 && (k.C0 % KC) != 0) return SCF_EUNSUPPORTED;
+  if ((!k.wp4 && !k.wp4s) || (k.stride != 1 && k.stride != 2) || k.w_ns != 0) return SCF_EUNSUPPORTED;
   const int FC = 1 << k.fc_log2, FR = 32 / FC;
   const int frags_m = (k.Cout + 31) / 32;
+  int G = k.wp4 ? k.G4 : 0;
+  int KC = 8 * G;
+  const bool pix_ok = k.wp4 && (G == 1 || G == 2 || G == 4) && !(k.in1 && (k.C0 % KC) != 0);
   // candidates in order of preference; WM must divide the channel fragments (no idle MFMA
   // rows) unless nothing else fits; take the first that gives >= 2 blocks per CU, else the one
   // with the most blocks.
@@ -394,7 +416,7 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   int best = -1;
   long long best_blk = 0;
   size_t best_lds = 0;
-  for (int pass = 0; pass < 2 && best < 0; ++pass) {
+  for (int pass = 0; pix_ok && pass < 2 && best < 0; ++pass) {
     for (int c = 0; c < 4; ++c) {
       const int WM = cand[c][0], WN = cand[c][1];
       if (WM > frags_m) continue;
@@ -405,7 +427,7 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
       const long long PE = (long long)KC * PH * PW;
       const long long WF4 = (long long)k.T * G * 2 * WM * 32;
       const size_t ldsb = (size_t)(WF4 * 4 + PE) * 2 * sizeof(float);
-      if (PE > 256 * SCF_DMA_PU || WF4 > 256 * 7 || ldsb > SCF_DMA_LDS_MAX) continue;
+      if (PE > 256 * SCF_DMA_PU || WF4 > 256 * SCF_DMA_WU || ldsb > SCF_DMA_LDS_MAX) continue;
       const long long blk = (long long)N * ((k.Ho + TR - 1) / TR) * ((k.Wo + FC - 1) / FC) *
                             ((frags_m + WM - 1) / WM);
       if (best < 0 || blk > best_blk) { best = c; best_blk = blk; best_lds = ldsb; }
@@ -418,7 +440,13 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
 #endif
   if (k.T == 1 && large) return SCF_EUNSUPPORTED;     // dense 1x1 on a full grid: the KC = 32 register-staged
                                                       // kernel is faster (chunks too short for this pipeline)
-  k.nchunk = (k.Cin + KC - 1) / KC;
+  if (!pix_ok) {
+    // only the small-grid packing is present (dense 1x1): it is for small grids only -- fewer than
+    // 256 blocks even with the smallest pixel-split tile (32 channels x 128 pixels)
+    const long long blk11 = (long long)N * ((k.Ho + 4 * FR - 1) / (4 * FR)) * ((k.Wo + FC - 1) / FC) * frags_m;
+    if (blk11 >= 256) return SCF_EUNSUPPORTED;
+  }
+  if (KC) k.nchunk = (k.Cin + KC - 1) / KC;
   int WM = 1, WN = 1, NST = 2;
   bool ksp = false;
   long long nblk = 0;
@@ -438,12 +466,19 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
     k.PH = (TR - 1) * k.stride + k.KH;
     k.tiles_y = (k.Ho + TR - 1) / TR;
   } else {                                             // K-split tile: one 32-pixel fragment per block
+    if (k.wp4s && (k.G4s == 1 || k.G4s == 2 || k.G4s == 4) && !(k.in1 && (k.C0 % (8 * k.G4s)) != 0)) {
+      k.wp4 = k.wp4s; k.G4 = k.G4s;                    // the small-grid packing: bigger chunks
+    } else if (!pix_ok) {
+      return SCF_EUNSUPPORTED;
+    }
+    G = k.G4; KC = 8 * G;
+    k.nchunk = (k.Cin + KC - 1) / KC;
     const int PH = (FR - 1) * k.stride + k.KH, PWin = (FC - 1) * k.stride + k.KW;
     const int PW = k.stride == 1 ? PWin : ((PWin + 1) / 2) * 2;
     const long long PE = (long long)KC * PH * PW, WF4 = (long long)k.T * G * 2 * 32;
-    if (PE > 256 * SCF_DMA_PU || WF4 > 256 * 7) return SCF_EUNSUPPORTED;
+    if (PE > 256 * SCF_DMA_PU_KSP || WF4 > 256 * SCF_DMA_WU_KSP) return SCF_EUNSUPPORTED;
     const size_t stage_b = (size_t)(WF4 * 4 + PE) * sizeof(float);
-    NST = k.nchunk >= 6 && stage_b * 6 <= SCF_DMA_LDS_DEEP ? 6 : k.nchunk >= 4 && stage_b * 4 <= SCF_DMA_LDS_DEEP ? 4 : 2;
+    NST = k.nchunk >= 6 && stage_b * 6 <= SCF_DMA_LDS_DEEP ? 6 : k.nchunk >= 3 && stage_b * 4 <= SCF_DMA_LDS_DEEP ? 4 : 2;
     ldsb = stage_b * NST;
     if (ldsb < 16 * 1024) ldsb = 16 * 1024;            // cross-wave reduction area
     if (ldsb > SCF_DMA_LDS_DEEP) return SCF_EUNSUPPORTED;

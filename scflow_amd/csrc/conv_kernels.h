@@ -11,6 +11,7 @@ struct ConvK {
   const void* wp16;          // split-fp16 packing (conv_f16x3.hip) or nullptr
   const float* wthin;               // [Cin][T][CO] packing (conv_thin.hip) or nullptr
   const float* wp4; int G4, Mld4;   // LDS-DMA packing (conv_dma.hip) or nullptr
+  const float* wp4s; int G4s;       // its small-grid variant (more channels per chunk) or nullptr
   int Mld, Cout, Krows;
   int KH, KW, T, stride, pad_h, pad_w, KC, nchunk;
   int fc_log2, tiles_x, tiles_y, mblocks, PH, PW, PWin;

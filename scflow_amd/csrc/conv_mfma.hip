@@ -424,6 +424,7 @@ static int conv_plan(const scf_conv_desc* d, ConvPlan* plan) {
   k.wp16 = d->wp_f16;
   k.wthin = d->wp_thin;
   k.wp4 = d->wp_a4; k.G4 = d->a4_groups; k.Mld4 = d->a4_mld;
+  k.wp4s = d->wp_a4s; k.G4s = d->a4s_groups;
   k.out_tile = d->out_tile8x4;
   k.KH = d->KH; k.KW = d->KW; k.T = d->KH * d->KW; k.stride = d->stride;
   k.pad_h = d->pad_h; k.pad_w = d->pad_w; k.KC = d->KC;
@@ -524,7 +525,8 @@ static bool want_f16x3(const scf_conv_desc* d) {
 }
 
 static bool want_dma(const scf_conv_desc* d) {      // a layer opts in by carrying the LDS-DMA packing
-  return d->wp_a4 != nullptr && (d->stride == 1 || d->stride == 2) && d->w_nstride == 0 && d->a4_mld >= d->Cout;
+  return (d->wp_a4 != nullptr || d->wp_a4s != nullptr) && (d->stride == 1 || d->stride == 2) &&
+         d->w_nstride == 0 && d->a4_mld >= d->Cout;
 }
 
 extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
@@ -599,6 +601,7 @@ extern "C" int scf_sepconv_gru(float* hx, int64_t hx_nstride, int N, int Ch, int
     d.in0 = hx; d.C0 = Ch + Cx; d.in0_nstride = hx_nstride;
     d.Mld = (2 * Ch + 31) / 32 * 32; d.Cout = 2 * Ch; d.bias = g.bias_zr;
     d.wp_a4 = g.wp_zr_a4; d.a4_groups = g.a4_groups; d.a4_mld = d.Mld; d.wp_f16 = g.wp_zr_f16;
+    d.wp_a4s = g.wp_zr_a4s; d.a4s_groups = g.a4s_groups;
     d.out = z; d.out_nstride = Ch * hw;
     d.mode = SCF_CONV_GRU_ZR; d.gru_h = hx; d.gru_h_nstride = hx_nstride;
     d.gru_aux = rh; d.gru_aux_nstride = Ch * hw;
@@ -610,6 +613,7 @@ extern "C" int scf_sepconv_gru(float* hx, int64_t hx_nstride, int N, int Ch, int
     d.in1 = hx + (int64_t)Ch * hw; d.C1 = Cx; d.in1_nstride = hx_nstride;
     d.Mld = (Ch + 31) / 32 * 32; d.Cout = Ch; d.bias = g.bias_q;
     d.wp_a4 = g.wp_q_a4; d.a4_mld = d.Mld; d.wp_f16 = g.wp_q_f16;
+    d.wp_a4s = g.wp_q_a4s;
     d.out = hx; d.out_nstride = hx_nstride;
     d.mode = SCF_CONV_GRU_Q; d.gru_h = hx; d.gru_h_nstride = hx_nstride;
     d.gru_aux = nullptr; d.gru_aux_nstride = 0;

@@ -188,9 +188,19 @@ def choose_a4_groups(cin: int, kh: int, kw: int, stride: int) -> int:
     t = kh * kw
     if stride not in (1, 2) or cin < 8 or t >= 25:
         return 0
-    if t == 1:      # dense 1x1: 32-channel chunks; used on SMALL grids only (deep-ring K-split tile) --
-        return 4 if cin >= 32 else 0      # on full grids the dispatcher keeps the KC = 32 register-staged kernel
+    if t == 1:      # dense 1x1 on a full grid: chunks too short for this pipeline (measured 54 vs
+        return 0    # 62-70 TF/s): the KC = 32 register-staged kernel keeps them; small grids: a4s
     return 2 if t <= 5 else 1
+
+
+def choose_a4s_groups(cin: int, kh: int, kw: int, stride: int) -> int:
+    """8G channels per staged chunk of the SMALL-GRID a4 packing (0: not eligible): at batch 1
+    one block runs per CU and the per-chunk fixed cost dominates, so chunks are 2-4x bigger than on
+    full grids (and dense 1x1 layers join in)."""
+    t = kh * kw
+    if stride not in (1, 2) or cin < 16 or t >= 25:
+        return 0
+    return 4 if t <= 5 else 2
 
 
 def pack_conv_weight_a4(weight: Tensor, groups: int) -> Tuple[Tensor, int]:
@@ -261,6 +271,8 @@ class PackedConv:
     wp4: Optional[Tensor] = None      # LDS-DMA packing (stride 1, Cin >= 8)
     g4: int = 0
     wthin: Optional[Tensor] = None    # [Cin][T][CO] packing (Cout <= 4)
+    wp4s: Optional[Tensor] = None     # small-grid LDS-DMA packing (bigger chunks)
+    g4s: int = 0
 
     @staticmethod
     def from_weight(weight: Tensor, bias: Optional[Tensor], stride: int = 1,
@@ -283,9 +295,12 @@ class PackedConv:
             shift = (beta - mean * scale).contiguous()
         g4 = choose_a4_groups(cin, kh, kw, stride) if dma_packing else 0
         wp4 = pack_conv_weight_a4(weight, g4)[0] if g4 else None
+        g4s = choose_a4s_groups(cin, kh, kw, stride) if dma_packing else 0
+        wp4s = pack_conv_weight_a4(weight, g4s)[0] if g4s else None
         return PackedConv(wp, None if bias is None else bias.float().contiguous(), scale, shift,
                           cin, cout, kh, kw, stride, ph, pw, kc, mld, wp_alt, {}, wp16, wp4, g4,
-                          pack_conv_weight_thin(weight) if (cout <= 4 and stride == 1 and cin >= 32) else None)
+                          pack_conv_weight_thin(weight) if (cout <= 4 and stride == 1 and cin >= 32) else None,
+                          wp4s, g4s)
 
     def out_hw(self, h: int, w: int) -> Tuple[int, int]:
         return ((h + 2 * self.pad_h - self.kh) // self.stride + 1,
@@ -350,6 +365,8 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
         d.wp_thin = pc.wthin.data_ptr()
     if pc.wp4 is not None:
         d.wp_a4, d.a4_groups, d.a4_mld = pc.wp4.data_ptr(), pc.g4, pc.mld
+    if pc.wp4s is not None:
+        d.wp_a4s, d.a4s_groups, d.a4_mld = pc.wp4s.data_ptr(), pc.g4s, pc.mld
     if pc.wp_alt is not None and (c1 == 0 or c0 % 32 == 0):
         key = (n, h, w, c0, c1, d.wp_f16 is not None)
         use_alt = pc.plans.get(key)
@@ -408,6 +425,8 @@ def sepconv_gru(packs, hx: Tensor, h_channels: int, z: Tensor, rh: Tensor) -> No
             g.wp_zr_f16, g.wp_q_f16 = pzr.wp16.data_ptr(), pq.wp16.data_ptr()
         if pzr.wp_alt is not None and pq.wp_alt is not None:
             g.wp_zr_k32, g.wp_q_k32 = pzr.wp_alt.data_ptr(), pq.wp_alt.data_ptr()
+        if pzr.wp4s is not None and pq.wp4s is not None and pzr.g4s == pq.g4s:
+            g.wp_zr_a4s, g.wp_q_a4s, g.a4s_groups = pzr.wp4s.data_ptr(), pq.wp4s.data_ptr(), pzr.g4s
     _lib.check(_lib.load().scf_sepconv_gru(p, sn, n, h_channels, c - h_channels, h, w, arr, len(packs),
                                            _dense(z, 'z'), _dense(rh, 'rh'), _stream()),
                'scf_sepconv_gru')

@@ -470,6 +470,13 @@ def test_sepconv_gru_c_entry(n, h, w, kind):
             assert lib.scf_pack_conv_weight(wt.data_ptr(), co, ci, kh, kw, 32, a32.data_ptr()) == 0
             bufs.append(a32.to(DEV))
         g.wp_zr_k32, g.wp_q_k32 = bufs[6].data_ptr(), bufs[7].data_ptr()
+        grps = ops.choose_a4s_groups(ch + cx, k[0], k[1], 1)      # small-grid a4 packings (bigger chunks)
+        for wt in (wzr, wq.contiguous()):
+            co, ci, kh, kw = wt.shape
+            a4s = torch.empty(lib.scf_pack_conv_weight_a4_size(co, ci, kh, kw, grps))
+            assert lib.scf_pack_conv_weight_a4(wt.data_ptr(), co, ci, kh, kw, grps, a4s.data_ptr()) == 0
+            bufs.append(a4s.to(DEV))
+        g.wp_zr_a4s, g.wp_q_a4s, g.a4s_groups = bufs[8].data_ptr(), bufs[9].data_ptr(), grps
         keep += bufs
         g.KH, g.KW, g.pad_h, g.pad_w = k[0], k[1], pad[0], pad[1]
         g.wp_zr, g.wp_zr_a4, g.wp_q, g.wp_q_a4 = (t.data_ptr() for t in bufs[:4])
@@ -540,7 +547,10 @@ def test_conv2d_small_grid_kernels(case):
     d.wp, d.Mld, d.Cout, d.KC = pc.wp.data_ptr(), pc.mld, cout, pc.kc
     d.KH, d.KW, d.stride, d.pad_h, d.pad_w = pc.kh, pc.kw, stride, pc.pad_h, pc.pad_w
     d.out, d.out_nstride, d.out_div = got.data_ptr(), got.stride(0), 1.0
-    d.wp_a4, d.a4_groups, d.a4_mld = pc.wp4.data_ptr(), pc.g4, pc.mld
+    if pc.wp4 is not None:
+        d.wp_a4, d.a4_groups, d.a4_mld = pc.wp4.data_ptr(), pc.g4, pc.mld
+    if pc.wp4s is not None:
+        d.wp_a4s, d.a4s_groups, d.a4_mld = pc.wp4s.data_ptr(), pc.g4s, pc.mld
     info = (C.c_int32 * 4)()
     assert _lib.load().scf_conv2d_query(C.byref(d), info) == 0 and info[3] < 0, list(info)
     # residual + no activation, output into a channel slice
