@@ -82,6 +82,20 @@ __device__ __forceinline__ int fast_div(int e, int d, float rd) {
   return q;
 }
 
+#ifdef SCF_CONV_TRACE      /* lab builds only (tools/lab/conv_trace.py): s_memrealtime stamps of block 0 */
+__device__ unsigned long long* scf_conv_trace_ptr = nullptr;
+extern "C" int scf_conv_trace_set(unsigned long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(scf_conv_trace_ptr), &p, sizeof(p)) == hipSuccess ? 0 : -3;
+}
+#define CTRACE(slot)                                                                              \
+  do {                                                                                            \
+    if (scf_conv_trace_ptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (slot) < 256)         \
+      scf_conv_trace_ptr[(threadIdx.x >> 6) * 256 + (slot)] = __builtin_amdgcn_s_memrealtime();   \
+  } while (0)
+#else
+#define CTRACE(slot) do { } while (0)
+#endif
+
 // s_waitcnt vmcnt(n) for a wave-uniform RUN-TIME n (the instruction takes an immediate)
 template <int V>
 __device__ __forceinline__ void wait_vmcnt_imm() {
@@ -114,6 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   constexpr int PU = KSP ? SCF_DMA_PU_KSP : SCF_DMA_PU;
 
   __builtin_amdgcn_s_setprio(3);       // setup / staging / epilogue instructions go first
+  CTRACE(0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, half = lane >> 5;
@@ -242,10 +257,12 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   // DMA instructions this wave issues per chunk (the same for every chunk): vmcnt bookkeeping
   const int cnt = __builtin_amdgcn_readfirstlane(((PE + 255) >> 8) + ((WF4 + 255) >> 8));
 
+  CTRACE(1);
   __syncthreads();                     // zero fill complete before any DMA data can land
 #pragma unroll
   for (int c = 0; c < NST - 1; ++c)
     if (c < p.nchunk) stage(c, c);
+  CTRACE(2);
 
   int buf = 0;                         // ring slot of the current chunk
   for (int chunk = 0; chunk < p.nchunk; ++chunk) {
@@ -257,8 +274,11 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
       const int later = min(NST - 2, p.nchunk - 1 - chunk);
       wait_vmcnt_le(later * cnt);
     }
+    CTRACE(4 + chunk * 4);
     __syncthreads();                                   // everyone's has; previous MFMA phase done
+    CTRACE(5 + chunk * 4);
     if (chunk + NST - 1 < p.nchunk) stage(chunk + NST - 1, buf == 0 ? NST - 1 : buf - 1);
+    CTRACE(6 + chunk * 4);
     __builtin_amdgcn_s_setprio(0);                     // the MFMA stream yields to the other waves
 
     const f32x4* wl = reinterpret_cast<const f32x4*>(lds + buf * bufsz) + half * BM + l32;
@@ -296,6 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
           acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s4], b1[s4], acc2, 0, 0, 0);
         it += 4;
       }
+      CTRACE(7 + chunk * 4);
       continue;
     }
     f32x4 a[2][WM], b[2][WN];
@@ -356,6 +377,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
       // the four consecutive rows 8w + 4 half .. + 3
       scf_conv_epilogue_group(p, epi, v, m0 + 8 * wave + 4 * half, pixk, p.out_div != 1.0f);
     }
+    CTRACE(3);
     return;
   }
 
