@@ -27,6 +27,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SCF_DMA_WU 7    // weight float4 per thread per chunk
 #define SCF_DMA_PU_KSP 24   // K-split tile (small grids: 32-channel chunks, one wave per SIMD: registers are free)
 #define SCF_DMA_WU_KSP 9
+#ifndef SCF_PX4_MODE
+#define SCF_PX4_MODE 3      // bit 0: full-grid tiles, bit 1: small-grid tiles (lab builds vary this)
+#endif
+#define SCF_DMA_PU_X4 8     // PX4: float4 patch cells per thread per chunk (256 * 8 * 4 floats)
 #define SCF_DMA_LDS_MAX (80 * 1024)   // two blocks per CU (160 KB)
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -119,13 +123,19 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 // KSP   : K-split tile for small grids: 32 channels x ONE 32-pixel fragment per block (4x the
 //         blocks of the smallest pixel-split tile); the four waves take every fourth (tap, group)
 //         step of each chunk and combine their partial sums through LDS in a fixed order.
-template <int WM, int WN, int NST = 2, bool KSP = false>
+// PX4   : (stride 1, W % 4 == 0) the patch is staged as PLAIN channel planes [KC][PH][PWa] with
+//         dwordx4 DMA: a patch row starts at the 16-byte-aligned column ixa = ix0 - px_off, so every
+//         lane moves one aligned group of 4 columns that lies wholly inside or wholly outside the
+//         image (4x fewer patch DMA instructions, contiguous instead of 4-plane interleaved gathers:
+//         ~125 vs 4 x 117 cycles of texture-path time per KiB).  B operands are then read with four
+//         ds_read_b32 per (tap, group) step instead of one ds_read_b128.
+template <int WM, int WN, int NST = 2, bool KSP = false, bool PX4 = false>
 __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(!KSP || (WM == 1 && WN == 1), "K-split tile is one 32x32 fragment");
   constexpr int BM = WM * 32;
   constexpr int NFRAG = KSP ? 1 : WN * 4;
-  constexpr int PU = KSP ? SCF_DMA_PU_KSP : SCF_DMA_PU;
+  constexpr int PU = PX4 ? SCF_DMA_PU_X4 : KSP ? SCF_DMA_PU_KSP : SCF_DMA_PU;
 
   __builtin_amdgcn_s_setprio(3);       // setup / staging / epilogue instructions go first
   CTRACE(0);
@@ -176,7 +186,16 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
     const int e = tid + u * 256;
     bool ok = false;
     unsigned o = 0;
-    if (u * 256 < PE) {
+    if (PX4) {                         // e = float4 cell: (channel c, row py, aligned column group p4)
+      if (u * 1024 < PE) {
+        const int PW4 = PW >> 2, PHW4 = PHW >> 2;
+        const int c = fast_div(e, PHW4, 1.0f / (float)PHW4), r = e - c * PHW4;
+        const int py = fast_div(r, PW4, 1.0f / (float)PW4), p4 = r - py * PW4;
+        const int iy = iy0 + py, ix = ix0 - p.px_off + 4 * p4;
+        ok = e * 4 < PE && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        o = (unsigned)(c * HWin + iy * p.W + ix) * 4u;
+      }
+    } else if (u * 256 < PE) {
       const int s = e & 3, q = e >> 2;
       const int gh = fast_div(q, PHW, rPHW), r = q - gh * PHW;
       const int py = fast_div(r, PW, rPW), pxs = r - py * PW;
@@ -202,7 +221,9 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   const int fr = l32 >> p.fc_log2, fc = l32 & (FC - 1);
   int boff[WN];                        // float4 index of this lane's pixel, fragment j, tap (0,0)
 #pragma unroll
-  for (int j = 0; j < WN; ++j) boff[j] = ((KSP ? 0 : (wave * WN + j)) * FR + fr) * st * PW + fc + half * PHW;
+  for (int j = 0; j < WN; ++j)
+    boff[j] = ((KSP ? 0 : (wave * WN + j)) * FR + fr) * st * PW + fc + half * PHW + (PX4 ? p.px_off : 0);
+  // (PX4: FLOAT index into the plain planes; lane half h reads channel 2s + h: + h * PHW)
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -231,9 +252,26 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
     // site counts re-materialised per call (one s_cmp per site): left to itself hipcc hoists the
     // 27 loop-invariant guards out of the chunk loop as 64-bit masks, spills them, and reloads
     // each with two v_readlane -- VALU slots the co-resident wave's MFMA stream leaves scarce
-    int npu = (PE + 255) >> 8, nwu = (WF4 + 255) >> 8;
+    int npu = PX4 ? (PE / 4 + 255) >> 8 : (PE + 255) >> 8, nwu = (WF4 + 255) >> 8;
     asm volatile("" : "+s"(npu), "+s"(nwu));
-    if (nvalid >= KC) {                // chunk-invariant masks apply
+    if (PX4) {
+      if (nvalid >= KC) {
+#pragma unroll
+        for (int u = 0; u < PU; ++u)
+          if (u < npu) dma_b128_v(base, toff[u], lds_addr(pb + (u * 256 + wave * 64) * 4));
+      } else {                         // last chunk of a segment: channels past the end are zero
+        const unsigned limit = (unsigned)nvalid * (unsigned)HWin * 4u;
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+          if (u * 1024 < PE) {
+            const bool in = toff[u] < limit;
+            dma_b128(base, toff[u], lds_addr(pb + (u * 256 + wave * 64) * 4), __ballot(in));
+            if (!in && toff[u] != 0xFFFFFFFFu)
+              *reinterpret_cast<f32x4*>(pb + (u * 256 + tid) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      }
+    } else if (nvalid >= KC) {         // chunk-invariant masks apply
 #pragma unroll
       for (int u = 0; u < PU; ++u)
         if (u < npu) dma_b32_v(base, toff[u], lds_addr(pb + u * 256 + wave * 64));
@@ -255,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   };
 
   // DMA instructions this wave issues per chunk (the same for every chunk): vmcnt bookkeeping
-  const int cnt = __builtin_amdgcn_readfirstlane(((PE + 255) >> 8) + ((WF4 + 255) >> 8));
+  const int cnt = __builtin_amdgcn_readfirstlane((PX4 ? (PE / 4 + 255) >> 8 : (PE + 255) >> 8) + ((WF4 + 255) >> 8));
 
   CTRACE(1);
   __syncthreads();                     // zero fill complete before any DMA data can land
@@ -294,9 +332,16 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
       int ky = 0, kx = wave >> gshift;
       while (kx >= p.KW) { kx -= p.KW; ++ky; }
       const f32x4* pg = pl + g * 2 * PHW + boff[0];
+      const float* pgf = reinterpret_cast<const float*>(pl) + g * 8 * PHW + boff[0];   // PX4
       auto opnd = [&](int it, f32x4& aa, f32x4& bb) {
         aa = wl[it * 2 * BM];
-        bb = pg[ky * PW + (st == 1 ? kx : (kx & 1) * PWh + (kx >> 1))];
+        if (PX4) {
+          const float* q = pgf + ky * PW + kx;
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) bb[s4] = q[2 * s4 * PHW];
+        } else {
+          bb = pg[ky * PW + (st == 1 ? kx : (kx & 1) * PWh + (kx >> 1))];
+        }
         kx += tstep;
         while (kx >= p.KW) { kx -= p.KW; ++ky; }
       };
@@ -323,11 +368,19 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
     int lg = 0, lky = 0, lkx = 0;                     // (tap, group) of the next operand load
     auto load = [&](f32x4 (&aa)[WM], f32x4 (&bb)[WN], int it) {
       const f32x4* wt = wl + it * 2 * BM;
-      const f32x4* pt = pl + lg * 2 * PHW + lky * PW + (st == 1 ? lkx : (lkx & 1) * PWh + (lkx >> 1));
 #pragma unroll
       for (int i = 0; i < WM; ++i) aa[i] = wt[i * 32];
+      if (PX4) {
+        const float* ptf = reinterpret_cast<const float*>(pl) + lg * 8 * PHW + lky * PW + lkx;
 #pragma unroll
-      for (int j = 0; j < WN; ++j) bb[j] = pt[boff[j]];
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) bb[j][s4] = ptf[boff[j] + 2 * s4 * PHW];
+      } else {
+        const f32x4* pt = pl + lg * 2 * PHW + lky * PW + (st == 1 ? lkx : (lkx & 1) * PWh + (lkx >> 1));
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bb[j] = pt[boff[j]];
+      }
       if (++lg == G) {
         lg = 0;
         if (++lkx == p.KW) { lkx = 0; ++lky; }
@@ -342,15 +395,25 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
           for (int j = 0; j < WN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[i][s], bb[j][s], acc[i][j], 0, 0, 0);
     };
+    // Steady state without conditions around the loads: with a conditional load the compiler's
+    // wait-count insertion falls back to lgkmcnt(0) at the join, i.e. it waits for the operands it
+    // has just requested for the NEXT step before starting this step's MFMAs.
     load(a[0], b[0], 0);
-    for (int it = 0; it < NIT; it += 2) {
-      if (it + 1 < NIT) load(a[1], b[1], it + 1);
+    int it = 0;
+    for (; it + 2 < NIT; it += 2) {
+      load(a[1], b[1], it + 1);
       mma(a[0], b[0]);
-      if (it + 1 < NIT) {
-        if (it + 2 < NIT) load(a[0], b[0], it + 2);
-        mma(a[1], b[1]);
-      }
+      load(a[0], b[0], it + 2);
+      mma(a[1], b[1]);
     }
+    if (it + 1 < NIT) {
+      load(a[1], b[1], it + 1);
+      mma(a[0], b[0]);
+      mma(a[1], b[1]);
+    } else {
+      mma(a[0], b[0]);
+    }
+    CTRACE(7 + chunk * 4);
   }
 
   if (KSP) {
@@ -395,11 +458,12 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
     pix[j] = pok ? lin : -1;
   }
   scf_conv_epilogue_tile<WM, WN>(p, epi, acc, m0, half, pix, use_div);
+  CTRACE(3);
 }
 
 #define SCF_DMA_LDS_DEEP (144 * 1024)  // deep rings on small grids: one block per CU
 
-template <int WM, int WN, int NST = 2, bool KSP = false>
+template <int WM, int WN, int NST = 2, bool KSP = false, bool PX4 = false>
 static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
   if (lds_bytes > 64 * 1024) {       // opt in to > 64 KiB of dynamic LDS: once per instantiation AND device
     static std::atomic<unsigned long long> raised{0};      // bit d: done on device d
@@ -407,14 +471,14 @@ static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st
     if (hipGetDevice(&dev) != hipSuccess) return SCF_ELAUNCH;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(raised.load(std::memory_order_relaxed) & bit)) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WM, WN, NST, KSP>),
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WM, WN, NST, KSP, PX4>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               NST == 2 ? SCF_DMA_LDS_MAX : SCF_DMA_LDS_DEEP) != hipSuccess)
         return SCF_ELAUNCH;
       raised.fetch_or(bit, std::memory_order_relaxed);
     }
   }
-  scf_launch((conv_dma_kernel<WM, WN, NST, KSP>), dim3(nblk), dim3(256), lds_bytes, st, k);
+  scf_launch((conv_dma_kernel<WM, WN, NST, KSP, PX4>), dim3(nblk), dim3(256), lds_bytes, st, k);
   return scf_launch_status();
 }
 
@@ -430,6 +494,15 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   const int frags_m = (k.Cout + 31) / 32;
   int G = k.wp4 ? k.G4 : 0;
   int KC = 8 * G;
+  // aligned dwordx4 patch staging (PX4): stride 1, rows and planes that keep 16-byte alignment
+  const bool px4_ok = k.stride == 1 && FC >= 4 && (k.W & 3) == 0 && (k.in0_ns & 3) == 0 &&
+                      ((uintptr_t)k.in0 & 15) == 0 &&
+                      (!k.in1 || ((k.in1_ns & 3) == 0 && ((uintptr_t)k.in1 & 15) == 0));
+  const bool px4_large = px4_ok && (SCF_PX4_MODE & 1), px4_small = px4_ok && (SCF_PX4_MODE & 2);
+  const int px_off = (4 - (k.pad_w & 3)) & 3;
+  auto pitch = [&](int PWin, bool px4) {
+    return px4 ? (px_off + PWin + 3) & ~3 : k.stride == 1 ? PWin : ((PWin + 1) / 2) * 2;
+  };
   const bool pix_ok = k.wp4 && (G == 1 || G == 2 || G == 4) && !(k.in1 && (k.C0 % KC) != 0);
   // candidates in order of preference; WM must divide the channel fragments (no idle MFMA
   // rows) unless nothing else fits; take the first that gives >= 2 blocks per CU, else the one
@@ -445,11 +518,12 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
       if (pass == 0 && frags_m % WM != 0) continue;
       const int TR = WN * 4 * FR;
       const int PH = (TR - 1) * k.stride + k.KH, PWin = (FC - 1) * k.stride + k.KW;
-      const int PW = k.stride == 1 ? PWin : ((PWin + 1) / 2) * 2;
+      const int PW = pitch(PWin, px4_large);
       const long long PE = (long long)KC * PH * PW;
       const long long WF4 = (long long)k.T * G * 2 * WM * 32;
       const size_t ldsb = (size_t)(WF4 * 4 + PE) * 2 * sizeof(float);
-      if (PE > 256 * SCF_DMA_PU || WF4 > 256 * SCF_DMA_WU || ldsb > SCF_DMA_LDS_MAX) continue;
+      if (PE > (px4_large ? 1024 * SCF_DMA_PU_X4 : 256 * SCF_DMA_PU) || WF4 > 256 * SCF_DMA_WU ||
+          ldsb > SCF_DMA_LDS_MAX) continue;
       const long long blk = (long long)N * ((k.Ho + TR - 1) / TR) * ((k.Wo + FC - 1) / FC) *
                             ((frags_m + WM - 1) / WM);
       if (best < 0 || blk > best_blk) { best = c; best_blk = blk; best_lds = ldsb; }
@@ -470,7 +544,7 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   }
   if (KC) k.nchunk = (k.Cin + KC - 1) / KC;
   int WM = 1, WN = 1, NST = 2;
-  bool ksp = false;
+  bool ksp = false, px4 = false;
   long long nblk = 0;
   size_t ldsb = 0;
   if (best >= 0 && best_blk >= 256) {                  // pixel-split tile
@@ -487,6 +561,7 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
     const int TR = WN * 4 * FR;
     k.PH = (TR - 1) * k.stride + k.KH;
     k.tiles_y = (k.Ho + TR - 1) / TR;
+    px4 = px4_large;
   } else {                                             // K-split tile: one 32-pixel fragment per block
     if (k.wp4s && (k.G4s == 1 || k.G4s == 2 || k.G4s == 4) && !(k.in1 && (k.C0 % (8 * k.G4s)) != 0)) {
       k.wp4 = k.wp4s; k.G4 = k.G4s;                    // the small-grid packing: bigger chunks
@@ -496,9 +571,10 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
     G = k.G4; KC = 8 * G;
     k.nchunk = (k.Cin + KC - 1) / KC;
     const int PH = (FR - 1) * k.stride + k.KH, PWin = (FC - 1) * k.stride + k.KW;
-    const int PW = k.stride == 1 ? PWin : ((PWin + 1) / 2) * 2;
+    px4 = px4_small;
+    const int PW = pitch(PWin, px4);
     const long long PE = (long long)KC * PH * PW, WF4 = (long long)k.T * G * 2 * 32;
-    if (PE > 256 * SCF_DMA_PU_KSP || WF4 > 256 * SCF_DMA_WU_KSP) return SCF_EUNSUPPORTED;
+    if (PE > (px4 ? 1024 * SCF_DMA_PU_X4 : 256 * SCF_DMA_PU_KSP) || WF4 > 256 * SCF_DMA_WU_KSP) return SCF_EUNSUPPORTED;
     const size_t stage_b = (size_t)(WF4 * 4 + PE) * sizeof(float);
     NST = k.nchunk >= 6 && stage_b * 6 <= SCF_DMA_LDS_DEEP ? 6 : k.nchunk >= 3 && stage_b * 4 <= SCF_DMA_LDS_DEEP ? 4 : 2;
     ldsb = stage_b * NST;
@@ -511,26 +587,30 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   }
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
   k.PWin = (FC - 1) * k.stride + k.KW;                       // input columns a tile needs
-  k.PW = k.stride == 1 ? k.PWin : ((k.PWin + 1) / 2) * 2;     // LDS row pitch
+  k.PW = pitch(k.PWin, px4);                                  // LDS row pitch
+  k.px_off = px4 ? px_off : 0;
   k.tiles_x = (k.Wo + FC - 1) / FC;
   k.mblocks = (frags_m + WM - 1) / WM;
   if (info) { info[0] = WM; info[1] = WN; info[2] = (int)nblk; info[3] = k.T * G * 4 * WM * WN / (ksp ? 4 : 1); }
   if (dry_run) return SCF_OK;
+#define SCF_GO(...) return px4 ? launch_dma<__VA_ARGS__, true>(k, (int)nblk, ldsb, st)            \
+                               : launch_dma<__VA_ARGS__, false>(k, (int)nblk, ldsb, st)
   if (ksp) {
-    if (NST == 6) return launch_dma<1, 1, 6, true>(k, (int)nblk, ldsb, st);
-    if (NST == 4) return launch_dma<1, 1, 4, true>(k, (int)nblk, ldsb, st);
-    return launch_dma<1, 1, 2, true>(k, (int)nblk, ldsb, st);
+    if (NST == 6) SCF_GO(1, 1, 6, true);
+    if (NST == 4) SCF_GO(1, 1, 4, true);
+    SCF_GO(1, 1, 2, true);
   }
   if (NST == 4) {
-    if (WM == 1) return launch_dma<1, 1, 4>(k, (int)nblk, ldsb, st);
-    return launch_dma<2, 1, 4>(k, (int)nblk, ldsb, st);
+    if (WM == 1) SCF_GO(1, 1, 4, false);
+    SCF_GO(2, 1, 4, false);
   }
   if (NST == 3) {
-    if (WM == 1) return launch_dma<1, 1, 3>(k, (int)nblk, ldsb, st);
-    return launch_dma<2, 1, 3>(k, (int)nblk, ldsb, st);
+    if (WM == 1) SCF_GO(1, 1, 3, false);
+    SCF_GO(2, 1, 3, false);
   }
-#define SCF_CASE(M, Nn) if (WM == M && WN == Nn) return launch_dma<M, Nn>(k, (int)nblk, ldsb, st);
+#define SCF_CASE(M, Nn) if (WM == M && WN == Nn) SCF_GO(M, Nn, 2, false);
   SCF_CASE(2, 2) SCF_CASE(3, 1) SCF_CASE(2, 1) SCF_CASE(1, 1)
 #undef SCF_CASE
+#undef SCF_GO
   return SCF_EUNSUPPORTED;
 }
