@@ -497,7 +497,7 @@ def main():
             for us, fl, tag in conv_launches:
                 a = by_shape.setdefault(tag, [0, 0.0, 0.0])
                 a[0] += 1; a[1] += us; a[2] += fl
-            top = sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:14]
+            top = sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('SCF_BENCH_TOP_LAYERS', '14'))]
             result['roofline_conv'] = {
                 'kernel': 'conv_dma_kernel / conv_mfma_kernel (all convolution launches of one step)',
                 'bound': 'mfma', 'achieved': round(c_fl / (c_us * 1e-6) / 1e12, 1),

@@ -30,6 +30,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef SCF_PX4_MODE
 #define SCF_PX4_MODE 3      // bit 0: full-grid tiles, bit 1: small-grid tiles (lab builds vary this)
 #endif
+#ifndef SCF_DMA_STAGGER_S
+#define SCF_DMA_STAGGER_S -1     // cycles a block spends per chunk outside its MFMA loop (-1: no stagger; lab builds set it)
+#endif
 #define SCF_DMA_PU_X4 8     // PX4: float4 patch cells per thread per chunk (256 * 8 * 4 floats)
 #define SCF_DMA_LDS_MAX (80 * 1024)   // two blocks per CU (160 KB)
 
@@ -37,22 +40,53 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
 
-// LDS-DMA, 16 / 4 bytes per lane: lane l's data lands at lds_base + l*16 (l*4); source = scalar
-// base + 32-bit per-lane byte offset; only the lanes of `mask` take part.  Everything that
-// touches EXEC / M0 sits in ONE statement (both are restored to "all lanes" / don't-care before
-// the compiler gets control back; the kernel runs with all 64 lanes active here).  The compiler
-// does not count these loads: the caller waits (vmcnt) itself.
-__device__ __forceinline__ void dma_b128(const void* sbase, unsigned voff, unsigned lds_base,
-                                         unsigned long long mask) {
-  asm volatile("s_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %1, %0\n\ts_mov_b64 exec, -1"
-               : : "s"(sbase), "v"(voff), "s"(lds_base), "s"(mask) : "memory");
+// LDS-DMA through a raw buffer descriptor: `buffer_load_dword[x4] voff, rsrc, 0 offen lds` moves
+// 4 / 16 bytes per lane from rsrc.base + voff to LDS byte M0 + lane * size.  The descriptor's
+// range check does the masking: a lane whose offset is >= num_records writes ZEROS to its LDS
+// cell (checked on gfx950: tools/lab/buf_lds_test.hip), so zero padding, out-of-image positions
+// and the channels past the end of a short last chunk need no EXEC mask, no pre-zeroed LDS and
+// no special path -- and no EXEC write after a vector-memory instruction (~35 cycles of issue
+// stall each: tools/lab/dma_rate.hip).  The compiler does not count these loads: the caller
+// waits (vmcnt) itself.
+typedef int scf_rsrc_t __attribute__((ext_vector_type(4)));
+#define SCF_DMA_OOB 0x80000000u        // an offset past every descriptor range: the lane's cell is zeroed
+
+__device__ __forceinline__ scf_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  scf_rsrc_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu));   // stride 0: raw buffer
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);                             // num_records (bytes)
+  r[3] = 0x00020000;
+  return r;
 }
-__device__ __forceinline__ void dma_b32(const void* sbase, unsigned voff, unsigned lds_base,
-                                        unsigned long long mask) {
-  asm volatile("s_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-               "global_load_lds_dword %1, %0\n\ts_mov_b64 exec, -1"
-               : : "s"(sbase), "v"(voff), "s"(lds_base), "s"(mask) : "memory");
+__device__ __forceinline__ void bdma_b128(scf_rsrc_t rsrc, unsigned voff, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %0, 0 offen lds"
+               : : "s"(rsrc), "v"(voff), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void bdma_b32(scf_rsrc_t rsrc, unsigned voff, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %0, 0 offen lds"
+               : : "s"(rsrc), "v"(voff), "s"(lds_base) : "memory");
+}
+// the first n (0 < n < 64) lanes only: the last, partial slot of an LDS area
+__device__ __forceinline__ void bdma_b128_n(scf_rsrc_t rsrc, unsigned voff, unsigned lds_base, int n) {
+  asm volatile("s_bfm_b64 exec, %3, 0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "buffer_load_dwordx4 %1, %0, 0 offen lds\n\ts_mov_b64 exec, -1"
+               : : "s"(rsrc), "v"(voff), "s"(lds_base), "s"(n) : "memory");
+}
+__device__ __forceinline__ void bdma_b32_n(scf_rsrc_t rsrc, unsigned voff, unsigned lds_base, int n) {
+  asm volatile("s_bfm_b64 exec, %3, 0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "buffer_load_dword %1, %0, 0 offen lds\n\ts_mov_b64 exec, -1"
+               : : "s"(rsrc), "v"(voff), "s"(lds_base), "s"(n) : "memory");
+}
+// one slot of an area of `count` cells: this wave's 64 lanes hold cells [first, first + 64)
+template <bool X4>
+__device__ __forceinline__ void bdma_slot(scf_rsrc_t rsrc, unsigned voff, unsigned lds_base, int rem) {
+  if (rem >= 64) {
+    if (X4) bdma_b128(rsrc, voff, lds_base); else bdma_b32(rsrc, voff, lds_base);
+  } else if (rem > 0) {
+    if (X4) bdma_b128_n(rsrc, voff, lds_base, rem); else bdma_b32_n(rsrc, voff, lds_base, rem);
+  }
 }
 
 // a pointer the compiler keeps in SGPRs (block-uniform by construction)
@@ -86,15 +120,24 @@ __device__ __forceinline__ int fast_div(int e, int d, float rd) {
   return q;
 }
 
-#ifdef SCF_CONV_TRACE      /* lab builds only (tools/lab/conv_trace.py): s_memrealtime stamps of block 0 */
+#ifdef SCF_CONV_TRACE      /* lab builds only (tools/lab/conv_trace*.py): s_memrealtime stamps of the first blocks */
 __device__ unsigned long long* scf_conv_trace_ptr = nullptr;
-extern "C" int scf_conv_trace_set(unsigned long long* p) {
+__device__ int scf_conv_trace_nblk = 0;
+extern "C" int scf_conv_trace_set(unsigned long long* p, int nblk) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(scf_conv_trace_nblk), &nblk, sizeof(nblk)) != hipSuccess) return -3;
   return hipMemcpyToSymbol(HIP_SYMBOL(scf_conv_trace_ptr), &p, sizeof(p)) == hipSuccess ? 0 : -3;
 }
+// [block][wave][128]: slot 0 entry, 1 setup, 2 prologue, 3 end, 4 + 4c.. chunk c (wait, barrier, stage, mfma),
+// slot 127 = HW_ID | XCC_ID << 32
 #define CTRACE(slot)                                                                              \
   do {                                                                                            \
-    if (scf_conv_trace_ptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (slot) < 256)         \
-      scf_conv_trace_ptr[(threadIdx.x >> 6) * 256 + (slot)] = __builtin_amdgcn_s_memrealtime();   \
+    if (scf_conv_trace_ptr && (int)blockIdx.x < scf_conv_trace_nblk && (threadIdx.x & 63) == 0 && (slot) < 125) { \
+      unsigned long long* tp_ = scf_conv_trace_ptr + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 128; \
+      tp_[slot] = __builtin_amdgcn_s_memrealtime();                                               \
+      if ((slot) == 0 || (slot) == 3) tp_[(slot) == 0 ? 125 : 126] = __builtin_readcyclecounter();  /* shader clock */ \
+      if ((slot) == 0) tp_[127] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | \
+                                  ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32); \
+    }                                                                                             \
   } while (0)
 #else
 #define CTRACE(slot) do { } while (0)
@@ -169,15 +212,9 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   const int PE = KC * PHW;             // patch floats per chunk
   const int bufsz = WF4 * 4 + PE;      // floats per buffer (multiple of 4)
 
-  // ---- zero every patch area (padding positions stay zero for the whole kernel) ----
-  for (int b = 0; b < NST; ++b) {
-    f32x4* z = reinterpret_cast<f32x4*>(lds + b * bufsz + WF4 * 4);
-    for (int i = tid; i < PE / 4; i += 256) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-
   // ---- gather table: LDS patch float e = tid + 256u <-> (group g, half h, py, px, s) ----
-  // Chunk-invariant: byte offset from the chunk's first channel plane + a lane mask per u
-  // (out-of-image positions are never fetched: they keep the zeros written above).
+  // Chunk-invariant: byte offset from the chunk's first channel plane; out-of-image positions get
+  // SCF_DMA_OOB (the descriptor's range check writes zeros there).
   const int HWin = p.H * p.W;
   const float rPHW = 1.0f / (float)PHW, rPW = 1.0f / (float)PW;
   unsigned toff[PU];
@@ -205,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
       ok = e < PE && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && px < p.PWin;
       o = (unsigned)(c * HWin + iy * p.W + ix) * 4u;
     }
-    toff[u] = ok ? o : 0xFFFFFFFFu;
+    toff[u] = ok ? o : SCF_DMA_OOB;
   }
   // weights: float4 e = tid + 256u of the chunk's [NIT*2 rows][BM] slab out of [rows][Mld4]
   constexpr int WU = KSP ? SCF_DMA_WU_KSP : SCF_DMA_WU;
@@ -215,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
     const int e = tid + u * 256;
     const int row = e / BM, m = e - row * BM;
     const bool ok = e < WF4 && m0 + m < p.Mld4;
-    woff[u] = ok ? (unsigned)((row * p.Mld4 + m) * 16) : 0xFFFFFFFFu;
+    woff[u] = ok ? (unsigned)((row * p.Mld4 + m) * 16) : SCF_DMA_OOB;
   }
 
   const int fr = l32 >> p.fc_log2, fc = l32 & (FC - 1);
@@ -240,6 +277,12 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
   const float* in1n = p.in1 ? p.in1 + (long long)n * p.in1_ns : nullptr;
   const long long wrow = (long long)p.Mld4 * 4;      // floats per (chunk, tap, g, h) weight row
 
+  // cells of the patch / weight areas (a cell = one lane's DMA unit) and this wave's share of them
+  const int pcells = PX4 ? PE >> 2 : PE;
+  const int prem0 = pcells - wave * 64, wrem0 = WF4 - wave * 64;   // cells from this wave's first lane on, slot 0
+  const long long wslab = (long long)NIT * 2 * wrow;               // floats per chunk of packed weights
+  const unsigned wbytes = (unsigned)(((long long)(NIT * 2 - 1) * p.Mld4 + min(BM, p.Mld4 - m0)) * 16);
+
   auto stage = [&](int chunk, int b) {
     float* wb = lds + b * bufsz;
     float* pb = wb + WF4 * 4;
@@ -248,59 +291,41 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvK p) {
     int nvalid;
     if (c0 < p.C0) { base = in0n + (long long)c0 * HWin; nvalid = p.C0 - c0; }
     else { base = in1n + (long long)(c0 - p.C0) * HWin; nvalid = p.Cin - c0; }
-    base = (const float*)sgpr_ptr(base);
-    // site counts re-materialised per call (one s_cmp per site): left to itself hipcc hoists the
-    // 27 loop-invariant guards out of the chunk loop as 64-bit masks, spills them, and reloads
+    // channels past the end of a segment's last chunk fall outside the descriptor: zeros
+    const scf_rsrc_t prs = make_rsrc(base, (unsigned)min(nvalid, KC) * (unsigned)HWin * 4u);
+    const scf_rsrc_t wrs = make_rsrc(p.wp4 + (long long)chunk * wslab + (long long)m0 * 4, wbytes);
+    // slot counts re-materialised per call (scalar compares per site): left to itself hipcc hoists
+    // the loop-invariant guards out of the chunk loop as 64-bit masks, spills them, and reloads
     // each with two v_readlane -- VALU slots the co-resident wave's MFMA stream leaves scarce
-    int npu = PX4 ? (PE / 4 + 255) >> 8 : (PE + 255) >> 8, nwu = (WF4 + 255) >> 8;
-    asm volatile("" : "+s"(npu), "+s"(nwu));
-    if (PX4) {
-      if (nvalid >= KC) {
+    int prem = prem0, wrem = wrem0;
+    asm volatile("" : "+s"(prem), "+s"(wrem));
+    const unsigned pl0 = lds_addr(pb) + wave * (PX4 ? 1024 : 256), wl0 = lds_addr(wb) + wave * 1024;
 #pragma unroll
-        for (int u = 0; u < PU; ++u)
-          if (u < npu) dma_b128_v(base, toff[u], lds_addr(pb + (u * 256 + wave * 64) * 4));
-      } else {                         // last chunk of a segment: channels past the end are zero
-        const unsigned limit = (unsigned)nvalid * (unsigned)HWin * 4u;
-#pragma unroll
-        for (int u = 0; u < PU; ++u) {
-          if (u * 1024 < PE) {
-            const bool in = toff[u] < limit;
-            dma_b128(base, toff[u], lds_addr(pb + (u * 256 + wave * 64) * 4), __ballot(in));
-            if (!in && toff[u] != 0xFFFFFFFFu)
-              *reinterpret_cast<f32x4*>(pb + (u * 256 + tid) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-        }
-      }
-    } else if (nvalid >= KC) {         // chunk-invariant masks apply
-#pragma unroll
-      for (int u = 0; u < PU; ++u)
-        if (u < npu) dma_b32_v(base, toff[u], lds_addr(pb + u * 256 + wave * 64));
-    } else {                           // last chunk of a segment: channels past the end are zero
-      const unsigned limit = (unsigned)nvalid * (unsigned)HWin * 4u;
-#pragma unroll
-      for (int u = 0; u < PU; ++u) {
-        if (u * 256 < PE) {
-          const bool in = toff[u] < limit;
-          dma_b32(base, toff[u], lds_addr(pb + u * 256 + wave * 64), __ballot(in));
-          if (!in && toff[u] != 0xFFFFFFFFu) pb[u * 256 + tid] = 0.f;
-        }
-      }
-    }
-    const float* wsrc = (const float*)sgpr_ptr(p.wp4 + (long long)chunk * NIT * 2 * wrow + (long long)m0 * 4);
+    for (int u = 0; u < PU; ++u)
+      bdma_slot<PX4>(prs, toff[u], pl0 + u * (PX4 ? 4096 : 1024), prem - u * 256);
 #pragma unroll
     for (int u = 0; u < WU; ++u)
-      if (u < nwu) dma_b128_v(wsrc, woff[u], lds_addr(wb + (u * 256 + wave * 64) * 4));
+      bdma_slot<true>(wrs, woff[u], wl0 + u * 4096, wrem - u * 256);
   };
 
   // DMA instructions this wave issues per chunk (the same for every chunk): vmcnt bookkeeping
-  const int cnt = __builtin_amdgcn_readfirstlane((PX4 ? (PE / 4 + 255) >> 8 : (PE + 255) >> 8) + ((WF4 + 255) >> 8));
+  const int cnt = __builtin_amdgcn_readfirstlane(max(0, (prem0 + 255) >> 8) + max(0, (wrem0 + 255) >> 8));
 
   CTRACE(1);
-  __syncthreads();                     // zero fill complete before any DMA data can land
 #pragma unroll
   for (int c = 0; c < NST - 1; ++c)
     if (c < p.nchunk) stage(c, c);
   CTRACE(2);
+  // Two blocks share a CU's matrix pipes.  Started together they stay phase-locked (equal shares
+  // of the pipe -> both finish a chunk together -> both stage together, pipe idle: 2W / (2W + S)
+  // of peak for W = one block's MFMA time per chunk, S = its wait + barrier + staging time).  Holding
+  // every second block (by its workgroup slot on the CU) back by (W + S) / 2 once puts the pair in
+  // anti-phase, which the same dynamics then preserve: one stages while the other computes.
+  if (!KSP && p.stagger > 0) {
+    const unsigned tg = (__builtin_amdgcn_s_getreg(4 | (31 << 11)) >> 16) & 15u;   // HW_ID.TG_ID
+    if (tg & 1u)
+      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);            // 1024 cycles each
+  }
 
   int buf = 0;                         // ring slot of the current chunk
   for (int chunk = 0; chunk < p.nchunk; ++chunk) {
@@ -589,6 +614,11 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   k.PWin = (FC - 1) * k.stride + k.KW;                       // input columns a tile needs
   k.PW = pitch(k.PWin, px4);                                  // LDS row pitch
   k.px_off = px4 ? px_off : 0;
+  {
+    // MFMA cycles per chunk of one block (its 4 waves run on 4 SIMDs) and the stagger (see the kernel)
+    const long long wcyc = (long long)k.T * G * 4 * WM * WN * 64;
+    k.stagger = (ksp || NST != 2 || SCF_DMA_STAGGER_S < 0) ? 0 : (int)((wcyc + SCF_DMA_STAGGER_S) / 2 / 1024);
+  }
   k.tiles_x = (k.Wo + FC - 1) / FC;
   k.mblocks = (frags_m + WM - 1) / WM;
   if (info) { info[0] = WM; info[1] = WN; info[2] = (int)nblk; info[3] = k.T * G * 4 * WM * WN / (ksp ? 4 : 1); }
