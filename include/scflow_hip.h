@@ -123,7 +123,8 @@ typedef struct scf_conv_desc {
   float* out; int64_t out_nstride;
   const float* bias;                    /* [Cout] or NULL                              */
   const float* scale; const float* shift; /* [Cout] each or both NULL (BN eval)        */
-  const float* res; int64_t res_nstride;  /* residual added before act, or NULL        */
+  const float* res; int64_t res_nstride;  /* residual added before act (GRU modes: before
+                                             the gate's sigmoid / tanh), or NULL       */
   float out_div;                        /* accumulator divided by this (1 = off)       */
   int32_t act, act2, act_split;         /* act for co < act_split, act2 otherwise;
                                            act_split <= 0 -> act everywhere            */
@@ -201,6 +202,19 @@ typedef struct scf_gru_pass {
 int scf_sepconv_gru(float* hx, int64_t hx_nstride, int N, int Ch, int Cx, int H, int W,
                     const scf_gru_pass* passes, int npass, float* z, float* rh,
                     scf_stream_t stream);
+
+/* The same update (ConvGRU.forward, raft_decoder.py:235-253) with the iteration-invariant part
+ * of x hoisted out of the refinement loop.  hx = [h (Ch) | c (Cc) | x' (Cx)], where c -- the
+ * context features, scflow_decoder.py:189-190 / raft_decoder.py:430 -- is the same in every
+ * iteration: conv([h | c | x']) = conv([h | x']) + conv_c(c).  The caller computes, once per
+ * pair and per pass i, ctx[i] = conv_c(c) + bias as a plain scf_conv2d over c whose weight is the
+ * c columns of conv_z | conv_r | conv_q stacked into 3 Ch output rows: (N, 3 Ch, H, W) with
+ * sample stride ctx_nstride, channels [0, 2 Ch) for z | r and [2 Ch, 3 Ch) for q.  `passes` then
+ * holds packings over the remaining Ch + Cx input channels, with bias_zr = bias_q = NULL (folded
+ * into ctx).  Results equal scf_sepconv_gru's up to fp32 summation order. */
+int scf_sepconv_gru_ctx(float* hx, int64_t hx_nstride, int N, int Ch, int Cc, int Cx, int H, int W,
+                        const scf_gru_pass* passes, int npass, const float* const* ctx,
+                        int64_t ctx_nstride, float* z, float* rh, scf_stream_t stream);
 /* dry run of scf_conv2d's tile selection: info[4] = {WM, WN, grid blocks, MFMAs per wave per
  * staged chunk}; SCF_EUNSUPPORTED when the packing's KC does not fit this shape.         */
 int scf_conv2d_query(const scf_conv_desc* desc, int32_t* info);

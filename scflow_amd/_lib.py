@@ -91,6 +91,9 @@ SIGNATURES = {
     'scf_pack_conv_weight_a4': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'scf_sepconv_gru': (C.c_int, [_fp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.POINTER(GruPass), C.c_int, _fp, _fp, _fp]),
+    'scf_sepconv_gru_ctx': (C.c_int, [_fp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.POINTER(GruPass), C.c_int, C.POINTER(_fp),
+                                      C.c_int64, _fp, _fp, _fp]),
     'scf_instance_norm': (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int, C.c_float, C.c_int, _fp]),
     'scf_group_norm_relu': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_float, _fp]),

@@ -137,6 +137,7 @@ __device__ __forceinline__ void scf_epi_general_group(const ConvK& p, const Conv
   const bool need_aux = (KIND == SCF_EPI_GENERAL) ? (e.res != nullptr) : true;
   const int hc = p.Cout >> 1;
   float aux0[4] = {0.f, 0.f, 0.f, 0.f}, aux1[4] = {0.f, 0.f, 0.f, 0.f};
+  float aux2[4] = {0.f, 0.f, 0.f, 0.f};    // GRU kinds: pre-activation term (res), e.g. the context part
   if (need_aux) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -147,9 +148,11 @@ __device__ __forceinline__ void scf_epi_general_group(const ConvK& p, const Conv
           aux0[q] = e.res[off];
         } else if (KIND == SCF_EPI_GRU_ZR) {
           if (co >= hc) aux0[q] = e.gru_h[off - hc * e.HWo];
+          if (e.res) aux2[q] = e.res[off];
         } else {
           aux0[q] = e.gru_h[off];
           aux1[q] = e.gru_z[off];
+          if (e.res) aux2[q] = e.res[off];
         }
       }
     }
@@ -168,11 +171,11 @@ __device__ __forceinline__ void scf_epi_general_group(const ConvK& p, const Conv
         const int a = (p.act_split > 0 && co >= p.act_split) ? p.act2 : p.act;
         e.out[off] = scf_apply_act(v, a);
       } else if (KIND == SCF_EPI_GRU_ZR) {
-        const float sg = scf_fast_sigmoid(v);
+        const float sg = scf_fast_sigmoid(v + aux2[q]);
         if (co < hc) e.out[off] = sg;
         else e.gru_aux[off - hc * e.HWo] = sg * aux0[q];
       } else {
-        const float qv = scf_fast_tanh(v);
+        const float qv = scf_fast_tanh(v + aux2[q]);
         e.out[off] = (1.f - aux1[q]) * aux0[q] + aux1[q] * qv;
       }
     }
@@ -188,7 +191,7 @@ __device__ __forceinline__ void scf_epi_general_frag(const ConvK& p, const ConvE
                                                      const scf_f32x16& acc, int cb, int pix,
                                                      bool use_div) {
   const int hc = p.Cout >> 1;
-  float bv[16], a0[16], a1[16];
+  float bv[16], a0[16], a1[16];      // GRU kinds: bv also takes the pre-activation term (res)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int co = cb + 8 * (r >> 2) + (r & 3);
@@ -202,9 +205,11 @@ __device__ __forceinline__ void scf_epi_general_frag(const ConvK& p, const ConvE
       if (e.res) a0[r] = e.res[off];
     } else if (KIND == SCF_EPI_GRU_ZR) {
       if (ok && co >= hc) a0[r] = e.gru_h[off - hc * e.HWo];
+      if (e.res) bv[r] += e.res[off];
     } else {
       a0[r] = e.gru_h[off];
       a1[r] = e.gru_z[off];
+      if (e.res) bv[r] += e.res[off];
     }
   }
 #pragma unroll

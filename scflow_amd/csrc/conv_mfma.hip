@@ -582,35 +582,45 @@ static void gru_choose_packing(scf_conv_desc& d, const float* wp8, const float* 
   }
 }
 
-extern "C" int scf_sepconv_gru(float* hx, int64_t hx_nstride, int N, int Ch, int Cx, int H, int W,
-                               const scf_gru_pass* passes, int npass, float* z, float* rh,
-                               scf_stream_t stream) {
-  if (!hx || !passes || !z || !rh || N <= 0 || Ch <= 0 || Cx <= 0 || H <= 0 || W <= 0 || npass <= 0)
+// hx = [h (Ch) | skipped (Cskip) | x (Cx)]: the convolutions read h (or r*h) and x; ctx[i] (may be
+// NULL) = pass i's pre-activation term (N, 3 Ch, H, W): channels [0, 2Ch) for z | r, [2Ch, 3Ch) for q
+static int sepconv_gru_impl(float* hx, int64_t hx_nstride, int N, int Ch, int Cskip, int Cx, int H, int W,
+                            const scf_gru_pass* passes, int npass, const float* const* ctx,
+                            int64_t ctx_nstride, float* z, float* rh, scf_stream_t stream) {
+  if (!hx || !passes || !z || !rh || N <= 0 || Ch <= 0 || Cx <= 0 || Cskip < 0 || H <= 0 || W <= 0 || npass <= 0)
     return SCF_EINVAL;
   if (Ch % 8 != 0) return SCF_EUNSUPPORTED;      // the h | x boundary must not split a channel chunk
   const int64_t hw = (int64_t)H * W;
+  float* xin = hx + (int64_t)(Ch + Cskip) * hw;
   for (int i = 0; i < npass; ++i) {
     const scf_gru_pass& g = passes[i];
     if (!g.wp_zr || !g.wp_q || g.KH <= 0 || g.KW <= 0) return SCF_EINVAL;
     if (2 * g.pad_h != g.KH - 1 || 2 * g.pad_w != g.KW - 1) return SCF_EUNSUPPORTED;   // 'same' convolutions
+    const float* cx = ctx ? ctx[i] : nullptr;
     scf_conv_desc d = {};
     d.N = N; d.H = H; d.W = W;
     d.KH = g.KH; d.KW = g.KW; d.stride = 1; d.pad_h = g.pad_h; d.pad_w = g.pad_w; d.KC = 8;
     d.out_div = 1.f;
-    // z | r = sigmoid(conv([h | x])): z -> z, r*h -> rh
-    d.in0 = hx; d.C0 = Ch + Cx; d.in0_nstride = hx_nstride;
+    // z | r = sigmoid(conv([h | x]) [+ ctx]): z -> z, r*h -> rh
+    if (Cskip == 0) {
+      d.in0 = hx; d.C0 = Ch + Cx; d.in0_nstride = hx_nstride;
+    } else {
+      d.in0 = hx; d.C0 = Ch; d.in0_nstride = hx_nstride;
+      d.in1 = xin; d.C1 = Cx; d.in1_nstride = hx_nstride;
+    }
     d.Mld = (2 * Ch + 31) / 32 * 32; d.Cout = 2 * Ch; d.bias = g.bias_zr;
     d.wp_a4 = g.wp_zr_a4; d.a4_groups = g.a4_groups; d.a4_mld = d.Mld; d.wp_f16 = g.wp_zr_f16;
     d.wp_a4s = g.wp_zr_a4s; d.a4s_groups = g.a4s_groups;
     d.out = z; d.out_nstride = Ch * hw;
     d.mode = SCF_CONV_GRU_ZR; d.gru_h = hx; d.gru_h_nstride = hx_nstride;
     d.gru_aux = rh; d.gru_aux_nstride = Ch * hw;
+    d.res = cx; d.res_nstride = cx ? ctx_nstride : 0;
     gru_choose_packing(d, g.wp_zr, g.wp_zr_k32);
     int rc = scf_conv2d(&d, stream);
     if (rc != SCF_OK) return rc;
-    // q = tanh(conv([r*h | x])); h <- (1 - z) h + z q
+    // q = tanh(conv([r*h | x]) [+ ctx]); h <- (1 - z) h + z q
     d.in0 = rh; d.C0 = Ch; d.in0_nstride = Ch * hw;
-    d.in1 = hx + (int64_t)Ch * hw; d.C1 = Cx; d.in1_nstride = hx_nstride;
+    d.in1 = xin; d.C1 = Cx; d.in1_nstride = hx_nstride;
     d.Mld = (Ch + 31) / 32 * 32; d.Cout = Ch; d.bias = g.bias_q;
     d.wp_a4 = g.wp_q_a4; d.a4_mld = d.Mld; d.wp_f16 = g.wp_q_f16;
     d.wp_a4s = g.wp_q_a4s;
@@ -618,11 +628,36 @@ extern "C" int scf_sepconv_gru(float* hx, int64_t hx_nstride, int N, int Ch, int
     d.mode = SCF_CONV_GRU_Q; d.gru_h = hx; d.gru_h_nstride = hx_nstride;
     d.gru_aux = nullptr; d.gru_aux_nstride = 0;
     d.gru_z = z; d.gru_z_nstride = Ch * hw;
+    d.res = cx ? cx + (int64_t)2 * Ch * hw : nullptr;
     gru_choose_packing(d, g.wp_q, g.wp_q_k32);
     rc = scf_conv2d(&d, stream);
     if (rc != SCF_OK) return rc;
   }
   return SCF_OK;
+}
+
+extern "C" int scf_sepconv_gru(float* hx, int64_t hx_nstride, int N, int Ch, int Cx, int H, int W,
+                               const scf_gru_pass* passes, int npass, float* z, float* rh,
+                               scf_stream_t stream) {
+  return sepconv_gru_impl(hx, hx_nstride, N, Ch, 0, Cx, H, W, passes, npass, nullptr, 0, z, rh, stream);
+}
+
+// The same update with the iteration-invariant part of x hoisted out of the refinement loop:
+// hx = [h | c | x'] where c (Cc channels, e.g. RAFT's context features) does not change between
+// iterations.  conv([h | c | x']) = conv_hx'([h | x']) + conv_c(c): the caller computes
+// ctx[i] = conv_c(c) + bias once per pair (a plain scf_conv2d over c with the z | r | q weight
+// columns of c stacked into 3 Ch output rows) and passes packings over the Ch + Cx remaining input
+// channels (bias_zr / bias_q = NULL: folded into ctx).  Saves Cc / (Ch + Cc + Cx) of the GRU's
+// multiply-adds in every iteration but the first.
+extern "C" int scf_sepconv_gru_ctx(float* hx, int64_t hx_nstride, int N, int Ch, int Cc, int Cx, int H,
+                                   int W, const scf_gru_pass* passes, int npass,
+                                   const float* const* ctx, int64_t ctx_nstride, float* z, float* rh,
+                                   scf_stream_t stream) {
+  if (!ctx || Cc <= 0) return SCF_EINVAL;
+  for (int i = 0; i < npass; ++i)
+    if (!ctx[i]) return SCF_EINVAL;
+  return sepconv_gru_impl(hx, hx_nstride, N, Ch, Cc, Cx, H, W, passes, npass, ctx, ctx_nstride, z, rh,
+                          stream);
 }
 
 // Dry run of the tile selection for a descriptor: info[0..3] = WM, WN, grid blocks, MFMA

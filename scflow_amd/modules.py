@@ -344,14 +344,47 @@ class ConvGRU(HipModule):
                           PackedConv.from_weight(q.conv.weight, q.conv.bias, 1, q.conv.padding)))
         return packs
 
-    def forward_inplace(self, hx: Tensor) -> Tensor:
+    # ---- iteration-invariant context (DESIGN.md "GRU context hoisting") ----
+    # x = [c | x'] where c (the context features) is the same in every refinement iteration:
+    # conv([h | c | x']) = conv([h | x']) + conv_c(c).  ``context_terms`` evaluates conv_c(c) + bias
+    # for z | r | q once per pair; ``forward_inplace`` with those terms convolves [h | x'] only.
+    def _ctx_packs(self, cc: int):
+        """per pass: (PackedConv c -> 3 h_channels rows [z | r | q] with the biases,
+        PackedConv [h | x'] -> z | r without bias, PackedConv [h | x'] -> q without bias)"""
+        hc = self.h_channels
+        key = ('ctx', cc, self._pack_key())
+        if self.__dict__.get('_ctx_cache', (None,))[0] != key:
+            packs = []
+            for z, r, q in zip(self.conv_z, self.conv_r, self.conv_q):
+                wz, wr, wq = z.conv.weight.detach(), r.conv.weight.detach(), q.conv.weight.detach()
+                sel = lambda w: torch.cat([w[:, :hc], w[:, hc + cc:]], 1)
+                w_c = torch.cat([wz[:, hc:hc + cc], wr[:, hc:hc + cc], wq[:, hc:hc + cc]], 0)
+                b_c = torch.cat([z.conv.bias, r.conv.bias, q.conv.bias], 0).detach()
+                packs.append((PackedConv.from_weight(w_c, b_c, 1, z.conv.padding),
+                              PackedConv.from_weight(torch.cat([sel(wz), sel(wr)], 0), None, 1, z.conv.padding),
+                              PackedConv.from_weight(sel(wq), None, 1, q.conv.padding)))
+            self.__dict__['_ctx_cache'] = (key, packs)
+        return self.__dict__['_ctx_cache'][1]
+
+    def context_terms(self, c: Tensor) -> List[Tensor]:
+        """one (N, 3 h_channels, H, W) tensor per pass: the c part of conv_z | conv_r | conv_q + bias"""
+        return [ops.conv2d(pk[0], c) for pk in self._ctx_packs(c.shape[1])]
+
+    def forward_inplace(self, hx: Tensor, ctx: Optional[Sequence[Tensor]] = None,
+                        ctx_channels: int = 0) -> Tensor:
         """hx: (N, h_ch + x_ch, h, w) = [h | x]; h is updated in place.  One C-ABI call
-        (``scf_sepconv_gru``: the launch sequence lives in the library)."""
+        (``scf_sepconv_gru``: the launch sequence lives in the library).  ``ctx`` =
+        ``context_terms(hx[:, h_ch:h_ch + ctx_channels])`` of this pair: those channels are then
+        not convolved again (``scf_sepconv_gru_ctx``)."""
         hc = self.h_channels
         n, _, h, w = hx.shape
         z = torch.empty((n, hc, h, w), dtype=torch.float32, device=hx.device)
         rh = torch.empty((n, hc, h, w), dtype=torch.float32, device=hx.device)
-        ops.sepconv_gru(self.packed, hx, hc, z, rh)
+        if ctx is None:
+            ops.sepconv_gru(self.packed, hx, hc, z, rh)
+        else:
+            packs = [(pk[1], pk[2]) for pk in self._ctx_packs(ctx_channels)]
+            ops.sepconv_gru(packs, hx, hc, z, rh, ctx=ctx, ctx_channels=ctx_channels)
         return hx[:, :hc]
 
     def forward(self, h: Tensor, x: Tensor) -> Tensor:
@@ -484,6 +517,7 @@ class SCFlowDecoder(HipModule):
         self.mask_encoder = nn.Sequential(ConvBlock(1, 64, 3, padding=1, act_cfg=act_cfg),
                                           ConvBlock(64, 32, 3, padding=1, act_cfg=act_cfg))
         self.tiled_level0 = True      # decoder-internal pyramid layout (see _use_tiled_level0)
+        self.hoist_context = True     # GRU: convolve the (iteration-invariant) context channels once per pair
 
     def _pack_sources(self):
         a, b = self.flow_pred.layers[0].conv, self.mask_pred.layers[0].conv
@@ -520,6 +554,8 @@ class SCFlowDecoder(HipModule):
         outs = ([], [], [], [], [], [], [])
         dm = torch.empty((n, 96, h, w), **f32)
         heads = torch.empty((n, 512, h, w), **f32)
+        # the context channels of hx never change: their part of the GRU convolutions, once
+        ctx = self.gru.context_terms(hx[:, hc:hc + cc]) if self.hoist_context else None
         # small batches: independent branches side by side
         ov_flow, ov_mask, ov_up = (ops.small_work(n, H, W, b) for b in ('flow', 'mask', 'upsample'))
         for _ in range(self.iters):
@@ -529,7 +565,7 @@ class SCFlowDecoder(HipModule):
                 ops.fork_point()             # the motion encoder's flow branch starts here
             corr = self.corr_lookup(pyramid, flow_lr, level0_tiled=tiled)          # :198
             self.encoder(corr, flow_lr, out=hx[:, hc + cc:], overlap=ov_flow, cf=cf)   # :206
-            hv = self.gru.forward_inplace(hx)                                      # :207-208
+            hv = self.gru.forward_inplace(hx, ctx, cc)                             # :207-208
             ops.conv2d(self.packed, hv, out=heads, act=ACT_RELU)
             d_flow = self.flow_pred.predict(heads[:, :256])                        # :210
             mask = self.mask_pred.predict(heads[:, 256:], act=ACT_SIGMOID)         # :212-213
@@ -590,15 +626,20 @@ class _RAFTDecoderBase(HipModule):
         self.mask_pred = XHead(self.h_channels, [256], self.mask_channels, x='mask')
         self.convex_upsample_flow = convex_unsample_flow
         self.tiled_level0 = True      # decoder-internal pyramid layout (see _use_tiled_level0)
+        self.hoist_context = True     # GRU: convolve the (iteration-invariant) context channels once per pair
         if self.mask_channels != 9 * (2 ** (num_levels - 1)) ** 2:
             raise NotImplementedError('convex up-sampling kernel: 9 x 8 x 8 mask (radius 4, 4 levels)')
 
-    def _step(self, pyramid, flow, hx, tiled=False):
+    def _context(self, hx):
+        hc, cc = self.h_channels, self.cxt_channels
+        return self.gru.context_terms(hx[:, hc:hc + cc]) if self.hoist_context else None
+
+    def _step(self, pyramid, flow, hx, tiled=False, ctx=None):
         """one update: lookup, motion encoder, GRU (in place in hx), flow += delta."""
         hc, cc = self.h_channels, self.cxt_channels
         corr = self.corr_lookup(pyramid, flow, level0_tiled=tiled)
         self.encoder(corr, flow, out=hx[:, hc + cc:])
-        hv = self.gru.forward_inplace(hx)
+        hv = self.gru.forward_inplace(hx, ctx, cc)
         d_flow = self.flow_pred(hv)
         n, _, h, w = flow.shape
         return hv, ops.resize_bilinear(flow, (h, w), b=d_flow)       # flow + delta (same size)
@@ -624,8 +665,9 @@ class RAFTDecoder(_RAFTDecoderBase):
         scale = float(2 ** (self.num_levels - 1))
         flow = flow.contiguous()
         outs = []
+        ctx = self._context(hx)
         for _ in range(self.iters):
-            hv, flow = self._step(pyramid, flow, hx, tiled)
+            hv, flow = self._step(pyramid, flow, hx, tiled, ctx)
             mask = self.mask_pred(hv) if self.convex_upsample_flow else None   # 0.25 folded in
             outs.append(self._upsample(flow, mask, scale))
         return outs
@@ -648,8 +690,9 @@ class RAFTDecoderMask(_RAFTDecoderBase):
         scale = float(2 ** (self.num_levels - 1))
         flow = flow.contiguous()
         flows, occs = [], []
+        ctx = self._context(hx)
         for _ in range(self.iters):
-            hv, flow = self._step(pyramid, flow, hx, tiled)
+            hv, flow = self._step(pyramid, flow, hx, tiled, ctx)
             occ = self.occlusion_pred.predict(self.occlusion_pred.layers[0](hv), act=ACT_SIGMOID)
             mask = self.mask_pred(hv) if self.convex_upsample_flow else None
             flows.append(self._upsample(flow, mask, scale))

@@ -401,24 +401,13 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
 _CONV_EVENTS = None
 
 
-def sepconv_gru(packs, hx: Tensor, h_channels: int, z: Tensor, rh: Tensor) -> None:
-    """ConvGRU.forward (raft_decoder.py:235-253) on hx = [h | x], h updated in place:
-    ``scf_sepconv_gru``.  ``packs``: [(PackedConv of cat(conv_z, conv_r), PackedConv of conv_q)]
-    per pass.  With convolution timers armed (bench.py) the same launches are issued one by one
-    through ``conv2d`` so that each carries its own timer."""
-    if _CONV_EVENTS is not None:
-        hv, xv = hx[:, :h_channels], hx[:, h_channels:]
-        for pzr, pq in packs:
-            conv2d(pzr, hx, out=z, mode=CONV_GRU_ZR, gru_h=hv, gru_aux=rh)
-            conv2d(pq, rh, xv, out=hv, mode=CONV_GRU_Q, gru_h=hv, gru_z=z)
-        return
-    p, n, c, h, w, sn = _nchw(hx, 'hx')
+def _gru_passes(packs):
     arr = (_lib.GruPass * len(packs))()
     f16 = _CONV_PRECISION == 'f16x3'
     for g, (pzr, pq) in zip(arr, packs):
         g.KH, g.KW, g.pad_h, g.pad_w = pzr.kh, pzr.kw, pzr.pad_h, pzr.pad_w
-        g.wp_zr, g.bias_zr = pzr.wp.data_ptr(), pzr.bias.data_ptr()
-        g.wp_q, g.bias_q = pq.wp.data_ptr(), pq.bias.data_ptr()
+        g.wp_zr, g.bias_zr = pzr.wp.data_ptr(), (None if pzr.bias is None else pzr.bias.data_ptr())
+        g.wp_q, g.bias_q = pq.wp.data_ptr(), (None if pq.bias is None else pq.bias.data_ptr())
         if pzr.wp4 is not None and pq.wp4 is not None and pzr.g4 == pq.g4:
             g.wp_zr_a4, g.wp_q_a4, g.a4_groups = pzr.wp4.data_ptr(), pq.wp4.data_ptr(), pzr.g4
         if f16 and pzr.wp16 is not None and pq.wp16 is not None:
@@ -427,9 +416,47 @@ def sepconv_gru(packs, hx: Tensor, h_channels: int, z: Tensor, rh: Tensor) -> No
             g.wp_zr_k32, g.wp_q_k32 = pzr.wp_alt.data_ptr(), pq.wp_alt.data_ptr()
         if pzr.wp4s is not None and pq.wp4s is not None and pzr.g4s == pq.g4s:
             g.wp_zr_a4s, g.wp_q_a4s, g.a4s_groups = pzr.wp4s.data_ptr(), pq.wp4s.data_ptr(), pzr.g4s
-    _lib.check(_lib.load().scf_sepconv_gru(p, sn, n, h_channels, c - h_channels, h, w, arr, len(packs),
-                                           _dense(z, 'z'), _dense(rh, 'rh'), _stream()),
-               'scf_sepconv_gru')
+    return arr
+
+
+def sepconv_gru(packs, hx: Tensor, h_channels: int, z: Tensor, rh: Tensor,
+                ctx: Optional[Sequence[Tensor]] = None, ctx_channels: int = 0) -> None:
+    """ConvGRU.forward (raft_decoder.py:235-253) on hx = [h | x], h updated in place:
+    ``scf_sepconv_gru``.  ``packs``: [(PackedConv of cat(conv_z, conv_r), PackedConv of conv_q)]
+    per pass.  With ``ctx`` (one (N, 3 h_channels, H, W) tensor per pass) hx = [h | c | x'] and
+    the packs cover [h | x'] only: ``scf_sepconv_gru_ctx`` (the c part of the convolutions, computed
+    once per pair, enters before the gates' activations).  With convolution timers armed (bench.py)
+    the same launches are issued one by one through ``conv2d`` so that each carries its own timer."""
+    hc = h_channels
+    if ctx is not None and (ctx_channels <= 0 or len(ctx) != len(packs)):
+        raise _lib.ScflowHipError('sepconv_gru: one context term per pass, ctx_channels > 0')
+    if _CONV_EVENTS is not None:
+        hv, xv = hx[:, :hc], hx[:, hc + ctx_channels:]
+        for i, (pzr, pq) in enumerate(packs):
+            if ctx is None:
+                conv2d(pzr, hx, out=z, mode=CONV_GRU_ZR, gru_h=hv, gru_aux=rh)
+                conv2d(pq, rh, xv, out=hv, mode=CONV_GRU_Q, gru_h=hv, gru_z=z)
+            else:
+                conv2d(pzr, hv, xv, out=z, mode=CONV_GRU_ZR, gru_h=hv, gru_aux=rh, res=ctx[i][:, :2 * hc])
+                conv2d(pq, rh, xv, out=hv, mode=CONV_GRU_Q, gru_h=hv, gru_z=z, res=ctx[i][:, 2 * hc:])
+        return
+    p, n, c, h, w, sn = _nchw(hx, 'hx')
+    arr = _gru_passes(packs)
+    if ctx is None:
+        _lib.check(_lib.load().scf_sepconv_gru(p, sn, n, hc, c - hc, h, w, arr, len(packs),
+                                               _dense(z, 'z'), _dense(rh, 'rh'), _stream()),
+                   'scf_sepconv_gru')
+        return
+    ptrs, cs = (C.c_void_p * len(ctx))(), None
+    for i, t in enumerate(ctx):
+        pc_, nc, cc_, hh, ww, s_ = _nchw(t, 'ctx')
+        if (nc, cc_, hh, ww) != (n, 3 * hc, h, w) or (cs is not None and s_ != cs):
+            raise _lib.ScflowHipError('sepconv_gru: ctx must be (N, 3*h_channels, H, W), equal strides')
+        ptrs[i], cs = pc_, s_
+    _lib.check(_lib.load().scf_sepconv_gru_ctx(p, sn, n, hc, ctx_channels, c - hc - ctx_channels, h, w,
+                                               arr, len(packs), ptrs, cs, _dense(z, 'z'),
+                                               _dense(rh, 'rh'), _stream()),
+               'scf_sepconv_gru_ctx')
 
 
 def _read_timers(timers):

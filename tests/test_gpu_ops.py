@@ -285,6 +285,46 @@ def test_conv2d_gru_fusions():
     close(hxd[:, 128:], x, atol=0, what='x untouched')
 
 
+@pytest.mark.parametrize('n,h,w,kind', [(2, 8, 8, 'SeqConv'), (32, 32, 32, 'SeqConv'), (1, 32, 32, 'SeqConv'),
+                                         (1, 60, 80, 'SeqConv'), (2, 12, 20, 'Conv')])
+def test_convgru_context_hoisting(n, h, w, kind):
+    """ConvGRU with the context channels' part of the convolutions evaluated once
+    (scf_sepconv_gru_ctx) == the plain cell (scf_sepconv_gru) and == torch
+    (raft_decoder.py:235-253) within fp32 round-off, over several iterations with the same
+    context and changing motion features."""
+    from scflow_amd.modules import ConvGRU
+    torch.manual_seed(11)
+    hc, cc, xc = 128, 128, 128
+    gru = ConvGRU(hc, cc + xc, kind)
+    for prm in gru.parameters():
+        prm.data.mul_(1.5)
+    gru_d = ConvGRU(hc, cc + xc, kind).to(DEV)
+    gru_d.load_state_dict(gru.state_dict())
+    hx = rnd((n, hc + cc + xc, h, w), 90)
+    hx[:, :hc] = torch.tanh(hx[:, :hc])
+    a, b = hx.to(DEV), hx.to(DEV)
+    ctx = gru_d.context_terms(b[:, hc:hc + cc])
+    assert len(ctx) == len(gru.conv_z) and ctx[0].shape == (n, 3 * hc, h, w)
+    href = hx[:, :hc].clone()
+    for it in range(3):
+        mot = rnd((n, xc, h, w), 91 + it)
+        a[:, hc + cc:] = mot.to(DEV)
+        b[:, hc + cc:] = mot.to(DEV)
+        gru_d.forward_inplace(a)
+        gru_d.forward_inplace(b, ctx, cc)
+        x = torch.cat([hx[:, hc:hc + cc], mot], 1)
+        for cz, cr, cq in zip(gru.conv_z, gru.conv_r, gru.conv_q):
+            hxr = torch.cat([href, x], 1)
+            z = torch.sigmoid(F.conv2d(hxr, cz.conv.weight, cz.conv.bias, padding=cz.conv.padding))
+            r = torch.sigmoid(F.conv2d(hxr, cr.conv.weight, cr.conv.bias, padding=cr.conv.padding))
+            q = torch.tanh(F.conv2d(torch.cat([r * href, x], 1), cq.conv.weight, cq.conv.bias,
+                                    padding=cq.conv.padding))
+            href = ((1 - z) * href + z * q).detach()
+        close(b[:, :hc], href, atol=5e-5, what=f'hoisted vs torch, iteration {it}')
+        close(b[:, :hc], a[:, :hc].cpu(), atol=2e-5, what=f'hoisted vs plain cell, iteration {it}')
+        close(b[:, hc:], a[:, hc:].cpu(), atol=0, what='x untouched')
+
+
 # ----------------------------------------------------------- small kernels
 @pytest.mark.parametrize('hw', [(128, 128), (64, 64), (32, 32), (12, 20), (5, 7)])
 def test_instance_norm(hw):
