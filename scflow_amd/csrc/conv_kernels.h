@@ -15,7 +15,6 @@ struct ConvK {
   int Mld, Cout, Krows;
   int KH, KW, T, stride, pad_h, pad_w, KC, nchunk;
   int fc_log2, tiles_x, tiles_y, mblocks, PH, PW, PWin;
-  int stagger;               // conv_dma: units of 1024 cycles every second co-resident block waits before chunk 0
   int px_off;                // PX4 patch staging: columns between the 16-byte-aligned row start and ix0
   int wvec;
   int out_tile;              // 1: 8x4-float tiled output planes (correlation level 0)
