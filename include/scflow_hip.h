@@ -236,6 +236,13 @@ int scf_group_norm_relu(const float* x, const float* gamma, const float* beta, f
 int scf_linear(const float* x, const float* W, const float* b, float* y, int N, int K,
                int O, int act, scf_stream_t stream);
 
+/* Two linear layers over the same input in one launch: y1 = act(W1 x + b1), y2 = act(W2 x + b2)
+ * (rotation_pred and translation_pred, pose_head.py:203-206).  Same arithmetic as two scf_linear
+ * calls.                                                                            */
+int scf_linear_pair(const float* x, const float* W1, const float* b1, float* y1, int O1,
+                    const float* W2, const float* b2, float* y2, int O2, int N, int K, int act,
+                    scf_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * Pose head tail + pose update.  replaces pose_head.py:207-210 (class select) and
  * get_pose_from_delta_pose, models/utils/pose.py:124-149 (+ :153-169 ortho6d).

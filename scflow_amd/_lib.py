@@ -98,6 +98,8 @@ SIGNATURES = {
     'scf_group_norm_relu': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_float, _fp]),
     'scf_linear': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'scf_linear_pair': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, _fp]),
     'scf_pose_update': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp,
                                   C.c_int, _fp]),
     'scf_reproject_flow': (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int,

@@ -3,19 +3,23 @@
 // 32-channel fragment (16x-32x wasted matrix work); here it is what it is -- a bandwidth-bound
 // reduction over Cin*KH*KW with a handful of FMAs per loaded value -- and runs on the vector
 // ALUs straight from NCHW:
-//   block = 32 output columns x PY output rows x 8 channel groups (256 threads);
+//   block = 32 output columns x PY output rows x NCG = 16 channel groups (512 threads);
 //   lane <-> column (128-byte coalesced rows), thread = PY vertically adjacent pixels of one
-//   channel group (c = cg, cg+8, ...): (K+PY-1)*K loads feed PY*K*K*Cout FMAs per channel,
-//   four channels' loads in flight per thread (the kernel is latency-bound otherwise);
+//   channel group (c = cg, cg+NCG, ...): (K+PY-1)*K loads feed PY*K*K*Cout FMAs per channel,
+//   eight channels' loads in flight per thread: a block's run time is a chain of dependent
+//   memory round trips (22 us per launch with 8 groups x 4 in flight, whatever the batch), so
+//   the channel loop is made as short as the register file allows;
 //   weights are staged once per block in LDS and read as wave-uniform broadcasts;
-//   the 8 partial sums per pixel are combined through LDS in a fixed order.
+//   the NCG partial sums per pixel are combined through LDS in a fixed order.
 #include "scf_common.h"
 #include "conv_kernels.h"
 
+#define SCF_THIN_NCG 16
 template <int K, int CO>
-__global__ __launch_bounds__(256) void conv_thin_kernel(ConvK p) {
+__global__ __launch_bounds__(32 * SCF_THIN_NCG) void conv_thin_kernel(ConvK p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int PY = 2;                        // output rows per thread
+  constexpr int NCG = SCF_THIN_NCG, NT = 32 * NCG;
   constexpr int T = K * K, R = K / 2, NR = PY + K - 1;
   const int tid = threadIdx.x, col = tid & 31, cg = tid >> 5;
   const int b = blockIdx.x;
@@ -29,7 +33,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvK p) {
   // weights -> LDS: straight copy of the [c][t][co] packing
   float* wl = lds;
   const int nw4 = (p.Cin * T * CO + 3) / 4;
-  for (int e = tid; e < nw4; e += 256)
+  for (int e = tid; e < nw4; e += NT)
     reinterpret_cast<float4*>(wl)[e] = reinterpret_cast<const float4*>(p.wthin)[e];
   __syncthreads();
 
@@ -52,8 +56,8 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvK p) {
     for (int co = 0; co < CO; ++co) acc[py][co] = 0.f;
 
   const float* xin = p.in0 + (long long)n * p.in0_ns;
-#pragma unroll 4
-  for (int c = cg; c < p.Cin; c += 8) {
+#pragma unroll 8
+  for (int c = cg; c < p.Cin; c += NCG) {
     const float* xc = xin + (long long)c * HW;
     float v[NR][K];
 #pragma unroll
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvK p) {
         }
   }
 
-  // ---- combine the 8 channel groups (fixed order), bias, activation, store ----
+  // ---- combine the channel groups (fixed order), bias, activation, store ----
   __syncthreads();                                   // weights no longer needed
   float* red = lds;                                  // [cg][py][co][col]
 #pragma unroll
@@ -84,12 +88,12 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvK p) {
 #pragma unroll
     for (int co = 0; co < CO; ++co) red[((cg * PY + py) * CO + co) * 32 + col] = acc[py][co];
   __syncthreads();
-  for (int e = tid; e < PY * CO * 32; e += 256) {
+  for (int e = tid; e < PY * CO * 32; e += NT) {
     const int c2 = e & 31, q = e >> 5;               // q = py*CO + co
     const int py = q / CO, co = q - py * CO;
     float s = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) s += red[(g * PY * CO + q) * 32 + c2];
+    for (int g = 0; g < NCG; ++g) s += red[(g * PY * CO + q) * 32 + c2];
     const int oy = y0 + py, ox = txi * 32 + c2;
     if (co < p.Cout && oy < p.Ho && ox < p.Wo) {
       if (p.bias) s += p.bias[co];
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvK p) {
 
 template <int K, int CO>
 static int launch_thin(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
-  scf_launch((conv_thin_kernel<K, CO>), dim3(nblk), dim3(256), lds_bytes, st, k);
+  scf_launch((conv_thin_kernel<K, CO>), dim3(nblk), dim3(32 * SCF_THIN_NCG), lds_bytes, st, k);
   return scf_launch_status();
 }
 
@@ -115,7 +119,7 @@ int scf_conv_thin_dispatch(ConvK k, int N, bool dry_run, hipStream_t st) {
   if (k.Cin < 32) return SCF_EUNSUPPORTED;
   const int CO = k.Cout <= 1 ? 1 : k.Cout <= 2 ? 2 : 4;
   const size_t wbytes = ((size_t)k.Cin * k.T * CO + 3) / 4 * 16;
-  const size_t rbytes = (size_t)8 * 2 * CO * 32 * sizeof(float);
+  const size_t rbytes = (size_t)SCF_THIN_NCG * 2 * CO * 32 * sizeof(float);
   const size_t lds = wbytes > rbytes ? wbytes : rbytes;
   if (lds > 64 * 1024) return SCF_EUNSUPPORTED;
   k.tiles_x = (k.Wo + 31) / 32;

@@ -161,31 +161,47 @@ extern "C" int scf_group_norm_relu(const float* x, const float* gamma, const flo
 
 // ---------------------------------------------------------------------------------
 // nn.Linear (+ReLU): pose_head.py:166-172, 203-206.  Weight-streaming GEMV batch: one wave
-// per output feature streams its weight row once (float4) and dots it with up to NB sample
-// rows (activations are L2 resident), wave-level shuffle reduction.
+// per output feature streams its weight row once (float4, four 1 KiB pieces in flight) and dots
+// it with up to NB sample rows (activations are L2 resident), wave-level shuffle reduction.
+// Two layers that read the same input (rotation_pred / translation_pred) share one launch: the
+// feature index runs over O + O2.
 // ---------------------------------------------------------------------------------
 template <int NB>
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x,
                                                      const float* __restrict__ W,
                                                      const float* __restrict__ b,
                                                      float* __restrict__ y, int N, int K, int O,
-                                                     int act) {
+                                                     int act, const float* __restrict__ W2,
+                                                     const float* __restrict__ b2,
+                                                     float* __restrict__ y2, int O2) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int o = blockIdx.x * 4 + wave;
+  int o = blockIdx.x * 4 + wave;
   const int n0 = blockIdx.y * NB;
-  if (o >= O) return;
+  if (o >= O + O2) return;
+  if (o >= O) { o -= O; W = W2; b = b2; y = y2; O = O2; }
   float acc[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) acc[i] = 0.f;
   const float* wrow = W + (long long)o * K;
   if ((K & 3) == 0) {
-    for (int k = lane * 4; k < K; k += 256) {
-      const float4 w = *reinterpret_cast<const float4*>(wrow + k);
+    for (int k0 = lane * 4; k0 < K; k0 += 1024) {
+      float4 w[4];
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        if (n0 + i < N) {
-          const float4 xv = *reinterpret_cast<const float4*>(x + (long long)(n0 + i) * K + k);
-          acc[i] += (w.x * xv.x + w.y * xv.y) + (w.z * xv.z + w.w * xv.w);
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + j * 256;
+        w[j] = k < K ? *reinterpret_cast<const float4*>(wrow + k) : float4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + j * 256;
+        if (k < K) {
+#pragma unroll
+          for (int i = 0; i < NB; ++i) {
+            if (n0 + i < N) {
+              const float4 xv = *reinterpret_cast<const float4*>(x + (long long)(n0 + i) * K + k);
+              acc[i] += (w[j].x * xv.x + w[j].y * xv.y) + (w[j].z * xv.z + w[j].w * xv.w);
+            }
+          }
         }
       }
     }
@@ -207,14 +223,27 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
   }
 }
 
+static int linear_launch(const float* x, const float* W, const float* b, float* y, int N, int K, int O,
+                         int act, const float* W2, const float* b2, float* y2, int O2,
+                         scf_stream_t stream) {
+  if ((((uintptr_t)x | (uintptr_t)W | (uintptr_t)W2) & 15) != 0 && (K & 3) == 0) return SCF_EUNSUPPORTED;
+  constexpr int NB = 8;
+  const dim3 grid((O + O2 + 3) / 4, (N + NB - 1) / NB);
+  if (grid.y > 65535) return SCF_EUNSUPPORTED;
+  scf_launch(linear_kernel<NB>, grid, dim3(256), 0, scf_stream(stream), x, W, b, y, N, K, O, act, W2,
+             b2, y2, O2);
+  return scf_launch_status();
+}
+
 extern "C" int scf_linear(const float* x, const float* W, const float* b, float* y, int N, int K,
                           int O, int act, scf_stream_t stream) {
   if (!x || !W || !y || N <= 0 || K <= 0 || O <= 0) return SCF_EINVAL;
-  if ((((uintptr_t)x | (uintptr_t)W) & 15) != 0 && (K & 3) == 0) return SCF_EUNSUPPORTED;
-  constexpr int NB = 8;
-  const dim3 grid((O + 3) / 4, (N + NB - 1) / NB);
-  if (grid.y > 65535) return SCF_EUNSUPPORTED;
-  scf_launch(linear_kernel<NB>, grid, dim3(256), 0, scf_stream(stream), x, W, b, y, N, K, O,
-                     act);
-  return scf_launch_status();
+  return linear_launch(x, W, b, y, N, K, O, act, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int scf_linear_pair(const float* x, const float* W1, const float* b1, float* y1, int O1,
+                               const float* W2, const float* b2, float* y2, int O2, int N, int K,
+                               int act, scf_stream_t stream) {
+  if (!x || !W1 || !y1 || !W2 || !y2 || N <= 0 || K <= 0 || O1 <= 0 || O2 <= 0) return SCF_EINVAL;
+  return linear_launch(x, W1, b1, y1, N, K, O1, act, W2, b2, y2, O2, stream);
 }

@@ -463,8 +463,8 @@ class MultiClassPoseHead(HipModule):
         x = x.view(x.shape[0], -1)
         for fc in self.fc_layers:
             x = ops.linear(x, fc[0].weight, fc[0].bias, ACT_RELU)
-        rot_all = ops.linear(x, self.rotation_pred.weight, self.rotation_pred.bias)
-        trans_all = ops.linear(x, self.translation_pred.weight, self.translation_pred.bias)
+        rot_all, trans_all = ops.linear_pair(x, self.rotation_pred.weight, self.rotation_pred.bias,
+                                             self.translation_pred.weight, self.translation_pred.bias)
         return rot_all, trans_all
 
     def forward(self, x: Tensor, label: Tensor) -> Tuple[Tensor, Tensor]:

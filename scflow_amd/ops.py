@@ -28,7 +28,7 @@ Tensor = torch.Tensor
 __all__ = ['PackedConv', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision',
            'get_conv_precision', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
            'instance_norm', 'group_norm_relu', 'linear', 'pose_update', 'reproject_flow',
-           'unproject_depth', 'resize_bilinear', 'convex_upsample', 'avgpool2x2', 'copy_channels',
+           'unproject_depth', 'linear_pair', 'resize_bilinear', 'convex_upsample', 'avgpool2x2', 'copy_channels',
            'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_TANH', 'CONV_PLAIN', 'CONV_GRU_ZR',
            'CONV_GRU_Q']
 
@@ -675,6 +675,22 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int = ACT_NON
     _lib.check(_lib.load().scf_linear(px, _dense(weight, 'weight'), _opt(bias, 'bias'),
                                       _dense(out, 'out'), n, k, o, act, _stream()), 'scf_linear')
     return out
+
+
+def linear_pair(x: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor],
+                act: int = ACT_NONE) -> Tuple[Tensor, Tensor]:
+    """(linear(x, w1, b1), linear(x, w2, b2)) in one launch (scf_linear_pair)."""
+    px = _dense(x, 'x')
+    n, k = x.shape
+    if w1.shape[1] != k or w2.shape[1] != k:
+        raise _lib.ScflowHipError('linear_pair: weight/in_features mismatch')
+    y1 = torch.empty((n, w1.shape[0]), dtype=torch.float32, device=x.device)
+    y2 = torch.empty((n, w2.shape[0]), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().scf_linear_pair(px, _dense(w1, 'w1'), _opt(b1, 'b1'), y1.data_ptr(),
+                                           w1.shape[0], _dense(w2, 'w2'), _opt(b2, 'b2'),
+                                           y2.data_ptr(), w2.shape[0], n, k, act, _stream()),
+               'scf_linear_pair')
+    return y1, y2
 
 
 def pose_update(rot_all: Tensor, trans_all: Tensor, label: Tensor, num_class: int,

@@ -351,6 +351,19 @@ def test_linear(n, k, o):
           atol=2e-5, what='linear')
 
 
+@pytest.mark.parametrize('n,k', [(1, 256), (3, 256), (32, 250), (2, 2048)])
+def test_linear_pair(n, k):
+    """scf_linear_pair (rotation_pred + translation_pred, pose_head.py:203-206) == two scf_linear
+    calls bit for bit, == torch within round-off."""
+    x = rnd((n, k), 58)
+    w1, b1, w2, b2 = rnd((126, k), 59, k ** -0.5), rnd((126,), 60, 0.1), rnd((63, k), 61, k ** -0.5), None
+    y1, y2 = ops.linear_pair(x.to(DEV), w1.to(DEV), b1.to(DEV), w2.to(DEV), b2)
+    close(y1, F.linear(x, w1, b1), atol=2e-5, what='pair first')
+    close(y2, F.linear(x, w2), atol=2e-5, what='pair second')
+    assert torch.equal(y1, ops.linear(x.to(DEV), w1.to(DEV), b1.to(DEV)))
+    assert torch.equal(y2, ops.linear(x.to(DEV), w2.to(DEV), None))
+
+
 def test_pose_update_and_label_quirk(golden_dir):
     g = np.load(os.path.join(golden_dir, 'pose_math.npz'))
     n, nc = 3, 21
