@@ -166,12 +166,13 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 // KSP   : K-split tile for small grids: 32 channels x ONE 32-pixel fragment per block (4x the
 //         blocks of the smallest pixel-split tile); the four waves take every fourth (tap, group)
 //         step of each chunk and combine their partial sums through LDS in a fixed order.
-// PX4   : (stride 1, W % 4 == 0) the patch is staged as PLAIN channel planes [KC][PH][PWa] with
+// PX4   : (W % 4 == 0) the patch is staged as PLAIN full-resolution channel planes [KC][PH][PWa] with
 //         dwordx4 DMA: a patch row starts at the 16-byte-aligned column ixa = ix0 - px_off, so every
 //         lane moves one aligned group of 4 columns that lies wholly inside or wholly outside the
 //         image (4x fewer patch DMA instructions, contiguous instead of 4-plane interleaved gathers:
 //         ~125 vs 4 x 117 cycles of texture-path time per KiB).  B operands are then read with four
-//         ds_read_b32 per (tap, group) step instead of one ds_read_b128.
+//         ds_read_b32 per (tap, group) step instead of one ds_read_b128 (stride 2: every second
+//         column, a 2-way bank conflict the MFMA-bound loop does not notice).
 // NP    : producer waves (0: the four MFMA waves stage their own quarter of every chunk).  A wave
 //         that issues LDS-DMA stalls in the issue stage whenever the CU's memory pipeline is full
 //         (~1 us per 32-channel chunk on a small grid, 1-3 us per chunk with two blocks per CU), and
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256 + 64 * NP, (KSP || NST > 2) ? 1 : 2) void conv_
   int boff[WN];                        // float4 index of this lane's pixel, fragment j, tap (0,0)
 #pragma unroll
   for (int j = 0; j < WN; ++j)
-    boff[j] = ((KSP ? 0 : (wave * WN + j)) * FR + fr) * st * PW + fc + half * PHW + (PX4 ? p.px_off : 0);
+    boff[j] = ((KSP ? 0 : (wave * WN + j)) * FR + fr) * st * PW + half * PHW + (PX4 ? fc * st + p.px_off : fc);
   // (PX4: FLOAT index into the plain planes; lane half h reads channel 2s + h: + h * PHW)
 
   f32x16 acc[WM][WN];
@@ -595,7 +596,7 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   int G = k.wp4 ? k.G4 : 0;
   int KC = 8 * G;
   // aligned dwordx4 patch staging (PX4): stride 1, rows and planes that keep 16-byte alignment
-  const bool px4_ok = k.stride == 1 && FC >= 4 && (k.W & 3) == 0 && (k.in0_ns & 3) == 0 &&
+  const bool px4_ok = FC * k.stride >= 4 && (k.W & 3) == 0 && (k.in0_ns & 3) == 0 &&
                       ((uintptr_t)k.in0 & 15) == 0 &&
                       (!k.in1 || ((k.in1_ns & 3) == 0 && ((uintptr_t)k.in1 & 15) == 0));
   const bool px4_large = px4_ok && (SCF_PX4_MODE & 1), px4_small = px4_ok && (SCF_PX4_MODE & 2);
