@@ -635,8 +635,9 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
 #ifdef SCF_NO_SMALL_GRID           /* experiment builds only: round-1 behaviour */
   if (best < 0 || best_blk < 256 || k.T == 1) return SCF_EUNSUPPORTED;
 #endif
-  if (k.T == 1 && large) return SCF_EUNSUPPORTED;     // dense 1x1 on a full grid: the KC = 32 register-staged
-                                                      // kernel is faster (chunks too short for this pipeline)
+  // dense 1x1 on a full grid: stride 1 runs here since the aligned-x4 staging (90 vs 78 TF/s for the
+  // register-staged KC = 32 kernel); stride 2 would stage four times the columns it uses
+  if (k.T == 1 && large && (k.stride != 1 || !px4_large)) return SCF_EUNSUPPORTED;
   if (!pix_ok) {
     // only the small-grid packing is present (dense 1x1): it is for small grids only -- fewer than
     // 256 blocks even with the smallest pixel-split tile (32 channels x 128 pixels)

@@ -188,8 +188,8 @@ def choose_a4_groups(cin: int, kh: int, kw: int, stride: int) -> int:
     t = kh * kw
     if stride not in (1, 2) or cin < 8 or t >= 25:
         return 0
-    if t == 1:      # dense 1x1 on a full grid: chunks too short for this pipeline (measured 54 vs
-        return 0    # 62-70 TF/s): the KC = 32 register-staged kernel keeps them; small grids: a4s
+    if t == 1:      # dense 1x1: 32-channel chunks, stride 1 only (stride 2 would stage 4x the columns it
+        return 4 if (stride == 1 and cin >= 64) else 0      # uses: the register-staged kernel keeps those)
     return 2 if t <= 5 else 1
 
 
