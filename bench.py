@@ -510,6 +510,21 @@ def main():
                                 'tflops': round(v[2] / v[1] / 1e6, 1)} for k, v in top],
                 'note': 'v_mfma_f32_32x32x2_f32 (exact fp32), dense peak 256 CU x 256 flop/clk x 2.4 GHz; '
                         'flops = 2*Cin*KH*KW*Cout*Ho*Wo*N per launch; HIP start/stop events bound to each launch'}
+            # GRU context hoisting: the context channels' part of the SepConvGRU
+            # convolutions runs once per pair instead of once per iteration.  `achieved` counts the
+            # flops actually executed; the same step in the reference's formulation would execute
+            # `saved` more -- reported beside it, not in place of it.
+            dec = getattr(model, 'decoder', None)
+            if dec is not None and getattr(dec, 'hoist_context', False):
+                hc_, cc_ = dec.h_channels, dec.cxt_channels
+                taps = sum(c.conv.kernel_size[0] * c.conv.kernel_size[1] for c in dec.gru.conv_z)
+                saved = 2.0 * cc_ * taps * 3 * hc_ * (32 * 32) * args.batch * (args.iters - 1)
+                result['roofline_conv']['gru_context_hoisting'] = {
+                    'flops_saved_per_step': saved,
+                    'tflops_in_reference_formulation': round((c_fl + saved) / (c_us * 1e-6) / 1e12, 1),
+                    'note': 'conv([h|c|x]) = conv([h|x]) + conv_c(c), c = context features (constant over '
+                            'the iterations): conv_c(c) once per pair; tflops_in_reference_formulation = '
+                            '(executed + saved flops) / conv time, for comparison with a per-iteration GRU'}
 
     # ---- config[1]: single pair latency (rank 0, informational) ----
     if rank == 0 and world == 1 and not standin and not args.no_batch1:
