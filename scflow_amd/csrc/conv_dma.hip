@@ -591,6 +591,8 @@ static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st
 //                  the K-split tile (32 channels x 32 pixels) with a ring as deep as LDS allows
 int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st) {
   if ((!k.wp4 && !k.wp4s) || (k.stride != 1 && k.stride != 2) || k.w_ns != 0) return SCF_EUNSUPPORTED;
+  // byte offsets inside a staged chunk (<= 32 channel planes) are 32-bit and must stay below SCF_DMA_OOB
+  if ((long long)k.H * k.W * 32 * 4 >= 0x7fffffffLL) return SCF_EUNSUPPORTED;
   const int FC = 1 << k.fc_log2, FR = 32 / FC;
   const int frags_m = (k.Cout + 31) / 32;
   int G = k.wp4 ? k.G4 : 0;

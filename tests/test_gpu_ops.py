@@ -163,7 +163,11 @@ DMA_CASES = [
     (64, 24, 40, (3, 3), (1, 1), 24, 40),           # (1,1), ragged tiles (Wo = 40, Ho = 24)
     (32, 224, 128, (3, 3), (1, 1), 32, 32, 2),      # stride 2 (pose head c0): parity-split patch rows
     (64, 64, 96, (3, 3), (1, 1), 64, 64, 2),        # stride 2, FC = 32
-    (64, 32, 64, (3, 3), (1, 1), 30, 22, 2),        # stride 2, odd sizes, ragged tiles
+    (64, 32, 64, (3, 3), (1, 1), 30, 22, 2),        # stride 2, odd sizes, ragged tiles (W % 4 != 0: dword staging)
+    (32, 324, 256, (1, 1), (0, 0), 32, 32),         # dense 1x1 on a full grid: 32-channel chunks, short last chunk (4)
+    (64, 40, 64, (3, 3), (1, 1), 30, 22),           # stride 1, W % 4 != 0: dword staging, ragged everything
+    (32, 72, 96, (3, 3), (1, 1), 16, 48, 2),        # stride 2 with the aligned-x4 staging, FC = 16, wide image
+    (48, 64, 64, (1, 5), (0, 2), 20, 36),           # 1x5 with x4 staging: px_off = 2, tiles cut by the right edge
 ]
 
 
