@@ -305,6 +305,32 @@ __global__ __launch_bounds__(256 + 64 * NP, (KSP || NST > 2) ? 1 : 2) void conv_
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
 
+  // GRU launches: the pre-activation term (`res`: the hoisted context part) goes into the
+  // accumulators NOW, while the first chunks are still on their way, instead of being read in
+  // the epilogue -- a launch of one round of blocks has all its epilogues at the same moment, and
+  // every byte they read or write there is unoverlapped HBM time at the end of the kernel.
+  if (p.res && (p.mode == SCF_CONV_GRU_ZR || p.mode == SCF_CONV_GRU_Q) && p.out_div == 1.0f && !p.out_tile) {
+    if (!is_prod && (!KSP || wave == 0)) {
+      const float* rn = p.res + (long long)n * p.res_ns;
+      const int HWo = p.Ho * p.Wo;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int oy = ty0 + (KSP ? 0 : (wave * WN + j)) * FR + fr, ox = tx0 + fc;
+        if (oy < p.Ho && ox < p.Wo) {
+          const int pj = oy * p.Wo + ox;
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int co = m0 + 32 * i + 8 * (r >> 2) + (r & 3) + 4 * half;
+              if (co < p.Cout) acc[i][j][r] = rn[co * HWo + pj];
+            }
+        }
+      }
+    }
+    p.res = nullptr;                   // consumed: the epilogue adds nothing
+  }
+
   const float* in0n = p.in0 + (long long)n * p.in0_ns;
   const float* in1n = p.in1 ? p.in1 + (long long)n * p.in1_ns : nullptr;
   const long long wrow = (long long)p.Mld4 * 4;      // floats per (chunk, tap, g, h) weight row
