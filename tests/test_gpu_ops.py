@@ -348,7 +348,8 @@ def test_group_norm_relu(hw):
           torch.relu(F.group_norm(x, 32, g, b, 1e-5)), atol=2e-5, what='gn')
 
 
-@pytest.mark.parametrize('n,k,o', [(3, 2048, 1024), (1, 1024, 256), (32, 256, 126), (5, 30, 7)])
+@pytest.mark.parametrize('n,k,o', [(3, 2048, 1024), (1, 1024, 256), (32, 256, 126), (5, 30, 7), (32, 2048, 1024),
+                                   (40, 4096, 70), (33, 72, 33), (2, 60, 5)])
 def test_linear(n, k, o):
     x, wt, b = rnd((n, k), 55), rnd((o, k), 56, k ** -0.5), rnd((o,), 57, 0.1)
     close(ops.linear(x.to(DEV), wt.to(DEV), b.to(DEV), ops.ACT_RELU), torch.relu(F.linear(x, wt, b)),
