@@ -9,6 +9,20 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// sum over an NT-thread workgroup (fixed order), result broadcast to every thread
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < NT / 64; w += 4) s += (red[w] + red[w + 1]) + (red[w + 2] + red[w + 3]);
+  return s;
+}
+
 // sum over a 256-thread workgroup, result broadcast to every thread
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
   v = wave_sum(v);
@@ -22,14 +36,16 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 // ---------------------------------------------------------------------------------
 // InstanceNorm2d(eps, affine=False, no running stats): F.instance_norm on the feature
 // encoder (norm_cfg IN; resnet.py:75-86, raft_encoder.py:300-302).  One block per (n, c)
-// plane; VEC4 float4 per thread cached in registers.
+// plane; VEC4 float4 per thread cached in registers.  NT = 256 threads for planes up to 128 x 128,
+// 1024 threads (16 waves, <= 128 VGPRs each) up to 80 K elements (the 240 x 320 planes of a
+// 480 x 640 crop): still one read and one write of the plane.
 // ---------------------------------------------------------------------------------
-template <int VEC4>
-__global__ __launch_bounds__(256) void instance_norm_kernel(const float* x,      // x / res may alias out (in place):
-                                                            const float* res,    // no __restrict__
-                                                            float* out, int HW,
-                                                            float eps, int relu) {
-  __shared__ float red[4];
+template <int VEC4, int NT = 256>
+__global__ __launch_bounds__(NT) void instance_norm_kernel(const float* x,      // x / res may alias out (in place):
+                                                           const float* res,    // no __restrict__
+                                                           float* out, int HW,
+                                                           float eps, int relu) {
+  __shared__ float red[NT / 64];
   const long long pl = blockIdx.x;
   const float4* xp = reinterpret_cast<const float4*>(x + pl * HW);
   const int n4 = HW >> 2;
@@ -37,27 +53,27 @@ __global__ __launch_bounds__(256) void instance_norm_kernel(const float* x,     
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < VEC4; ++i) {
-    const int idx = i * 256 + threadIdx.x;
+    const int idx = i * NT + threadIdx.x;
     v[i] = idx < n4 ? xp[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
     s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
-  const float mean = block_sum_256(s, red) / (float)HW;
+  const float mean = block_sum<NT>(s, red) / (float)HW;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < VEC4; ++i) {
-    const int idx = i * 256 + threadIdx.x;
+    const int idx = i * NT + threadIdx.x;
     if (idx < n4) {
       const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
       q += (a * a + b * b) + (c * c + d * d);
     }
   }
-  const float var = block_sum_256(q, red) / (float)HW;
+  const float var = block_sum<NT>(q, red) / (float)HW;
   const float rstd = 1.0f / sqrtf(var + eps);
   float4* op = reinterpret_cast<float4*>(out + pl * HW);
   const float4* rp = res ? reinterpret_cast<const float4*>(res + pl * HW) : nullptr;
 #pragma unroll
   for (int i = 0; i < VEC4; ++i) {
-    const int idx = i * 256 + threadIdx.x;
+    const int idx = i * NT + threadIdx.x;
     if (idx < n4) {
       float4 o;
       o.x = (v[i].x - mean) * rstd;
@@ -113,6 +129,8 @@ extern "C" int scf_instance_norm(const float* x, const float* res, float* out, i
   if (vec && n4 <= 256) scf_launch(instance_norm_kernel<1>, grid, blk, 0, st, x, res, out, HW, eps, relu);
   else if (vec && n4 <= 1024) scf_launch(instance_norm_kernel<4>, grid, blk, 0, st, x, res, out, HW, eps, relu);
   else if (vec && n4 <= 4096) scf_launch(instance_norm_kernel<16>, grid, blk, 0, st, x, res, out, HW, eps, relu);
+  else if (vec && n4 <= 8192) scf_launch((instance_norm_kernel<8, 1024>), grid, dim3(1024), 0, st, x, res, out, HW, eps, relu);
+  else if (vec && n4 <= 20480) scf_launch((instance_norm_kernel<20, 1024>), grid, dim3(1024), 0, st, x, res, out, HW, eps, relu);
   else scf_launch(instance_norm_generic_kernel, grid, blk, 0, st, x, res, out, HW, eps, relu);
   return scf_launch_status();
 }

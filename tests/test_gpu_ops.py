@@ -330,7 +330,7 @@ def test_convgru_context_hoisting(n, h, w, kind):
 
 
 # ----------------------------------------------------------- small kernels
-@pytest.mark.parametrize('hw', [(128, 128), (64, 64), (32, 32), (12, 20), (5, 7)])
+@pytest.mark.parametrize('hw', [(128, 128), (64, 64), (32, 32), (12, 20), (5, 7), (240, 320), (120, 160), (250, 330)])
 def test_instance_norm(hw):
     x, res = rnd((2, 6, *hw), 50, 2.0) + 0.5, rnd((2, 6, *hw), 51)
     close(ops.instance_norm(x.to(DEV), relu=True), torch.relu(F.instance_norm(x, eps=1e-5)),
