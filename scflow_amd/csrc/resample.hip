@@ -153,13 +153,25 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
   const int px = xt * 32 + xl;
   const long long hw = (long long)h * w;
   const bool ok = px < w;
-  for (int sub = sub0; sub < SS; sub += 8) {
+  // all SS / 8 * 9 mask values of this thread are requested before the first is used (the loop
+  // below was a chain of SS / 8 dependent memory round trips)
+  float wall[SS / 8][9];
+#pragma unroll
+  for (int it = 0; it < SS / 8; ++it) {
+    const int sub = sub0 + it * 8;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      wall[it][k] = ok ? mask[((long long)n * 9 * SS + k * SS + sub) * hw + (long long)y * w + px] : 0.f;
+  }
+#pragma unroll
+  for (int it = 0; it < SS / 8; ++it) {
+    const int sub = sub0 + it * 8;
     const int sy = sub / S, sx = sub - sy * S;
     float wk[9];
     float mx = -3.4e38f;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-      wk[k] = ok ? mask_mul * mask[((long long)n * 9 * SS + k * SS + sub) * hw + (long long)y * w + px] : 0.f;
+      wk[k] = ok ? mask_mul * wall[it][k] : 0.f;
       mx = fmaxf(mx, wk[k]);
     }
     float den = 0.f;
