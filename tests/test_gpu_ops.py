@@ -168,6 +168,9 @@ DMA_CASES = [
     (64, 40, 64, (3, 3), (1, 1), 30, 22),           # stride 1, W % 4 != 0: dword staging, ragged everything
     (32, 72, 96, (3, 3), (1, 1), 16, 48, 2),        # stride 2 with the aligned-x4 staging, FC = 16, wide image
     (48, 64, 64, (1, 5), (0, 2), 20, 36),           # 1x5 with x4 staging: px_off = 2, tiles cut by the right edge
+    (8, 128, 128, (3, 3), (1, 1), 60, 80),          # Wo = 80: 16-column fragments (5 x 16 instead of 3 x 32)
+    (8, 64, 96, (5, 1), (2, 0), 28, 40),            # Wo = 40: 8-column fragments, 4 rows per fragment
+    (8, 96, 64, (3, 3), (1, 1), 120, 160, 2),       # stride 2 onto a 60 x 80 map
 ]
 
 
