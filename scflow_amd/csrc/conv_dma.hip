@@ -634,12 +634,19 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   };
   const bool pix_ok = k.wp4 && (G == 1 || G == 2 || G == 4) && !(k.in1 && (k.C0 % KC) != 0);
   // candidates in order of preference; WM must divide the channel fragments (no idle MFMA
-  // rows) unless nothing else fits; take the first that gives >= 2 blocks per CU, else the one
-  // with the most blocks.
+  // rows) unless nothing else fits.  Among the tiles that give >= 2 blocks per CU the choice is
+  // by an estimate of (slot utilisation over the launch's rounds) x (what the tile itself
+  // reaches): blocks fill 2 x CUs slots per round, and a last round that leaves CUs with one or
+  // no block costs a good part of a full round (a block alone on its CU runs ~1.7x as fast) --
+  // 640 blocks of the (2,2) tile on a 60 x 80 map are 1.6 round-times for 1.25 rounds of work,
+  // 1280 blocks of the (2,1) tile 2.6 for 2.5.  Without such a tile: the one with the most blocks.
   const int cand[4][2] = {{2, 2}, {3, 1}, {2, 1}, {1, 1}};
+  const float tile_eff[4] = {1.00f, 0.97f, 0.90f, 0.75f};     // measured rate relative to the (2,2) tile
+  const long long slots = 2LL * scf_cu_count();
   int best = -1;
   long long best_blk = 0;
   size_t best_lds = 0;
+  float best_score = 0.f;
   for (int pass = 0; pix_ok && pass < 2 && best < 0; ++pass) {
     for (int c = 0; c < 4; ++c) {
       const int WM = cand[c][0], WN = cand[c][1];
@@ -653,13 +660,24 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
       const size_t ldsb = (size_t)(WF4 * 4 + PE) * 2 * sizeof(float);
       if (PE > (px4_large ? 1024 * SCF_DMA_PU_X4 : 256 * SCF_DMA_PU) || WF4 > 256 * SCF_DMA_WU ||
           ldsb > SCF_DMA_LDS_MAX) continue;
-      const long long blk = (long long)N * ((k.Ho + TR - 1) / TR) * ((k.Wo + FC - 1) / FC) *
-                            ((frags_m + WM - 1) / WM);
-      if (best < 0 || blk > best_blk) { best = c; best_blk = blk; best_lds = ldsb; }
-      if (blk >= 512) break;
+      const long long tiles_y = (k.Ho + TR - 1) / TR;
+      const long long blk = (long long)N * tiles_y * ((k.Wo + FC - 1) / FC) * ((frags_m + WM - 1) / WM);
+      if (blk >= slots) {
+        const long long full = blk / slots, rem = blk % slots;
+        const float rounds = (float)full + (rem == 0 ? 0.f : rem * 2 <= slots ? 0.6f : 1.0f);
+        // useful fraction of the tiles' rows / channel fragments (ragged last tile row, WM not dividing)
+        const float useful = (float)k.Ho / (float)(tiles_y * TR) *
+                             (float)frags_m / (float)(((frags_m + WM - 1) / WM) * WM);
+        const float score = (float)blk / (rounds * (float)slots) * useful * tile_eff[c];
+        if (best < 0 || best_blk < slots || score > best_score * 1.03f) {
+          best = c; best_blk = blk; best_lds = ldsb; best_score = score;
+        }
+      } else if (best < 0 || (best_blk < slots && blk > best_blk)) {
+        best = c; best_blk = blk; best_lds = ldsb;
+      }
     }
   }
-  const bool large = best >= 0 && best_blk >= 512;
+  const bool large = best >= 0 && best_blk >= slots;
 #ifdef SCF_NO_SMALL_GRID           /* experiment builds only: round-1 behaviour */
   if (best < 0 || best_blk < 256 || k.T == 1) return SCF_EUNSUPPORTED;
 #endif

@@ -407,19 +407,6 @@ static unsigned long long* scf_lab_trace = nullptr;
 static int scf_lab_skip_dma = 0, scf_lab_skip_store = 0, scf_lab_rotate = -1, scf_lab_grid = 0, scf_lab_store_mode = 0;
 #endif
 
-// CUs of the current device (cached per device): the grid is persistent, blocks-per-CU x CUs
-static int lookup_cu_count() {
-  static int cus[64] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (cus[dev] == 0) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cus[dev] = n;
-  }
-  return cus[dev];
-}
-
 static int lookup_launch(const float* const* levels, const float* flow, float* out, int N, int h, int w,
                          int r, int L, int level0_tiled, scf_stream_t stream) {
   if (level0_tiled && ((w & 7) || (h & 3) || h <= 2 * r + 2 || w <= 2 * r + 2)) return SCF_EUNSUPPORTED;
@@ -466,7 +453,7 @@ static int lookup_launch(const float* const* levels, const float* flow, float* o
   if (lds > 64 * 1024) return SCF_EUNSUPPORTED;
   int per_cu = (int)((160 * 1024) / (lds + 512));
   per_cu = per_cu > 4 ? 4 : per_cu < 1 ? 1 : per_cu;    // launch bounds: 4 blocks (16 waves) per CU
-  long long nblk = (long long)lookup_cu_count() * per_cu;
+  long long nblk = (long long)scf_cu_count() * per_cu;
   if (nblk > ngroups) nblk = ngroups;
 #ifdef SCF_LOOKUP_TRACE
   p.trace = scf_lab_trace; p.skip_dma = scf_lab_skip_dma; p.skip_store = scf_lab_skip_store;

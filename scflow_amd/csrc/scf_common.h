@@ -17,6 +17,20 @@ static inline hipStream_t scf_stream(scf_stream_t s) { return reinterpret_cast<h
 
 static inline int64_t scf_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// CUs of the current device (cached per device; 256 = MI355X when no device answers, e.g. a dry
+// run of the tile selection on a host without a GPU)
+static inline int scf_cu_count() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
 // A timer = two HIP events bound to ONE kernel launch (hipExtLaunchKernel start / stop events:
 // the dispatch's own begin / end timestamps, i.e. what a kernel trace reports; a pair of
 // recorded events around a launch additionally contains ~3 us of dispatch).  scf_timer_arm()
