@@ -284,3 +284,46 @@ def test_composite_modules_repack_when_a_child_block_changes():
         dec.mask_pred.layers[0].conv.bias.fill_(3.0)
     h1 = dec.packed
     assert h1 is not h0 and float(h1.bias[256:].min()) == 3.0 and float(h1.bias[:256].max()) < 3.0
+
+
+def test_conv_tile_selection_dry_run():
+    """scf_conv2d_query (no launch, runs without a GPU): the tile the LDS-DMA dispatcher picks for
+    the layers of the two benchmark configurations -- by estimated slot utilisation x tile rate
+    (conv_dma.hip): (2,2) where its block count is a whole number of 512-slot rounds, (2,1) / (1,1)
+    where Cout or a partial last round argue for it; 16-column fragments on an 80-wide map."""
+    import ctypes as C
+    from scflow_amd import ops, _lib
+    lib = _lib.load()
+
+    def q(n, cin, cout, k, pad, H, W, stride=1, c0=None):
+        w = torch.randn(cout, cin, *k) * 0.05
+        pc = ops.PackedConv.from_weight(w, None, stride, pad)
+        d = _lib.ConvDesc()
+        d.N, d.H, d.W = n, H, W
+        d.C0 = cin if c0 is None else c0
+        d.C1 = 0 if c0 is None else cin - c0
+        d.in0 = 0x1000
+        d.in1 = 0x2000 if c0 is not None else None
+        d.in0_nstride = d.in1_nstride = cin * H * W
+        d.wp, d.Mld, d.Cout = pc.wp.data_ptr(), pc.mld, cout
+        d.KH, d.KW, d.stride, d.pad_h, d.pad_w, d.KC = pc.kh, pc.kw, stride, pc.pad_h, pc.pad_w, pc.kc
+        d.out, d.out_nstride, d.out_div = 0x3000, cout * H * W, 1.0
+        if pc.wp4 is not None:
+            d.wp_a4, d.a4_groups, d.a4_mld = pc.wp4.data_ptr(), pc.g4, pc.mld
+        if pc.wp4s is not None:
+            d.wp_a4s, d.a4s_groups, d.a4_mld = pc.wp4s.data_ptr(), pc.g4s, pc.mld
+        info = (C.c_int32 * 4)()
+        assert lib.scf_conv2d_query(C.byref(d), info) == 0
+        assert info[3] < 0, 'expected the LDS-DMA kernel'
+        return info[0], info[1], info[2]
+
+    # batch 32, 256x256 crops: 32x32 maps in the loop, whole rounds of 512 blocks
+    assert q(32, 128, 512, (3, 3), 1, 32, 32) == (2, 2, 1024)
+    assert q(32, 256, 256, (1, 5), (0, 2), 32, 32, c0=128) == (2, 2, 512)
+    assert q(32, 256, 128, (1, 5), (0, 2), 32, 32, c0=128) == (2, 1, 512)      # Cout = 128: (2,2) would give 256 blocks
+    assert q(32, 256, 126, (3, 3), 1, 32, 32) == (2, 1, 512)
+    assert q(32, 128, 64, (3, 3), 1, 32, 32) == (1, 1, 512)
+    assert q(64, 64, 64, (3, 3), 1, 128, 128) == (2, 2, 4096)
+    assert q(32, 324, 256, (1, 1), 0, 32, 32) == (2, 2, 512)                   # dense 1x1, stride 1
+    # 8 x 480x640 crops: 60x80 maps; 5 x 16-column fragments per row; (2,2) would be 640 blocks = 1.25 rounds
+    assert q(8, 128, 256, (3, 3), 1, 60, 80) == (2, 1, 8 * 8 * 5 * 4)
