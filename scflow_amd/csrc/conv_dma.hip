@@ -30,9 +30,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef SCF_PX4_MODE
 #define SCF_PX4_MODE 3      // bit 0: full-grid tiles, bit 1: small-grid tiles (lab builds vary this)
 #endif
-#ifndef SCF_DMA_PRODUCERS
-#define SCF_DMA_PRODUCERS 0   // 1: dedicated staging waves (NP = NST - 1) -- measured slower in situ; 0: the MFMA waves stage
-#endif
 #define SCF_DMA_PU_X4 8     // PX4: float4 patch cells per thread per chunk (256 * 8 * 4 floats)
 #define SCF_DMA_LDS_MAX (80 * 1024)   // two blocks per CU (160 KB)
 
@@ -131,7 +128,7 @@ extern "C" int scf_conv_trace_set(unsigned long long* p, int nblk) {
 // slot 127 = HW_ID | XCC_ID << 32
 #define CTRACE(slot)                                                                              \
   do {                                                                                            \
-    if (scf_conv_trace_ptr && (int)blockIdx.x < scf_conv_trace_nblk && (threadIdx.x & 63) == 0 && threadIdx.x < 256 && (slot) < 125) { \
+    if (scf_conv_trace_ptr && (int)blockIdx.x < scf_conv_trace_nblk && (threadIdx.x & 63) == 0 && (slot) < 125) { \
       unsigned long long* tp_ = scf_conv_trace_ptr + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 128; \
       tp_[slot] = __builtin_amdgcn_s_memrealtime();                                               \
       if ((slot) == 0 || (slot) == 3) tp_[(slot) == 0 ? 125 : 126] = __builtin_readcyclecounter();  /* shader clock */ \
@@ -173,19 +170,10 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 //         ~125 vs 4 x 117 cycles of texture-path time per KiB).  B operands are then read with four
 //         ds_read_b32 per (tap, group) step instead of one ds_read_b128 (stride 2: every second
 //         column, a 2-way bank conflict the MFMA-bound loop does not notice).
-// NP    : producer waves (0: the four MFMA waves stage their own quarter of every chunk).  A wave
-//         that issues LDS-DMA stalls in the issue stage whenever the CU's memory pipeline is full
-//         (~1 us per 32-channel chunk on a small grid, 1-3 us per chunk with two blocks per CU), and
-//         an in-order wave cannot feed the matrix pipe meanwhile.  With NP > 0 the block has 4 + NP
-//         waves: waves 4.. do nothing but staging -- producer k owns the chunks c = k (mod NP), one
-//         in flight each (NST = NP + 1 ring slots), and confirms "chunk c has landed" (vmcnt(0)) before
-//         the per-chunk barrier; the MFMA waves only meet that barrier.  The gather tables are
-//         computed by the MFMA waves (as before, one quarter each) and handed over through LDS.
-template <int WM, int WN, int NST = 2, bool KSP = false, bool PX4 = false, int NP = 0>
-__global__ __launch_bounds__(256 + 64 * NP, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel(ConvK p) {
+template <int WM, int WN, int NST = 2, bool KSP = false, bool PX4 = false>
+__global__ __launch_bounds__(256, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel(ConvK p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(!KSP || (WM == 1 && WN == 1), "K-split tile is one 32x32 fragment");
-  static_assert(NP == 0 || NST == NP + 1, "one chunk in flight per producer wave");
   constexpr int BM = WM * 32;
   constexpr int NFRAG = KSP ? 1 : WN * 4;
   constexpr int PU = PX4 ? SCF_DMA_PU_X4 : KSP ? SCF_DMA_PU_KSP : SCF_DMA_PU;
@@ -227,15 +215,13 @@ __global__ __launch_bounds__(256 + 64 * NP, (KSP || NST > 2) ? 1 : 2) void conv_
   // SCF_DMA_OOB (the descriptor's range check writes zeros there).
   const int HWin = p.H * p.W;
   const float rPHW = 1.0f / (float)PHW, rPW = 1.0f / (float)PW;
-  const bool is_prod = NP > 0 && wave >= 4;
   unsigned toff[PU];
 #pragma unroll
   for (int u = 0; u < PU; ++u) {
     const int e = tid + u * 256;
     bool ok = false;
     unsigned o = 0;
-    if (is_prod) {
-    } else if (PX4) {                         // e = float4 cell: (channel c, row py, aligned column group p4)
+    if (PX4) {                         // e = float4 cell: (channel c, row py, aligned column group p4)
       if (u * 1024 < PE) {
         const int PW4 = PW >> 2, PHW4 = PHW >> 2;
         const int c = fast_div(e, PHW4, 1.0f / (float)PHW4), r = e - c * PHW4;
@@ -263,28 +249,8 @@ __global__ __launch_bounds__(256 + 64 * NP, (KSP || NST > 2) ? 1 : 2) void conv_
   for (int u = 0; u < WU; ++u) {
     const int e = tid + u * 256;
     const int row = e / BM, m = e - row * BM;
-    const bool ok = !is_prod && e < WF4 && m0 + m < p.Mld4;
+    const bool ok = e < WF4 && m0 + m < p.Mld4;
     woff[u] = ok ? (unsigned)((row * p.Mld4 + m) * 16) : SCF_DMA_OOB;
-  }
-  // NP > 0: hand the tables to the producer waves (every producer keeps all four quarters)
-  constexpr int NTAB = NP > 0 ? PU + WU : 1;
-  unsigned ptab[NP > 0 ? 4 : 1][NTAB];
-  if (NP > 0) {
-    unsigned* tabs = reinterpret_cast<unsigned*>(lds);
-    if (!is_prod) {
-#pragma unroll
-      for (int u = 0; u < PU; ++u) tabs[u * 256 + tid] = toff[u];
-#pragma unroll
-      for (int u = 0; u < WU; ++u) tabs[(PU + u) * 256 + tid] = woff[u];
-    }
-    __syncthreads();
-    if (is_prod) {
-#pragma unroll
-      for (int vw = 0; vw < 4; ++vw)
-#pragma unroll
-        for (int u = 0; u < NTAB; ++u) ptab[vw][u] = tabs[u * 256 + vw * 64 + lane];
-    }
-    __syncthreads();                   // the ring (which the table scratch aliases) may be written from here on
   }
 
   const int fr = l32 >> p.fc_log2, fc = l32 & (FC - 1);
@@ -310,7 +276,7 @@ __global__ __launch_bounds__(256 + 64 * NP, (KSP || NST > 2) ? 1 : 2) void conv_
   // the epilogue -- a launch of one round of blocks has all its epilogues at the same moment, and
   // every byte they read or write there is unoverlapped HBM time at the end of the kernel.
   if (p.res && (p.mode == SCF_CONV_GRU_ZR || p.mode == SCF_CONV_GRU_Q) && p.out_div == 1.0f && !p.out_tile) {
-    if (!is_prod && (!KSP || wave == 0)) {
+    if (!KSP || wave == 0) {
       const float* rn = p.res + (long long)n * p.res_ns;
       const int HWo = p.Ho * p.Wo;
 #pragma unroll
@@ -355,88 +321,40 @@ __global__ __launch_bounds__(256 + 64 * NP, (KSP || NST > 2) ? 1 : 2) void conv_
     // slot counts re-materialised per call (scalar compares per site): left to itself hipcc hoists
     // the loop-invariant guards out of the chunk loop as 64-bit masks, spills them, and reloads
     // each with two v_readlane -- VALU slots the co-resident wave's MFMA stream leaves scarce
-    if (NP == 0) {
-      int prem = prem0, wrem = wrem0;
-      asm volatile("" : "+s"(prem), "+s"(wrem));
-      const unsigned pl0 = lds_addr(pb) + wave * (PX4 ? 1024 : 256), wl0 = lds_addr(wb) + wave * 1024;
+    int prem = prem0, wrem = wrem0;
+    asm volatile("" : "+s"(prem), "+s"(wrem));
+    const unsigned pl0 = lds_addr(pb) + wave * (PX4 ? 1024 : 256), wl0 = lds_addr(wb) + wave * 1024;
 #pragma unroll
-      for (int u = 0; u < PU; ++u)
-        bdma_slot<PX4>(prs, toff[u], pl0 + u * (PX4 ? 4096 : 1024), prem - u * 256);
+    for (int u = 0; u < PU; ++u)
+      bdma_slot<PX4>(prs, toff[u], pl0 + u * (PX4 ? 4096 : 1024), prem - u * 256);
 #pragma unroll
-      for (int u = 0; u < WU; ++u)
-        bdma_slot<true>(wrs, woff[u], wl0 + u * 4096, wrem - u * 256);
-    } else {                           // a producer wave: all four quarters
-      int prem = pcells, wrem = WF4;
-      asm volatile("" : "+s"(prem), "+s"(wrem));
-      const unsigned pl0 = lds_addr(pb), wl0 = lds_addr(wb);
-#pragma unroll
-      for (int u = 0; u < PU; ++u)
-#pragma unroll
-        for (int vw = 0; vw < 4; ++vw)
-          bdma_slot<PX4>(prs, ptab[vw][u], pl0 + (u * 4 + vw) * (PX4 ? 1024 : 256), prem - (u * 4 + vw) * 64);
-#pragma unroll
-      for (int u = 0; u < WU; ++u)
-#pragma unroll
-        for (int vw = 0; vw < 4; ++vw)
-          bdma_slot<true>(wrs, ptab[vw][PU + u], wl0 + (u * 4 + vw) * 1024, wrem - (u * 4 + vw) * 64);
-    }
+    for (int u = 0; u < WU; ++u)
+      bdma_slot<true>(wrs, woff[u], wl0 + u * 4096, wrem - u * 256);
   };
 
   // DMA instructions this wave issues per chunk (the same for every chunk): vmcnt bookkeeping
   const int cnt = __builtin_amdgcn_readfirstlane(max(0, (prem0 + 255) >> 8) + max(0, (wrem0 + 255) >> 8));
 
   CTRACE(1);
-  if (NP > 0) {
-    if (is_prod) {
-      // ---- producer k: chunks k, k + NP, ...; chunk c lives in ring slot c % NST ----
-      const int pk = wave - 4;
-      if (pk < p.nchunk) stage(pk, pk);
-      int own = pk;                      // next chunk this producer has to confirm
-      for (int chunk = 0; chunk < p.nchunk; ++chunk) {
-        const bool mine = chunk == own;
-        if (mine) __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): chunk `own` has landed
-        __syncthreads();                                 // MFMA waves: done with chunk - 1 (its slot is free)
-        if (mine) {
-          own += NP;
-          if (own < p.nchunk) {
-            int slot = own % NST;
-            stage(own, slot);                            // == the slot of chunk - 1
-          }
-        }
-      }
-      if (KSP) {                         // the K-split reduction's two barriers
-        __syncthreads();
-        __syncthreads();
-      }
-      return;
-    }
-  } else {
 #pragma unroll
-    for (int c = 0; c < NST - 1; ++c)
-      if (c < p.nchunk) stage(c, c);
-  }
+  for (int c = 0; c < NST - 1; ++c)
+    if (c < p.nchunk) stage(c, c);
   CTRACE(2);
 
   int buf = 0;                         // ring slot of the current chunk
   for (int chunk = 0; chunk < p.nchunk; ++chunk) {
-    if (NP > 0) {
-      CTRACE(4 + chunk * 4);
-      __syncthreads();                                 // a producer has seen this chunk land
-      CTRACE(5 + chunk * 4);
+    __builtin_amdgcn_s_setprio(3);
+    // this wave's DMA of THIS chunk has landed; up to NST-2 later chunks stay in flight
+    if (NST == 2) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
     } else {
-      __builtin_amdgcn_s_setprio(3);
-      // this wave's DMA of THIS chunk has landed; up to NST-2 later chunks stay in flight
-      if (NST == 2) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
-      } else {
-        const int later = min(NST - 2, p.nchunk - 1 - chunk);
-        wait_vmcnt_le(later * cnt);
-      }
-      CTRACE(4 + chunk * 4);
-      __syncthreads();                                 // everyone's has; previous MFMA phase done
-      CTRACE(5 + chunk * 4);
-      if (chunk + NST - 1 < p.nchunk) stage(chunk + NST - 1, buf == 0 ? NST - 1 : buf - 1);
+      const int later = min(NST - 2, p.nchunk - 1 - chunk);
+      wait_vmcnt_le(later * cnt);
     }
+    CTRACE(4 + chunk * 4);
+    __syncthreads();                                   // everyone's has; previous MFMA phase done
+    CTRACE(5 + chunk * 4);
+    if (chunk + NST - 1 < p.nchunk) stage(chunk + NST - 1, buf == 0 ? NST - 1 : buf - 1);
     CTRACE(6 + chunk * 4);
     __builtin_amdgcn_s_setprio(0);                     // the MFMA stream yields to the other waves
 
@@ -586,26 +504,20 @@ __global__ __launch_bounds__(256 + 64 * NP, (KSP || NST > 2) ? 1 : 2) void conv_
 
 template <int WM, int WN, int NST = 2, bool KSP = false, bool PX4 = false>
 static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
-  constexpr int NP = SCF_DMA_PRODUCERS ? NST - 1 : 0;
-  if (NP > 0) {                      // the gather tables pass through LDS before the ring is used
-    constexpr size_t tab = (size_t)((PX4 ? SCF_DMA_PU_X4 : KSP ? SCF_DMA_PU_KSP : SCF_DMA_PU) +
-                                    (KSP ? SCF_DMA_WU_KSP : SCF_DMA_WU)) * 1024;
-    if (lds_bytes < tab) lds_bytes = tab;
-  }
   if (lds_bytes > 64 * 1024) {       // opt in to > 64 KiB of dynamic LDS: once per instantiation AND device
     static std::atomic<unsigned long long> raised{0};      // bit d: done on device d
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return SCF_ELAUNCH;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(raised.load(std::memory_order_relaxed) & bit)) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WM, WN, NST, KSP, PX4, NP>),
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WM, WN, NST, KSP, PX4>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               NST == 2 ? SCF_DMA_LDS_MAX : SCF_DMA_LDS_DEEP) != hipSuccess)
         return SCF_ELAUNCH;
       raised.fetch_or(bit, std::memory_order_relaxed);
     }
   }
-  scf_launch((conv_dma_kernel<WM, WN, NST, KSP, PX4, NP>), dim3(nblk), dim3(256 + 64 * NP), lds_bytes, st, k);
+  scf_launch((conv_dma_kernel<WM, WN, NST, KSP, PX4>), dim3(nblk), dim3(256), lds_bytes, st, k);
   return scf_launch_status();
 }
 
@@ -724,8 +636,7 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
     const long long PE = (long long)KC * PH * PW, WF4 = (long long)k.T * G * 2 * 32;
     if (PE > (px4 ? 1024 * SCF_DMA_PU_X4 : 256 * SCF_DMA_PU_KSP) || WF4 > 256 * SCF_DMA_WU_KSP) return SCF_EUNSUPPORTED;
     const size_t stage_b = (size_t)(WF4 * 4 + PE) * sizeof(float);
-    NST = (!SCF_DMA_PRODUCERS && k.nchunk >= 6 && stage_b * 6 <= SCF_DMA_LDS_DEEP) ? 6
-          : k.nchunk >= 3 && stage_b * 4 <= SCF_DMA_LDS_DEEP ? 4 : 2;
+    NST = k.nchunk >= 6 && stage_b * 6 <= SCF_DMA_LDS_DEEP ? 6 : k.nchunk >= 3 && stage_b * 4 <= SCF_DMA_LDS_DEEP ? 4 : 2;
     ldsb = stage_b * NST;
     if (ldsb < 16 * 1024) ldsb = 16 * 1024;            // cross-wave reduction area
     if (ldsb > SCF_DMA_LDS_DEEP) return SCF_EUNSUPPORTED;
@@ -746,9 +657,7 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
 #define SCF_GO(...) return px4 ? launch_dma<__VA_ARGS__, true>(k, (int)nblk, ldsb, st)            \
                                : launch_dma<__VA_ARGS__, false>(k, (int)nblk, ldsb, st)
   if (ksp) {
-#if !SCF_DMA_PRODUCERS
     if (NST == 6) SCF_GO(1, 1, 6, true);
-#endif
     if (NST == 4) SCF_GO(1, 1, 4, true);
     SCF_GO(1, 1, 2, true);
   }
