@@ -264,3 +264,30 @@ def test_repacks_after_in_place_weight_change(golden_dir):
         m.decoder.flow_pred.predict_layer.weight.mul_(0.5)
     c = run()[1][-1]
     assert not torch.equal(b, c)
+
+
+def test_get_pose_is_deterministic_and_hoisting_is_equivalent(golden_dir, model):
+    """no atomics, fixed reduction orders: two runs on the same inputs are bit-identical; and the GRU
+    with the context part hoisted out of the loop (decoder.hoist_context, the default) agrees with
+    the per-iteration form within the parity tolerance (EPE <= 1e-3 px; measured ~1e-5)."""
+    inp = scflow_amd.make_inputs(4, 256, 256, seed=23)
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    args = (d['render_images'], d['real_images'], d['ref_rotation'], d['ref_translation'], d['depth'],
+            d['internel_k'], d['label'])
+    model.decoder.iters = 8
+    a = model.get_pose(*args)
+    b = model.get_pose(*args)
+    for x, y in zip(a, b):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v)
+    assert model.decoder.hoist_context
+    model.decoder.hoist_context = False
+    try:
+        c = model.get_pose(*args)
+    finally:
+        model.decoder.hoist_context = True
+    valid = inp['depth'] > 0
+    for it in range(8):
+        assert oracle.end_point_error(a[0][it].cpu(), c[0][it].cpu(), valid) <= 1e-3
+        assert oracle.end_point_error(a[1][it].cpu(), c[1][it].cpu()) <= 1e-3
+    close(a[2][-1], c[2][-1].cpu(), atol=2e-5, what='final rotation, hoisted vs per-iteration GRU')
