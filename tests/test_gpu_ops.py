@@ -437,6 +437,8 @@ def test_avgpool_and_copy():
 
 # ------------------------------------------------------- split-fp16 (3 x MFMA) convolution
 F16_CASES = [c for c in CONV_CASES if c[1] >= 16 and c[3] != (1, 1)]
+F16_CASES += [(2, 128, 128, (3, 3), 1, (1, 1), 60, 80),     # 16-column fragments (Wo = 80)
+              (2, 64, 96, (5, 1), 1, (2, 0), 28, 40)]      # 8-column fragments (Wo = 40)
 
 
 @pytest.mark.parametrize('case', F16_CASES)
