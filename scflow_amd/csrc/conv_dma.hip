@@ -210,6 +210,35 @@ __global__ __launch_bounds__(256, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel
   const int PE = KC * PHW;             // patch floats per chunk
   const int bufsz = WF4 * 4 + PE;      // floats per buffer (multiple of 4)
 
+  // weights: float4 e = tid + 256u of the chunk's [NIT*2 rows][BM] slab out of [rows][Mld4]
+  constexpr int WU = KSP ? SCF_DMA_WU_KSP : SCF_DMA_WU;
+  unsigned woff[WU];
+#pragma unroll
+  for (int u = 0; u < WU; ++u) {
+    const int e = tid + u * 256;
+    const int row = e / BM, m = e - row * BM;
+    const bool ok = e < WF4 && m0 + m < p.Mld4;
+    woff[u] = ok ? (unsigned)((row * p.Mld4 + m) * 16) : SCF_DMA_OOB;
+  }
+  const long long wrow = (long long)p.Mld4 * 4;      // floats per (chunk, tap, g, h) weight row
+  const long long wslab = (long long)NIT * 2 * wrow; // floats per chunk of packed weights
+  const unsigned wbytes = (unsigned)(((long long)(NIT * 2 - 1) * p.Mld4 + min(BM, p.Mld4 - m0)) * 16);
+  const int wrem0 = WF4 - wave * 64;                 // weight cells from this wave's first lane on, slot 0
+  // a chunk's weight slab: WU pieces per wave.  Chunk 0's go out right here, before the patch table
+  // below is computed (~1.5 us of integer arithmetic the first memory round trip can hide behind).
+  auto stage_w = [&](int chunk, int b) {
+    const scf_rsrc_t wrs = make_rsrc(p.wp4 + (long long)chunk * wslab + (long long)m0 * 4, wbytes);
+    int wrem = wrem0;
+    asm volatile("" : "+s"(wrem));
+    const unsigned wl0 = lds_addr(lds + b * bufsz) + wave * 1024;
+#pragma unroll
+    for (int u = 0; u < WU; ++u)
+      bdma_slot<true>(wrs, woff[u], wl0 + u * 4096, wrem - u * 256);
+  };
+  CTRACE(1);
+  if (p.nchunk > 0) stage_w(0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+
   // ---- gather table: LDS patch float e = tid + 256u <-> (group g, half h, py, px, s) ----
   // Chunk-invariant: byte offset from the chunk's first channel plane; out-of-image positions get
   // SCF_DMA_OOB (the descriptor's range check writes zeros there).
@@ -241,16 +270,6 @@ __global__ __launch_bounds__(256, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel
       o = (unsigned)(c * HWin + iy * p.W + ix) * 4u;
     }
     toff[u] = ok ? o : SCF_DMA_OOB;
-  }
-  // weights: float4 e = tid + 256u of the chunk's [NIT*2 rows][BM] slab out of [rows][Mld4]
-  constexpr int WU = KSP ? SCF_DMA_WU_KSP : SCF_DMA_WU;
-  unsigned woff[WU];
-#pragma unroll
-  for (int u = 0; u < WU; ++u) {
-    const int e = tid + u * 256;
-    const int row = e / BM, m = e - row * BM;
-    const bool ok = e < WF4 && m0 + m < p.Mld4;
-    woff[u] = ok ? (unsigned)((row * p.Mld4 + m) * 16) : SCF_DMA_OOB;
   }
 
   const int fr = l32 >> p.fc_log2, fc = l32 & (FC - 1);
@@ -299,17 +318,13 @@ __global__ __launch_bounds__(256, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel
 
   const float* in0n = p.in0 + (long long)n * p.in0_ns;
   const float* in1n = p.in1 ? p.in1 + (long long)n * p.in1_ns : nullptr;
-  const long long wrow = (long long)p.Mld4 * 4;      // floats per (chunk, tap, g, h) weight row
 
   // cells of the patch / weight areas (a cell = one lane's DMA unit) and this wave's share of them
   const int pcells = PX4 ? PE >> 2 : PE;
-  const int prem0 = pcells - wave * 64, wrem0 = WF4 - wave * 64;   // cells from this wave's first lane on, slot 0
-  const long long wslab = (long long)NIT * 2 * wrow;               // floats per chunk of packed weights
-  const unsigned wbytes = (unsigned)(((long long)(NIT * 2 - 1) * p.Mld4 + min(BM, p.Mld4 - m0)) * 16);
+  const int prem0 = pcells - wave * 64;              // cells from this wave's first lane on, slot 0
 
-  auto stage = [&](int chunk, int b) {
-    float* wb = lds + b * bufsz;
-    float* pb = wb + WF4 * 4;
+  auto stage_p = [&](int chunk, int b) {
+    float* pb = lds + b * bufsz + WF4 * 4;
     const int c0 = chunk * KC;
     const float* base;
     int nvalid;
@@ -317,27 +332,27 @@ __global__ __launch_bounds__(256, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel
     else { base = in1n + (long long)(c0 - p.C0) * HWin; nvalid = p.Cin - c0; }
     // channels past the end of a segment's last chunk fall outside the descriptor: zeros
     const scf_rsrc_t prs = make_rsrc(base, (unsigned)min(nvalid, KC) * (unsigned)HWin * 4u);
-    const scf_rsrc_t wrs = make_rsrc(p.wp4 + (long long)chunk * wslab + (long long)m0 * 4, wbytes);
     // slot counts re-materialised per call (scalar compares per site): left to itself hipcc hoists
     // the loop-invariant guards out of the chunk loop as 64-bit masks, spills them, and reloads
     // each with two v_readlane -- VALU slots the co-resident wave's MFMA stream leaves scarce
-    int prem = prem0, wrem = wrem0;
-    asm volatile("" : "+s"(prem), "+s"(wrem));
-    const unsigned pl0 = lds_addr(pb) + wave * (PX4 ? 1024 : 256), wl0 = lds_addr(wb) + wave * 1024;
+    int prem = prem0;
+    asm volatile("" : "+s"(prem));
+    const unsigned pl0 = lds_addr(pb) + wave * (PX4 ? 1024 : 256);
 #pragma unroll
     for (int u = 0; u < PU; ++u)
       bdma_slot<PX4>(prs, toff[u], pl0 + u * (PX4 ? 4096 : 1024), prem - u * 256);
-#pragma unroll
-    for (int u = 0; u < WU; ++u)
-      bdma_slot<true>(wrs, woff[u], wl0 + u * 4096, wrem - u * 256);
+  };
+  auto stage = [&](int chunk, int b) {   // weights first (chunk 0: already out), then the patch
+    stage_w(chunk, b);
+    stage_p(chunk, b);
   };
 
   // DMA instructions this wave issues per chunk (the same for every chunk): vmcnt bookkeeping
   const int cnt = __builtin_amdgcn_readfirstlane(max(0, (prem0 + 255) >> 8) + max(0, (wrem0 + 255) >> 8));
 
-  CTRACE(1);
+  if (p.nchunk > 0) stage_p(0, 0);     // (its weights went out before the table)
 #pragma unroll
-  for (int c = 0; c < NST - 1; ++c)
+  for (int c = 1; c < NST - 1; ++c)
     if (c < p.nchunk) stage(c, c);
   CTRACE(2);
 
