@@ -65,6 +65,8 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-batch1', action='store_true')
     ap.add_argument('--no-config4', action='store_true')
+    ap.add_argument('--top-layers', type=int, default=14,
+                    help='convolution layers listed in roofline_conv.top_layers')
     ap.add_argument('--standin', action='store_true',
                     help='launcher self-test (tests/test_bench_launcher.py): the step is a CPU '
                          'stand-in, backend gloo; the line is marked "standin": true and is not a '
@@ -252,10 +254,10 @@ def config4_block(device: str, reps_min_s: float = 2.0):
     fa = torch.randn((n, 256, h, w), device=device)
     fb = torch.randn((n, 256, h, w), device=device)
     lv0 = [torch.empty((n * h * w, 1, h, w), device=device)]
-    tiled = ops.tiled_level0_ok(h, w, 4)
+    tiled = ops.pyramid_layout(h, w, 4, 1)
     for _ in range(2):
-        ops.corr_build(fa, fb, 1, out=lv0, level0_tiled=tiled)
-    cb = [ops.time_first_kernel(lambda: ops.corr_build(fa, fb, 1, out=lv0, level0_tiled=tiled))
+        ops.corr_build(fa, fb, 1, out=lv0, tiled_levels=tiled)
+    cb = [ops.time_first_kernel(lambda: ops.corr_build(fa, fb, 1, out=lv0, tiled_levels=tiled))
           for _ in range(5)]
     cb_us = sum(cb) / len(cb)
     cb_fl = 2.0 * 256 * (h * w) ** 2 * n
@@ -402,8 +404,8 @@ def main():
             fb = torch.randn((args.batch, 256, 32, 32), device=device)
             lv0 = [torch.empty((args.batch * 1024, 1, 32, 32), device=device)]
             for _ in range(3):
-                ops.corr_build(fa, fb, 1, out=lv0, level0_tiled=True)
-            cb_ev = [ops.time_first_kernel(lambda: ops.corr_build(fa, fb, 1, out=lv0, level0_tiled=True))
+                ops.corr_build(fa, fb, 1, out=lv0, tiled_levels=1)
+            cb_ev = [ops.time_first_kernel(lambda: ops.corr_build(fa, fb, 1, out=lv0, tiled_levels=1))
                      for _ in range(10)]
             cb_us = sum(cb_ev) / len(cb_ev)
             del fa, fb, lv0
@@ -497,7 +499,7 @@ def main():
             for us, fl, tag in conv_launches:
                 a = by_shape.setdefault(tag, [0, 0.0, 0.0])
                 a[0] += 1; a[1] += us; a[2] += fl
-            top = sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('SCF_BENCH_TOP_LAYERS', '14'))]
+            top = sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:args.top_layers]
             result['roofline_conv'] = {
                 'kernel': 'conv_dma_kernel / conv_mfma_kernel (all convolution launches of one step)',
                 'bound': 'mfma', 'achieved': round(c_fl / (c_us * 1e-6) / 1e12, 1),

@@ -34,7 +34,10 @@ enum {
   SCF_ENODEVICE = -4    /* no gfx950 device visible */
 };
 
-#define SCF_MAX_LEVELS 8
+/* Pyramid levels an entry point accepts.  Level l of an h x w map is (h >> l) x (w >> l) and the
+ * volume holds (h w)^2 floats per pair, so 12 levels already means a pyramid of more than 288 GB:
+ * the bound never binds on this device. */
+#define SCF_MAX_LEVELS 12
 
 /* activation codes used by scf_conv2d / scf_linear */
 enum { SCF_ACT_NONE = 0, SCF_ACT_RELU = 1, SCF_ACT_SIGMOID = 2, SCF_ACT_TANH = 3 };
@@ -46,6 +49,13 @@ enum {
   SCF_CONV_GRU_Q = 2   /* q=tanh; out = (1-z)*h + z*q                                   */
 };
 
+/* ABI version of this header: SCF_ABI_MAJOR changes whenever a struct layout or a signature changes
+ * (scf_conv_desc has grown twice), the minor part when entry points are added.  scf_version()
+ * returns the number the LIBRARY was built with: a C caller compares scf_version() / 100 with
+ * SCF_ABI_MAJOR before its first call; structs additionally carry no size field,
+ * so a mismatch must be refused, not worked around. */
+#define SCF_ABI_MAJOR 3
+#define SCF_VERSION (SCF_ABI_MAJOR * 100 + 0)
 int scf_version(void);
 const char* scf_error_string(int code);
 /* number of HIP devices visible (>=0) or SCF_ENODEVICE */
@@ -73,29 +83,31 @@ int scf_corr_build(const float* feat1, const float* feat2, float* const* levels,
 int scf_corr_lookup(const float* const* levels, const float* flow, float* out,
                     int N, int h, int w, int r, int L, scf_stream_t stream);
 
-/* Same pair with a lookup-friendly LEVEL-0 layout (level0_tiled = 1): every query's level-0
- * map is stored in 8x4-float tiles of one 128-byte line each (needs w % 8 == 0, h % 4 == 0), so
- * a (2r+2)^2 window touches ~6.9 lines instead of 2r+2 = 10 full rows.  Levels >= 1 keep the
- * reference layout.  level0_tiled = 0 is exactly scf_corr_build / scf_corr_lookup.        */
+/* The same pair with a lookup-friendly layout for the levels the caller names: bit l of
+ * `tiled_levels` set = every query's level-l map is stored in 8(x) x 4(y)-float tiles of one
+ * 128-byte line each -- tile-major, row-major inside a tile, the map padded to a multiple of 4 rows
+ * and 8 columns (padding floats are never read and may hold anything).  A (2r+2)^2 lookup window
+ * then touches ~(1 + (2r+1)/8)(1 + (2r+1)/4) = 6.9 lines at r = 4 instead of one or two lines per
+ * window row of a row-major map.  Level 0 is written by the correlation GEMM whose fragments are
+ * whole tiles: bit 0 needs w % 8 == 0 and h % 4 == 0 (SCF_EUNSUPPORTED otherwise).
+ *   scf_corr_level_floats      floats per query of level `level` in the given layout
+ *                              (levels[l] holds N*h*w maps of that many floats)
+ *   scf_corr_preferred_layout  the mask the lookup kernel is fastest with (tiles for every level
+ *                              whose rows are at least 24 floats long and that does not fit the
+ *                              lookup window whole)
+ * tiled_levels = 0 is exactly scf_corr_build / scf_corr_lookup.  Both calls of a pair must be given
+ * the same mask.
+ * scf_corr_lookup[_ex] accepts ANY radius >= 1, level count <= SCF_MAX_LEVELS and map size
+ * (CorrLookup's constructor arguments, corr_lookup.py:91-102): r <= 4 with maps of at most 32767
+ * floats run on the LDS-DMA kernel, everything else on a plain gather kernel with the same
+ * arithmetic.  A query whose flow is NaN / inf yields NaN in all its taps, as torch's
+ * grid_sample does on the reference's CPU path. */
+int64_t scf_corr_level_floats(int h, int w, int level, int tiled);
+unsigned scf_corr_preferred_layout(int h, int w, int r, int L);
 int scf_corr_build_ex(const float* feat1, const float* feat2, float* const* levels, int N, int C,
-                      int h, int w, int L, int level0_tiled, scf_stream_t stream);
+                      int h, int w, int L, unsigned tiled_levels, scf_stream_t stream);
 int scf_corr_lookup_ex(const float* const* levels, const float* flow, float* out, int N, int h,
-                       int w, int r, int L, int level0_tiled, scf_stream_t stream);
-
-/* Measurement aid: the same launch with a timer bound to it (hipExtLaunchKernel start / stop
- * events = the dispatch's own begin / end timestamps, what a kernel trace reports; a pair of
- * recorded events around a launch additionally contains ~3 us of dispatch).  A timer is reusable
- * after its launch has completed; read it after synchronising the stream. */
-typedef void* scf_timer_t;
-int scf_timer_create(scf_timer_t* timer);
-int scf_timer_destroy(scf_timer_t timer);
-int scf_timer_elapsed_us(scf_timer_t timer, float* microseconds);
-/* attach the timer to the NEXT kernel this thread launches through the library (the convolution
- * of scf_conv2d / scf_corr_build*, the lookup, ...); NULL disarms */
-int scf_timer_arm(scf_timer_t timer);
-int scf_corr_lookup_timed(const float* const* levels, const float* flow, float* out, int N, int h,
-                          int w, int r, int L, int level0_tiled, scf_timer_t timer,
-                          scf_stream_t stream);
+                       int w, int r, int L, unsigned tiled_levels, scf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Direct convolution as implicit GEMM on MFMA with fused epilogue.
@@ -215,9 +227,6 @@ int scf_sepconv_gru(float* hx, int64_t hx_nstride, int N, int Ch, int Cx, int H,
 int scf_sepconv_gru_ctx(float* hx, int64_t hx_nstride, int N, int Ch, int Cc, int Cx, int H, int W,
                         const scf_gru_pass* passes, int npass, const float* const* ctx,
                         int64_t ctx_nstride, float* z, float* rh, scf_stream_t stream);
-/* dry run of scf_conv2d's tile selection: info[4] = {WM, WN, grid blocks, MFMAs per wave per
- * staged chunk}; SCF_EUNSUPPORTED when the packing's KC does not fit this shape.         */
-int scf_conv2d_query(const scf_conv_desc* desc, int32_t* info);
 
 /* ---------------------------------------------------------------------------------
  * InstanceNorm2d(eps, affine=False) [+ residual] [+ ReLU] over N*C planes of HW floats.

@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libscflow_hip.so')
 SCF_OK = 0
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 CONV_PLAIN, CONV_GRU_ZR, CONV_GRU_Q = 0, 1, 2
-MAX_LEVELS = 8
+MAX_LEVELS = 12
+ABI_MAJOR = 3            # SCF_ABI_MAJOR of include/scflow_hip.h this binding was written against
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -72,17 +73,17 @@ SIGNATURES = {
     'scf_corr_lookup': (C.c_int, [C.POINTER(_fp), _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, _fp]),
     'scf_corr_build_ex': (C.c_int, [_fp, _fp, C.POINTER(_fp), C.c_int, C.c_int, C.c_int, C.c_int,
-                                    C.c_int, C.c_int, _fp]),
+                                    C.c_int, C.c_uint, _fp]),
     'scf_corr_lookup_ex': (C.c_int, [C.POINTER(_fp), _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
-                                     C.c_int, C.c_int, _fp]),
+                                     C.c_int, C.c_uint, _fp]),
+    'scf_corr_level_floats': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'scf_corr_preferred_layout': (C.c_uint, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'scf_pose_error': (C.c_int, [_fp, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     'scf_filter_flow_by_mask': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _fp]),
     'scf_timer_create': (C.c_int, [C.POINTER(_fp)]),
     'scf_timer_destroy': (C.c_int, [_fp]),
     'scf_timer_arm': (C.c_int, [_fp]),
     'scf_timer_elapsed_us': (C.c_int, [_fp, C.POINTER(C.c_float)]),
-    'scf_corr_lookup_timed': (C.c_int, [C.POINTER(_fp), _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
-                                        C.c_int, C.c_int, _fp, _fp]),
     'scf_conv2d': (C.c_int, [C.POINTER(ConvDesc), _fp]),
     'scf_conv2d_query': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int32)]),
     'scf_pack_conv_weight_size': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -130,6 +131,11 @@ def load() -> C.CDLL:
             f'{LIB_PATH} is missing: the HIP kernels are the product and there is no fallback. '
             'Build it with `python scflow_amd/csrc/build.py` (hipcc --offload-arch=gfx950).')
     lib = C.CDLL(LIB_PATH)
+    lib.scf_version.restype = C.c_int
+    have = lib.scf_version()
+    if have // 100 != ABI_MAJOR:
+        raise ScflowHipError(f'{LIB_PATH} was built with ABI major {have // 100}, this binding expects '
+                             f'{ABI_MAJOR}: rebuild it (python scflow_amd/csrc/build.py --force)')
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the .so does not export it
         fn.restype = res

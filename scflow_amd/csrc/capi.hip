@@ -1,7 +1,7 @@
 // Library-level entry points of libscflow_hip.so.
 #include "scf_common.h"
 
-extern "C" int scf_version(void) { return 100; /* 0.1.0 */ }
+extern "C" int scf_version(void) { return SCF_VERSION; }
 
 extern "C" const char* scf_error_string(int code) {
   switch (code) {

@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include "scf_common.h"
+#include <atomic>
 #include "conv_kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -242,13 +243,16 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvK p) {
 
 template <int WM, int WN, int NK>
 static int launch_f16(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
-  if (lds_bytes > 64 * 1024) {       // opt in to > 64 KiB of dynamic LDS once per instantiation
-    static bool raised = false;
-    if (!raised) {
+  if (lds_bytes > 64 * 1024) {       // opt in to > 64 KiB of dynamic LDS: once per instantiation AND device
+    static std::atomic<unsigned long long> raised{0};      // bit d: done on device d
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return SCF_ELAUNCH;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(raised.load(std::memory_order_relaxed) & bit)) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16x3_kernel<WM, WN, NK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
         return SCF_ELAUNCH;
-      raised = true;
+      raised.fetch_or(bit, std::memory_order_relaxed);
     }
   }
   scf_launch((conv_f16x3_kernel<WM, WN, NK>), dim3(nblk), dim3(256), lds_bytes, st, k);

@@ -696,73 +696,3 @@ extern "C" int scf_conv2d_query(const scf_conv_desc* d, int32_t* info) {
   info[3] = pl.k.T * (pl.k.KC / 2) * pl.WM * pl.WN / (pl.k.ksplit ? 4 : 1);
   return SCF_OK;
 }
-
-// ---------------------------------------------------------------------------------
-// Correlation volume + pyramid: CorrelationPyramid.forward, raft_decoder.py:35-58.
-// level0 = conv2d(1x1) with per-sample weights feat1[n] ([C][hw] is already the packed
-// [K][M] layout), divided by sqrt(C); levels 1.. = cascaded 2x2 average pools.
-// ---------------------------------------------------------------------------------
-extern "C" int scf_avgpool2x2_tiled_in(const float* x, float* out, int64_t planes, int Hin, int Win,
-                                       scf_stream_t stream);
-int scf_corr_gemm_dispatch(const float* feat1, const float* feat2, float* lvl0, float* lvl1, int N, int C,
-                           int h, int w, int tiled, hipStream_t st);
-
-extern "C" int scf_corr_build_ex(const float* feat1, const float* feat2, float* const* levels, int N,
-                                 int C, int h, int w, int L, int level0_tiled, scf_stream_t stream) {
-  if (!feat1 || !feat2 || !levels || N <= 0 || C <= 0 || h <= 0 || w <= 0 || L <= 0) return SCF_EINVAL;
-  if (L > SCF_MAX_LEVELS) return SCF_EUNSUPPORTED;
-  if (level0_tiled && ((w & 7) || (h & 3))) return SCF_EUNSUPPORTED;
-  for (int l = 0; l < L; ++l)
-    if (!levels[l]) return SCF_EINVAL;
-  const int hw = h * w;
-  // dedicated GEMM kernel (corr_gemm.hip): level 0, and level 1 from the same fragments when the
-  // tiled layout is used; generic shapes fall through to the convolution kernel + separate pools
-  {
-    float* l1 = (level0_tiled && L >= 2 && h >= 2 && w >= 2) ? levels[1] : nullptr;
-    int rg = scf_corr_gemm_dispatch(feat1, feat2, levels[0], l1, N, C, h, w, level0_tiled, scf_stream(stream));
-    if (rg == SCF_OK) {
-      int lh = h, lw = w;
-      for (int l = 1; l < L; ++l) {
-        if (lh < 2 || lw < 2) return SCF_EINVAL;
-        if (!(l == 1 && l1)) {
-          rg = (l == 1 && level0_tiled)
-                   ? scf_avgpool2x2_tiled_in(levels[0], levels[1], (int64_t)N * hw, lh, lw, stream)
-                   : scf_avgpool2x2(levels[l - 1], levels[l], (int64_t)N * hw, lh, lw, stream);
-          if (rg != SCF_OK) return rg;
-        }
-        lh /= 2;
-        lw /= 2;
-      }
-      return SCF_OK;
-    }
-    if (rg != SCF_EUNSUPPORTED) return rg;
-  }
-  scf_conv_desc d = {};
-  d.in0 = feat2; d.C0 = C; d.in0_nstride = (int64_t)C * hw;
-  d.N = N; d.H = h; d.W = w;
-  d.wp = feat1; d.w_nstride = (int64_t)C * hw; d.Mld = hw; d.Cout = hw;
-  d.KH = d.KW = 1; d.stride = 1; d.pad_h = d.pad_w = 0;
-  d.KC = (C % 32 == 0) ? 32 : (C % 8 == 0) ? 8 : 2;
-  d.out = levels[0]; d.out_nstride = (int64_t)hw * hw;
-  d.out_div = sqrtf((float)C);
-  d.act = SCF_ACT_NONE; d.mode = SCF_CONV_PLAIN;
-  d.out_tile8x4 = level0_tiled ? 1 : 0;
-  int rc = scf_conv2d(&d, stream);
-  if (rc != SCF_OK) return rc;
-  int lh = h, lw = w;
-  for (int l = 1; l < L; ++l) {
-    if (lh < 2 || lw < 2) return SCF_EINVAL;
-    rc = (l == 1 && level0_tiled)
-             ? scf_avgpool2x2_tiled_in(levels[0], levels[1], (int64_t)N * hw, lh, lw, stream)
-             : scf_avgpool2x2(levels[l - 1], levels[l], (int64_t)N * hw, lh, lw, stream);
-    if (rc != SCF_OK) return rc;
-    lh /= 2;
-    lw /= 2;
-  }
-  return SCF_OK;
-}
-
-extern "C" int scf_corr_build(const float* feat1, const float* feat2, float* const* levels, int N,
-                              int C, int h, int w, int L, scf_stream_t stream) {
-  return scf_corr_build_ex(feat1, feat2, levels, N, C, h, w, L, 0, stream);
-}

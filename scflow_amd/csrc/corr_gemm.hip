@@ -37,8 +37,9 @@ struct CorrGemmParams {
   int mblocks, nblocks;               // 128-query / 128-target blocks per sample
   int tiled;                          // level 0 (and the target order) in 8x4 tiles
   int ntiles_x;                       // w / 8 (tiled)
-  float scale; int exact_scale;       // exact_scale: multiply by scale (= 1/sqrt(C), power of two); else divide by 1/scale... see epilogue
+  float scale; int exact_scale;       // exact_scale: multiply by scale (= 1/sqrt(C), power of two); else divide by `divisor`
   float divisor;
+  int l1_pw4, l1_msz;                 // level-1 layout: 4 x padded width when tiled (0 = row-major), floats per query map
 };
 
 #define CG_KC 16
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256, 3) void corr_gemm_kernel(CorrGemmParams p) {
 
   // ---- epilogue: D layout col = lane & 31 (target element of the fragment), row = query
   //      i0 + wm*64 + 32 fi + (r & 3) + 8 (r >> 2) + 4 half ----
-  const int hw1 = (p.h >> 1) * (p.w >> 1), w1 = p.w >> 1;
+  const int hw1 = p.l1_msz, w1 = p.w >> 1;
   float* o0 = p.lvl0 + (long long)n * hw * hw;
   float* o1 = POOL ? p.lvl1 + (long long)n * hw * hw1 : nullptr;
 #pragma unroll
@@ -190,7 +191,8 @@ __global__ __launch_bounds__(256, 3) void corr_gemm_kernel(CorrGemmParams p) {
         const int ty = F / p.ntiles_x, tx = F - ty * p.ntiles_x;
         const int x = l32 & 7, y = l32 >> 3;
         pool_lane = fok && !(x & 1) && !(y & 1);
-        pos1 = (ty * 2 + (y >> 1)) * w1 + tx * 4 + (x >> 1);
+        const int y1 = ty * 2 + (y >> 1), x1 = tx * 4 + (x >> 1);      // level-1 pixel of this window
+        pos1 = p.l1_pw4 ? (y1 >> 2) * p.l1_pw4 + (x1 >> 3) * 32 + (y1 & 3) * 8 + (x1 & 7) : y1 * w1 + x1;
       }
     } else {
       pos0 = F * 32 + l32;
@@ -221,8 +223,8 @@ __global__ __launch_bounds__(256, 3) void corr_gemm_kernel(CorrGemmParams p) {
 
 // levels[0] (and levels[1] when pooled) of the pyramid.  SCF_EUNSUPPORTED: the caller falls back
 // to the generic path (register-staged kernel + separate pool).
-int scf_corr_gemm_dispatch(const float* feat1, const float* feat2, float* lvl0, float* lvl1, int N, int C,
-                           int h, int w, int tiled, hipStream_t st) {
+static int corr_gemm_dispatch(const float* feat1, const float* feat2, float* lvl0, float* lvl1, int l1_tiled,
+                              int N, int C, int h, int w, int tiled, hipStream_t st) {
   const long long hw = (long long)h * w;
   if (C % CG_KC != 0 || (hw & 3) != 0 || hw > 0x3fffffffLL) return SCF_EUNSUPPORTED;
   if ((long long)C * hw * 4 > 0x7fffffffLL) return SCF_EUNSUPPORTED;          // 32-bit lane byte offsets
@@ -243,6 +245,8 @@ int scf_corr_gemm_dispatch(const float* feat1, const float* feat2, float* lvl0, 
   p.exact_scale = (frexpf(sq, &ex) == 0.5f) ? 1 : 0;       // sqrt(C) is a power of two
   p.scale = 1.0f / sq;
   p.divisor = sq;
+  p.l1_pw4 = (lvl1 && l1_tiled) ? (((w >> 1) + 7) / 8 * 8) * 4 : 0;
+  p.l1_msz = lvl1 ? (int)scf_corr_level_floats(h, w, 1, l1_tiled) : 0;
   const long long nblk = (long long)N * p.mblocks * p.nblocks;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
   const size_t lds = (size_t)CG_NSTAGE * CG_STAGE_FLOATS * sizeof(float);      // 48 KB
@@ -253,4 +257,56 @@ int scf_corr_gemm_dispatch(const float* feat1, const float* feat2, float* lvl0, 
     scf_launch((corr_gemm_kernel<false, false>), dim3((unsigned)nblk), dim3(256), lds, st, p);
   }
   return scf_launch_status();
+}
+
+// ---------------------------------------------------------------------------------
+// Correlation volume + pyramid: CorrelationPyramid.forward, raft_decoder.py:35-58.
+// level 0 = the GEMM above (level 1 from the same fragments when level 0 is tiled); shapes the GEMM
+// does not take (C % 16, hw % 4, unaligned pointers) run as a 1x1 convolution with per-sample
+// "weights" feat1[n] ([C][hw] is already the packed [K][M] layout) divided by sqrt(C); the remaining
+// levels are cascaded 2x2 average pools in the layout the caller names per level.
+// ---------------------------------------------------------------------------------
+int scf_avgpool2x2_layout(const float* x, float* out, int64_t planes, int Hin, int Win, int in_tiled,
+                          int out_tiled, hipStream_t st);
+
+extern "C" int scf_corr_build_ex(const float* feat1, const float* feat2, float* const* levels, int N,
+                                 int C, int h, int w, int L, unsigned tiled_levels, scf_stream_t stream) {
+  if (!feat1 || !feat2 || !levels || N <= 0 || C <= 0 || h <= 0 || w <= 0 || L <= 0) return SCF_EINVAL;
+  if (L > SCF_MAX_LEVELS) return SCF_EUNSUPPORTED;
+  if ((tiled_levels & 1u) && ((w & 7) || (h & 3))) return SCF_EUNSUPPORTED;
+  // everything is validated BEFORE the first launch: no level may be empty
+  for (int l = 0; l < L; ++l)
+    if (!levels[l] || (h >> l) < 1 || (w >> l) < 1) return SCF_EINVAL;
+  hipStream_t st = scf_stream(stream);
+  const int hw = h * w;
+  const int t0 = tiled_levels & 1u, t1 = (tiled_levels >> 1) & 1u;
+  float* l1 = (t0 && L >= 2) ? levels[1] : nullptr;           // first pool fused into the GEMM epilogue
+  int rc = corr_gemm_dispatch(feat1, feat2, levels[0], l1, t1, N, C, h, w, t0, st);
+  int done = (rc == SCF_OK && l1) ? 2 : 1;
+  if (rc == SCF_EUNSUPPORTED) {
+    scf_conv_desc d = {};
+    d.in0 = feat2; d.C0 = C; d.in0_nstride = (int64_t)C * hw;
+    d.N = N; d.H = h; d.W = w;
+    d.wp = feat1; d.w_nstride = (int64_t)C * hw; d.Mld = hw; d.Cout = hw;
+    d.KH = d.KW = 1; d.stride = 1; d.pad_h = d.pad_w = 0;
+    d.KC = (C % 32 == 0) ? 32 : (C % 8 == 0) ? 8 : 2;
+    d.out = levels[0]; d.out_nstride = (int64_t)hw * hw;
+    d.out_div = sqrtf((float)C);
+    d.act = SCF_ACT_NONE; d.mode = SCF_CONV_PLAIN;
+    d.out_tile8x4 = t0;
+    rc = scf_conv2d(&d, stream);
+    done = 1;
+  }
+  if (rc != SCF_OK) return rc;
+  for (int l = done; l < L; ++l) {
+    rc = scf_avgpool2x2_layout(levels[l - 1], levels[l], (int64_t)N * hw, h >> (l - 1), w >> (l - 1),
+                               (tiled_levels >> (l - 1)) & 1u, (tiled_levels >> l) & 1u, st);
+    if (rc != SCF_OK) return rc;
+  }
+  return SCF_OK;
+}
+
+extern "C" int scf_corr_build(const float* feat1, const float* feat2, float* const* levels, int N,
+                              int C, int h, int w, int L, scf_stream_t stream) {
+  return scf_corr_build_ex(feat1, feat2, levels, N, C, h, w, L, 0u, stream);
 }

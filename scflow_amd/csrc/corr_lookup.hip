@@ -23,7 +23,8 @@
 //   tables  : per level the query lanes (lane = query, the two half-waves split rows / columns)
 //             write a 20-entry u16 table per query to LDS: the offset (in floats) of each window
 //             row and of each window column inside the query's map, 0x8000 when outside it.
-//             This is where the layout lives (row-major, or 8x4-float tiles for level 0).
+//             This is where the layout lives (row-major, or 8x4-float tiles of 128 B: any level
+//             whose rows are about a cache line long, see scf_corr_preferred_layout).
 //   gather  : lane = footprint element e = (row, col) of ONE query, two DMA instructions per
 //             query.  Per DMA: two ds_read_u16 with IMMEDIATE offsets (the query loop is
 //             unrolled), v_add_lshl (row + col -> byte offset), v_cmp (any 0x8000 -> lane off),
@@ -35,6 +36,8 @@
 //   emit    : lane = (query, half); per-lane row addresses + immediate column offsets for both
 //             layouts; bilinear weights are per (query, level) constants; each half-wave
 //             writes 32 consecutive queries of one channel = one full 128-B line, write-through.
+//   generic : radius > 4, maps of more than 32767 floats or more LDS than a block may have take
+//             corr_lookup_generic_kernel (one thread per output element; same arithmetic).
 #include "scf_common.h"
 #include <type_traits>
 
@@ -42,33 +45,33 @@
 #define SCF_LOOKUP_STORE_MODE 2      // sc1 = write-through, see lk_store
 #endif
 
+// tools/lab/lookup_lab.hip compiles this file with per-wave timeline stamps and ablation switches;
+// their code lives in tools/lab/lookup_lab_hooks.h.  The product build sees empty hooks.
+#ifdef SCF_LOOKUP_LAB
+#include "../../tools/lab/lookup_lab_hooks.h"
+#else
+#define LK_LAB_PARAMS
+#define LK_TRACE(slot) do { } while (0)
+#define LK_TRACE_END(lvl) do { } while (0)
+#define LK_SKIP_DMA false
+#define LK_SKIP_STORE false
+#define LK_LAB_LAUNCH(p, nblk) do { } while (0)
+#endif
+
 struct LookupParams {
   const float* lvl[SCF_MAX_LEVELS];
   int lh[SCF_MAX_LEVELS];
   int lw[SCF_MAX_LEVELS];
+  int pw4[SCF_MAX_LEVELS];   // level stored in 8x4-float tiles: 4 * padded width (= floats per row of tiles); 0 = row-major
+  int msz[SCF_MAX_LEVELS];   // floats per query map (padded size when tiled)
   const float* flow;
   float* out;
   int N, h, w, L;
   int woff[4];            // LDS offset (floats) of each wave slot's staging region
-  int l0_tiled;           // level 0 stored in 8x4-float tiles (scf_corr_build_ex)
   int ngroups;            // ceil(total_q / 32)
   long long total_q;
-#ifdef SCF_LOOKUP_TRACE
-  unsigned long long* trace;   // [groups][4 waves][8] s_memrealtime stamps (tools/lab/lookup_lab.hip)
-  int skip_dma, skip_store;    // ablations
-#endif
+  LK_LAB_PARAMS
 };
-
-#ifdef SCF_LOOKUP_TRACE
-#define SCF_TRACE(slot)                                                                          \
-  do {                                                                                           \
-    if (p.trace && (threadIdx.x & 63) == 0)                                                      \
-      p.trace[((size_t)g * 4 + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
-  } while (0)
-#else
-#define SCF_TRACE(slot) do { } while (0)
-#endif
-
 
 // explicit LDS (address space 3) pointers: 32 bits each, ds_read / ds_write without relying on
 // address-space inference (the per-lane row address arrays would otherwise be 64-bit flat pointers)
@@ -130,6 +133,44 @@ __device__ __forceinline__ void lk_store(char* sbase, unsigned voff, float v) {
   else asm volatile("global_store_dword %0, %1, %2 sc1 nt" : : "v"(voff), "v"(v), "s"(sbase));
 }
 
+// Window centre of one (query, level) and its bilinear weights -- shared by the LDS-DMA kernel and
+// the generic kernel so that both are the same arithmetic.  Reference: corr_lookup.py:127 (centre /
+// 2^l), :64-67 (normalise with max(size-1, 1), grid_sample de-normalises with size-1).
+//   * along a size-1 axis every tap lands exactly on index 0 (flat: centre := R, weights 1 | 0);
+//   * a centre far outside any map is clamped to +-30000: all taps read zero padding;
+//   * NaN / inf flow, or a centre whose normalisation overflows fp32 (|c| * 2 = inf): the reference's
+//     grid_sample returns NaN for every tap of that query (torch CPU) -- reproduced by NaN weights
+//     on an all-padding window (0 * NaN = NaN).
+struct LkCentre {
+  float x0f, y0f;       // floor of the (clamped) centre
+  int x0, y0;           // map coordinates of window column / row 0
+  float nw, ne, sw, se;
+};
+template <int R_>
+__device__ __forceinline__ LkCentre lk_centre(float qx, float qy, float inv, bool flat_x, bool flat_y, int r_rt = 0) {
+  const int R = R_ > 0 ? R_ : r_rt;
+  const float cxu = qx * inv, cyu = qy * inv;               // exact power-of-two scaling
+  const bool bad = !(fabsf(cxu * 2.f) < __builtin_inff()) || !(fabsf(cyu * 2.f) < __builtin_inff());
+  float cx = flat_x ? (float)R : cxu;
+  float cy = flat_y ? (float)R : cyu;
+  cx = fminf(fmaxf(cx, -30000.f), 30000.f);                 // far outside any map -> all taps 0
+  cy = fminf(fmaxf(cy, -30000.f), 30000.f);
+  if (bad) { cx = -30000.f; cy = -30000.f; }
+  LkCentre c;
+  c.x0f = floorf(cx); c.y0f = floorf(cy);
+  c.x0 = (int)c.x0f - R; c.y0 = (int)c.y0f - R;
+  const float tx = cx - c.x0f, ty = cy - c.y0f;
+  const float wx0 = (c.x0f + 1.f) - cx, wy0 = (c.y0f + 1.f) - cy;   // grid_sample: (x_se - x)
+  const float nanv = __builtin_nanf("");
+  c.nw = bad ? nanv : wx0 * wy0; c.ne = bad ? nanv : tx * wy0;
+  c.sw = bad ? nanv : wx0 * ty;  c.se = bad ? nanv : tx * ty;
+  return c;
+}
+// the blend, as one explicit fma chain (same bits in both kernels)
+__device__ __forceinline__ float lk_blend(float a, float b, float c, float d, float nw, float ne, float sw, float se) {
+  return __builtin_fmaf(d, se, __builtin_fmaf(c, sw, __builtin_fmaf(b, ne, a * nw)));
+}
+
 template <int R, bool SMALL, int SM>
 __device__ __forceinline__ void lookup_emit(const lds_cfp_t (&rowp)[2 * R + 2], int lw, int xfirst,
                                             bool flat_x, float nw, float ne, float sw, float se,
@@ -175,7 +216,7 @@ __device__ __forceinline__ void lookup_emit(const lds_cfp_t (&rowp)[2 * R + 2], 
       char* oc = obase + (size_t)(it * D) * cs;      // wave-uniform channel base (SGPRs)
 #pragma unroll
       for (int j = 0; j < D; ++j) {
-        const float v = cA[j] * w0 + cB[j] * w1 + cA[j + 1] * w2 + cB[j + 1] * w3;
+        const float v = lk_blend(cA[j], cB[j], cA[j + 1], cB[j + 1], w0, w1, w2, w3);
         // a RUNNING scalar base (opaque to the optimiser: it would otherwise precompute all 81
         // channel bases and spill them): one s_add_u32 / s_addc_u32 per store
         asm volatile("" : "+s"(oc));
@@ -187,7 +228,7 @@ __device__ __forceinline__ void lookup_emit(const lds_cfp_t (&rowp)[2 * R + 2], 
   }
 }
 
-template <int R, bool TILED0, int SM>
+template <int R, int SM>
 __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
   constexpr int FW = 2 * R + 2;       // footprint width
   constexpr int FS = FW * FW;         // footprint size
@@ -199,11 +240,7 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds_fp[];
   typedef float __attribute__((ext_vector_type(4))) f4;
 
-#ifdef SCF_LOOKUP_TRACE
-  const bool skip_dma = p.skip_dma != 0, skip_store = p.skip_store != 0;
-#else
-  constexpr bool skip_dma = false, skip_store = false;
-#endif
+  const bool skip_dma = LK_SKIP_DMA, skip_store = LK_SKIP_STORE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
   const int l32 = lane & 31, half = lane >> 5;                // query within the group, half-wave
@@ -226,13 +263,15 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
     live[s] = __ballot(e < FS);
   }
 
+  // query indices fit 31 bits (the launcher refuses more): 32-bit divisions only
+  const unsigned total_q = (unsigned)p.total_q;
   auto flow_of = [&](int gg, float& fx_, float& fy_) {
-    const long long gq_ = (long long)gg * QB + l32;
+    const unsigned gq_ = (unsigned)gg * QB + l32;
     fx_ = 0.f; fy_ = 0.f;
-    if (gq_ < p.total_q) {
-      const int n_ = (int)(gq_ / hw);
-      const int q_ = (int)(gq_ - (long long)n_ * hw);
-      const float* fl = p.flow + (long long)n_ * 2 * hw + q_;
+    if (gq_ < total_q) {
+      const unsigned n_ = gq_ / (unsigned)hw;
+      const unsigned q_ = gq_ - n_ * (unsigned)hw;
+      const float* fl = p.flow + (size_t)n_ * 2 * hw + q_;
       fx_ = fl[0];
       fy_ = fl[hw];
     }
@@ -242,36 +281,40 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
   if (g < p.ngroups) flow_of(g, fx, fy);       // issued before any setup
 
   for (; g < p.ngroups; g += gridDim.x) {
-    SCF_TRACE(0);
-    const long long gq0 = (long long)g * QB;
-    const int n0 = (int)(gq0 / hw);     // sample of the group's first query (wave-uniform)
-    const long long gq = gq0 + l32;
-    const bool qvalid = gq < p.total_q;
-    int n = n0, q = 0;
-    if (qvalid) {
-      n = (int)(gq / hw);
-      q = (int)(gq - (long long)n * hw);
+    LK_TRACE(0);
+    const unsigned gq0 = (unsigned)g * QB;
+    const int n0 = (int)(gq0 / (unsigned)hw);     // sample of the group's first query (wave-uniform)
+    const unsigned gq = gq0 + l32;
+    const bool qvalid = gq < total_q;
+    // maps of >= 32 pixels (every real one): the group spans at most two samples, no per-lane division
+    unsigned q0 = gq - (unsigned)n0 * (unsigned)hw;
+    int n = n0;
+    if (hw >= QB) {
+      if (q0 >= (unsigned)hw) { q0 -= (unsigned)hw; ++n; }
+    } else {
+      const unsigned dn = q0 / (unsigned)hw;
+      n += (int)dn;
+      q0 -= dn * (unsigned)hw;
     }
-    const int y = q / p.w, x = q - y * p.w;
+    const int q = qvalid ? (int)q0 : 0;
+    const int y = (int)((unsigned)q / (unsigned)p.w), x = q - y * p.w;
     const float xf = (float)x, yf = (float)y;
     // byte offset of this lane's query from the group-uniform base out[n0, k, 0, 0]
-    const unsigned lane_off = (unsigned)(((long long)(n - n0) * ktot * hw + q) * 4);
-    const int nq = (int)((p.total_q - gq0) < QB ? (p.total_q - gq0) : QB);   // wave-uniform
+    const unsigned lane_off = ((unsigned)(n - n0) * (unsigned)(ktot * hw) + (unsigned)q) * 4u;
+    const int nq = (int)((total_q - gq0) < (unsigned)QB ? (total_q - gq0) : (unsigned)QB);   // wave-uniform
     const bool more = g + (int)gridDim.x < p.ngroups;
     float fxn = 0.f, fyn = 0.f;
-#ifdef SCF_LOOKUP_TRACE
-    { float a = fx, b = fy; asm volatile("" : "+v"(a), "+v"(b)); SCF_TRACE(1); }
-#endif
 
     for (int lvl = wave; lvl < p.L; lvl += 4) {
       const int lh = p.lh[lvl], lw = p.lw[lvl];
-      const int msz = lh * lw;
+      const int msz = p.msz[lvl];
+      const int pw4 = p.pw4[lvl];
+      const bool tiled = pw4 != 0;
       // Reference quirk at degenerate sizes: coordinates are normalised with max(size-1, 1) and
       // grid_sample(align_corners=True) de-normalises with (size-1), so along a size-1 axis
       // EVERY tap lands exactly on index 0 (corr_lookup.py:64-67).
       const bool flat_x = lw == 1, flat_y = lh == 1;
-      const bool small = (lh <= FW && lw <= FW);
-      const bool tiled = TILED0 && lvl == 0;
+      const bool small = !tiled && (lh <= FW && lw <= FW);
       // the staging area is cleared BEFORE the first use of the flow (whose load is still in flight)
       if (small) {
         if (lane < lw) (myfp + QB * (msz | 1))[lane] = 0.f;            // the shared zero row
@@ -280,16 +323,9 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
           ((__attribute__((address_space(3))) f4*)myfp)[i] = f4{0.f, 0.f, 0.f, 0.f};
       }
       const float inv = 1.0f / (float)(1 << lvl);
-      const float qx = xf + fx, qy = yf + fy;           // first use of the flow
-      float cx = flat_x ? (float)R : qx * inv;          // exact power-of-two scaling
-      float cy = flat_y ? (float)R : qy * inv;
-      cx = fminf(fmaxf(cx, -30000.f), 30000.f);         // far outside any map -> all taps 0
-      cy = fminf(fmaxf(cy, -30000.f), 30000.f);
-      if (!(cx == cx)) cx = -30000.f;                   // NaN flow: treat as out of range
-      if (!(cy == cy)) cy = -30000.f;
-      const float x0f = floorf(cx), y0f = floorf(cy);
-      const int x0 = (int)x0f - R, y0 = (int)y0f - R;
-      const char* lbase = (const char*)lk_sgpr_ptr(p.lvl[lvl] + gq0 * msz);
+      const LkCentre c = lk_centre<R>(xf + fx, yf + fy, inv, flat_x, flat_y);   // first use of the flow
+      const int x0 = c.x0, y0 = c.y0;
+      const char* lbase = (const char*)lk_sgpr_ptr(p.lvl[lvl] + (size_t)gq0 * msz);
       const int i0 = (half * D + 1) / 2;                // first x-offset of this half-wave
       lds_cfp_t rowp[FW];
       unsigned st0 = (unsigned)(uintptr_t)myfp;
@@ -302,7 +338,7 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
         const unsigned long long m0mask = msz >= 64 ? ~0ull : ((1ull << msz) - 1ull);
         const unsigned long long m1mask = msz > 64 ? ((1ull << (msz - 64)) - 1ull) : 0ull;
         const unsigned vlane4 = (unsigned)lane * 4u;
-        SCF_TRACE(2);
+        LK_TRACE(2);
         if (!skip_dma) {
           for (int qq = 0; qq < nq; ++qq) {
             const char* mb = lbase + (size_t)qq * msz * 4;
@@ -320,12 +356,13 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
         // ---- zero-padded footprints, stride FSP; two DMA instructions per query ----
         // offset tables: half-wave 0 writes this query's FW row offsets, half-wave 1 its FW column
         // offsets (in floats, inside the query's map; 0x8000 = outside).  The map layout lives
-        // here and nowhere else: row-major, or 8x4-float tiles of 128 B for level 0.
+        // here and nowhere else: row-major, or 8x4-float tiles of 128 B (rows / columns past the
+        // map's real size -- tile padding -- count as outside like everything else past it).
         {
           const int c0 = half ? x0 : y0, lim = half ? lw : lh;
           const bool flat = half ? flat_x : flat_y;
           const int sh = half ? 3 : 2, msk = half ? 7 : 3;
-          const int mula = tiled ? (half ? 32 : lw * 4) : 0, mulb = tiled ? (half ? 1 : 8) : (half ? 1 : lw);
+          const int mula = tiled ? (half ? 32 : pw4) : 0, mulb = tiled ? (half ? 1 : 8) : (half ? 1 : lw);
           const lds_u16p_t tq = tbl + l32 * TQ + half * FW;
 #pragma unroll
           for (int j = 0; j < FW; j += 2) {
@@ -343,7 +380,7 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): zeros and tables are in LDS
         __builtin_amdgcn_wave_barrier();
-        SCF_TRACE(2);
+        LK_TRACE(2);
         if (!skip_dma) {
           constexpr int QBATCH = 4;                      // table reads of a batch issue together
 #pragma unroll
@@ -372,150 +409,169 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
 #pragma unroll
         for (int r = 0; r < FW; ++r) rowp[r] = f + r * FW;
       }
-      SCF_TRACE(3);
+      LK_TRACE(3);
       // flow of this block's next group: issued behind the gathers, consumed after the stores
       if (more && lvl + 4 >= p.L) flow_of(g + (int)gridDim.x, fxn, fyn);
 
-      // ---- blend weights; lane = (query, half); halves split the x-offsets ----
-      const float tx = cx - x0f, ty = cy - y0f;
-      const float wx0 = (x0f + 1.f) - cx, wy0 = (y0f + 1.f) - cy;   // grid_sample: (x_se - x)
-      const float nw = wx0 * wy0, ne = tx * wy0, sw = wx0 * ty, se = tx * ty;
+      // ---- lane = (query, half); halves split the x-offsets ----
       char* obase = (char*)p.out + ((size_t)n0 * ktot + (size_t)lvl * D * D) * cs;
       __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the DMA data is in LDS
       __builtin_amdgcn_wave_barrier();
-      SCF_TRACE(4);
+      LK_TRACE(4);
       if (small)
-        lookup_emit<R, true, SM>(rowp, lw, x0 + i0, flat_x, nw, ne, sw, se, half, obase, lane_off, cs, qvalid && !skip_store);
+        lookup_emit<R, true, SM>(rowp, lw, x0 + i0, flat_x, c.nw, c.ne, c.sw, c.se, half, obase, lane_off, cs, qvalid && !skip_store);
       else
-        lookup_emit<R, false, SM>(rowp, lw, 0, flat_x, nw, ne, sw, se, half, obase, lane_off, cs, qvalid && !skip_store);
+        lookup_emit<R, false, SM>(rowp, lw, 0, flat_x, c.nw, c.ne, c.sw, c.se, half, obase, lane_off, cs, qvalid && !skip_store);
       __builtin_amdgcn_wave_barrier();
-#ifdef SCF_LOOKUP_TRACE
-      SCF_TRACE(5);
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      SCF_TRACE(6);
-      if (p.trace && lane == 0)
-        p.trace[((size_t)g * 4 + wave) * 8 + 7] = ((unsigned long long)lvl << 32) | __builtin_amdgcn_s_getreg(4 | (31 << 11));
-#endif
+      LK_TRACE_END(lvl);
     }
     fx = fxn;
     fy = fyn;
   }
 }
 
-#ifdef SCF_LOOKUP_TRACE
-static unsigned long long* scf_lab_trace = nullptr;
-static int scf_lab_skip_dma = 0, scf_lab_skip_store = 0, scf_lab_rotate = -1, scf_lab_grid = 0, scf_lab_store_mode = 0;
-#endif
+// ---------------------------------------------------------------------------------
+// Generic lookup: any radius, level count, map size and layout -- one thread per output element,
+// four cached loads per tap.  It exists so that the operator seam (CorrLookup(radius, ...) on any
+// pyramid, corr_lookup.py:91-102) never answers "unsupported"; every configuration the reference
+// ships (r = 4, L = 4, maps up to 60 x 80) takes the LDS-DMA kernel above.  Same centre / weight /
+// blend arithmetic (lk_centre, lk_blend), so both kernels produce the same bits.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void corr_lookup_generic_kernel(LookupParams p, int R) {
+  const int D = 2 * R + 1, DD = D * D;
+  const int hw = p.h * p.w;
+  const long long total = p.total_q * p.L * DD;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int q = (int)(idx % hw);
+    const long long t = idx / hw;
+    const int k = (int)(t % ((long long)p.L * DD));
+    const long long n = t / ((long long)p.L * DD);
+    const int lvl = k / DD, kk = k - lvl * DD;
+    const int i = kk / D, j = kk - i * D;           // x-offset index (slow), y-offset index (fast)
+    const int y = q / p.w, x = q - y * p.w;
+    const int lh = p.lh[lvl], lw = p.lw[lvl], pw4 = p.pw4[lvl];
+    const bool flat_x = lw == 1, flat_y = lh == 1;
+    const float fx = p.flow[(n * 2) * hw + q], fy = p.flow[(n * 2 + 1) * hw + q];
+    const LkCentre c = lk_centre<0>((float)x + fx, (float)y + fy, 1.0f / (float)(1 << lvl), flat_x, flat_y, R);
+    const float* map = p.lvl[lvl] + (n * hw + q) * (long long)p.msz[lvl];
+    auto at = [&](int yy, int xx) -> float {
+      if (flat_y) yy = 0;
+      if (flat_x) xx = 0;
+      if ((unsigned)yy >= (unsigned)lh || (unsigned)xx >= (unsigned)lw) return 0.f;
+      const int off = pw4 ? (yy >> 2) * pw4 + (xx >> 3) * 32 + (yy & 3) * 8 + (xx & 7) : yy * lw + xx;
+      return map[off];
+    };
+    const int xx = c.x0 + i, yy = c.y0 + j;
+    p.out[idx] = lk_blend(at(yy, xx), at(yy, xx + 1), at(yy + 1, xx), at(yy + 1, xx + 1), c.nw, c.ne, c.sw, c.se);
+  }
+}
+
+// floats per query of pyramid level `level` of an h x w map in the given layout
+extern "C" int64_t scf_corr_level_floats(int h, int w, int level, int tiled) {
+  if (h <= 0 || w <= 0 || level < 0 || level >= SCF_MAX_LEVELS) return SCF_EINVAL;
+  const int64_t lh = h >> level, lw = w >> level;
+  if (lh <= 0 || lw <= 0) return SCF_EINVAL;
+  return tiled ? ((lh + 3) / 4 * 4) * ((lw + 7) / 8 * 8) : lh * lw;
+}
+
+// The layout the lookup likes best (bit l = level l in 8x4-float tiles).  A (2r+2)^2 window costs
+// ~ (1 + (2r+1)/8) (1 + (2r+1)/4) 128-byte lines of a tiled map against one or two lines PER ROW of a
+// row-major one: tiling pays once a map row is about a line long (>= 24 floats).  Maps that fit
+// the window are staged whole and stay row-major; level 0 is written by the correlation GEMM, whose
+// fragments are whole tiles (no padding there: w % 8 == 0, h % 4 == 0).
+extern "C" unsigned scf_corr_preferred_layout(int h, int w, int r, int L) {
+  unsigned mask = 0;
+  if (h <= 0 || w <= 0 || r < 1 || L <= 0) return 0;
+  const int FW = 2 * r + 2;
+  for (int l = 0; l < L && l < SCF_MAX_LEVELS; ++l) {
+    const int lh = h >> l, lw = w >> l;
+    if (lh <= 0 || lw <= 0) break;
+    const bool small = lh <= FW && lw <= FW;
+    if (small || lw < 24 || lh < 4) continue;
+    if (l == 0 && ((w & 7) || (h & 3))) continue;
+    mask |= 1u << l;
+  }
+  return mask;
+}
 
 static int lookup_launch(const float* const* levels, const float* flow, float* out, int N, int h, int w,
-                         int r, int L, int level0_tiled, scf_stream_t stream) {
-  if (level0_tiled && ((w & 7) || (h & 3) || h <= 2 * r + 2 || w <= 2 * r + 2)) return SCF_EUNSUPPORTED;
-  if (!levels || !flow || !out || N <= 0 || h <= 0 || w <= 0 || L <= 0) return SCF_EINVAL;
+                         int r, int L, unsigned tiled_levels, scf_stream_t stream) {
+  if (!levels || !flow || !out || N <= 0 || h <= 0 || w <= 0 || L <= 0 || r < 1) return SCF_EINVAL;
   if (L > SCF_MAX_LEVELS) return SCF_EUNSUPPORTED;
-  if (r < 1 || r > 4) return SCF_EUNSUPPORTED;
+  if ((tiled_levels & 1u) && ((w & 7) || (h & 3))) return SCF_EUNSUPPORTED;   // level 0 is never padded
   LookupParams p;
-  int lh = h, lw = w;
+  bool fast = r <= 4;                                    // the LDS-DMA kernel is instantiated for r = 1..4
   for (int l = 0; l < L; ++l) {
+    const int lh = h >> l, lw = w >> l;
     if (!levels[l] || lh <= 0 || lw <= 0) return SCF_EINVAL;
+    const bool tiled = (tiled_levels >> l) & 1u;
     p.lvl[l] = levels[l];
     p.lh[l] = lh;
     p.lw[l] = lw;
-    lh /= 2;
-    lw /= 2;
+    const long long msz = scf_corr_level_floats(h, w, l, tiled);
+    if (msz > 0x7fffffffLL) return SCF_EUNSUPPORTED;
+    p.msz[l] = (int)msz;
+    p.pw4[l] = tiled ? ((lw + 7) / 8 * 8) * 4 : 0;
+    if (msz > 32767) fast = false;                       // u16 offset tables (floats inside one map)
   }
-  for (int l = L; l < SCF_MAX_LEVELS; ++l) { p.lvl[l] = nullptr; p.lh[l] = p.lw[l] = 0; }
+  for (int l = L; l < SCF_MAX_LEVELS; ++l) { p.lvl[l] = nullptr; p.lh[l] = p.lw[l] = p.pw4[l] = p.msz[l] = 0; }
   p.flow = flow;
   p.out = out;
   p.N = N; p.h = h; p.w = w; p.L = L;
   p.total_q = (long long)N * h * w;
-  p.l0_tiled = level0_tiled ? 1 : 0;
   constexpr int qb = 32;   // 32 queries per group: full 128-byte store lines
   const long long ngroups = scf_cdiv(p.total_q, qb);
   if (ngroups > 0x7fffffffLL) return SCF_EUNSUPPORTED;
   p.ngroups = (int)ngroups;
-  // per-wave LDS region: wave w stages levels w, w+4, ...; a level whose whole map fits in the
-  // (2r+2)^2 footprint is staged whole (stride map|1) + one shared zero row, otherwise as
+  // per-wave LDS region: wave w stages levels w, w+4, ...; a row-major level whose whole map fits in
+  // the (2r+2)^2 footprint is staged whole (stride map|1) + one shared zero row, otherwise as
   // zero-padded footprints (stride FS|1) + the u16 offset tables (2*(2r+2) entries per query)
   const int FW = 2 * r + 2, FSP = (FW * FW) | 1;
-  if ((long long)h * w > 32767) return SCF_EUNSUPPORTED;      // u16 offset tables (floats inside one map)
   int off = 0;
   for (int wv = 0; wv < 4; ++wv) {
     int need = 0;
     for (int l = wv; l < L; l += 4) {
-      const bool small = p.lh[l] <= FW && p.lw[l] <= FW;
-      const int fl = small ? qb * ((p.lh[l] * p.lw[l]) | 1) + p.lw[l] : qb * FSP + qb * FW;   // 2*FW u16 = FW floats
+      const bool small = !p.pw4[l] && p.lh[l] <= FW && p.lw[l] <= FW;
+      const int fl = small ? qb * (p.msz[l] | 1) + p.lw[l] : qb * FSP + qb * FW;   // 2*FW u16 = FW floats
       need = need > fl ? need : fl;
     }
     p.woff[wv] = off;
     off += (need + 3) & ~3;                            // 16-byte aligned regions (b128 zero fill)
   }
   const size_t lds = (size_t)off * sizeof(float);
-  if (lds > 64 * 1024) return SCF_EUNSUPPORTED;
+  if (lds > 64 * 1024) fast = false;
+  // 32-bit lane offsets from a group's output base: a group of 32 queries spans at most two samples
+  if ((long long)2 * L * (2 * r + 1) * (2 * r + 1) * h * w * 4 > 0xffffffffLL) fast = false;
+  if (!fast) {
+    const long long total = p.total_q * L * (2 * r + 1) * (2 * r + 1);
+    long long nb = scf_cdiv(total, 256);
+    if (nb > 262144) nb = 262144;
+    scf_launch(corr_lookup_generic_kernel, dim3((unsigned)nb), dim3(256), 0, scf_stream(stream), p, r);
+    return scf_launch_status();
+  }
   int per_cu = (int)((160 * 1024) / (lds + 512));
   per_cu = per_cu > 4 ? 4 : per_cu < 1 ? 1 : per_cu;    // launch bounds: 4 blocks (16 waves) per CU
   long long nblk = (long long)scf_cu_count() * per_cu;
   if (nblk > ngroups) nblk = ngroups;
-#ifdef SCF_LOOKUP_TRACE
-  p.trace = scf_lab_trace; p.skip_dma = scf_lab_skip_dma; p.skip_store = scf_lab_skip_store;
-  if (scf_lab_grid > 0) nblk = scf_lab_grid;
-#endif
-#define SCF_LK2(R_, T_, S_)                                                                         \
-  scf_launch((corr_lookup_kernel<R_, T_, S_>), dim3((unsigned)nblk), dim3(256), lds, scf_stream(stream), p)
+  LK_LAB_LAUNCH(p, nblk);
 #define SCF_LK(R_)                                                                                 \
   case R_:                                                                                         \
-    if (level0_tiled) { SCF_LK2(R_, true, SCF_LOOKUP_STORE_MODE); } else { SCF_LK2(R_, false, SCF_LOOKUP_STORE_MODE); } \
+    scf_launch((corr_lookup_kernel<R_, SCF_LOOKUP_STORE_MODE>), dim3((unsigned)nblk), dim3(256), lds, scf_stream(stream), p); \
     break;
-#ifdef SCF_LOOKUP_TRACE
-  if (r == 4 && level0_tiled && scf_lab_store_mode > 0) {      // lab: A/B of the store policy
-    switch (scf_lab_store_mode) {
-      case 1: SCF_LK2(4, true, 1); break;
-      case 2: SCF_LK2(4, true, 2); break;
-      case 3: SCF_LK2(4, true, 3); break;
-      default: SCF_LK2(4, true, 4); break;
-    }
-    return scf_launch_status();
-  }
-#endif
-#ifdef SCF_LOOKUP_EXPERIMENT      /* TEMPORARY (never in the product build): store policy A/B inside the pipeline */
-  {
-    static const int sm = [] { const char* e = getenv("SCF_LK_SM"); return e ? atoi(e) : -1; }();
-    if (sm >= 0 && r == 4 && level0_tiled) {
-      switch (sm) {
-        case 0: SCF_LK2(4, true, 0); break;
-        case 1: SCF_LK2(4, true, 1); break;
-        case 2: SCF_LK2(4, true, 2); break;
-        case 3: SCF_LK2(4, true, 3); break;
-        default: SCF_LK2(4, true, 4); break;
-      }
-      return scf_launch_status();
-    }
-  }
-#endif
   switch (r) {
     SCF_LK(4) SCF_LK(3) SCF_LK(2) SCF_LK(1)
     default: return SCF_EUNSUPPORTED;
   }
-#undef SCF_LK2
 #undef SCF_LK
   return scf_launch_status();
 }
 
 extern "C" int scf_corr_lookup_ex(const float* const* levels, const float* flow, float* out, int N,
-                                  int h, int w, int r, int L, int level0_tiled, scf_stream_t stream) {
-  return lookup_launch(levels, flow, out, N, h, w, r, L, level0_tiled, stream);
-}
-
-extern "C" int scf_corr_lookup_timed(const float* const* levels, const float* flow, float* out, int N,
-                                     int h, int w, int r, int L, int level0_tiled, scf_timer_t timer,
-                                     scf_stream_t stream) {
-  if (!timer) return SCF_EINVAL;
-  scf_timer_arm(timer);
-  const int rc = lookup_launch(levels, flow, out, N, h, w, r, L, level0_tiled, stream);
-  scf_timer_arm(nullptr);
-  return rc;
+                                  int h, int w, int r, int L, unsigned tiled_levels, scf_stream_t stream) {
+  return lookup_launch(levels, flow, out, N, h, w, r, L, tiled_levels, stream);
 }
 
 extern "C" int scf_corr_lookup(const float* const* levels, const float* flow, float* out, int N,
                                int h, int w, int r, int L, scf_stream_t stream) {
-  return lookup_launch(levels, flow, out, N, h, w, r, L, 0, stream);
+  return lookup_launch(levels, flow, out, N, h, w, r, L, 0u, stream);
 }

@@ -78,34 +78,44 @@ extern "C" int scf_avgpool2x2(const float* x, float* out, int64_t planes, int Hi
   return scf_launch_status();
 }
 
-// level 1 from a level 0 stored in 8x4-float tiles (scf_corr_build_ex): same arithmetic, the
-// four taps of a window always lie in one tile row pair.
-__global__ __launch_bounds__(256) void avgpool2x2_tiled_in_kernel(const float* __restrict__ x,
-                                                                  float* __restrict__ out,
-                                                                  long long planes, int Hin, int Win,
-                                                                  int Ho, int Wo) {
+// The same pool between two pyramid levels in either layout (scf_corr_build_ex): a level is
+// row-major (pw4 = 0) or stored in 8x4-float tiles of a map padded to 4 rows x 8 columns (pw4 = 4 x
+// padded width = floats per row of tiles); msz = floats per query map.  Same arithmetic as above;
+// tile padding is neither read nor written.
+__device__ __forceinline__ int pyr_offset(int y, int x, int pw4, int lw) {
+  return pw4 ? (y >> 2) * pw4 + (x >> 3) * 32 + (y & 3) * 8 + (x & 7) : y * lw + x;
+}
+__global__ __launch_bounds__(256) void avgpool2x2_layout_kernel(const float* __restrict__ x,
+                                                                float* __restrict__ out,
+                                                                long long planes, int Win, int in_pw4,
+                                                                int in_msz, int Ho, int Wo, int out_pw4,
+                                                                int out_msz) {
   const long long total = planes * Ho * Wo;
-  const int tw = Win >> 3;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const int ox = (int)(idx % Wo);
     const long long t = idx / Wo;
     const int oy = (int)(t % Ho);
     const long long pl = t / Ho;
+    const float* s = x + pl * in_msz;
     const int y = 2 * oy, xx = 2 * ox;
-    const float* s = x + pl * Hin * Win + ((y >> 2) * tw + (xx >> 3)) * 32 + (y & 3) * 8 + (xx & 7);
-    out[idx] = (((s[0] + s[1]) + s[8]) + s[9]) * 0.25f;
+    const float a = s[pyr_offset(y, xx, in_pw4, Win)], b = s[pyr_offset(y, xx + 1, in_pw4, Win)];
+    const float c = s[pyr_offset(y + 1, xx, in_pw4, Win)], d = s[pyr_offset(y + 1, xx + 1, in_pw4, Win)];
+    out[pl * out_msz + pyr_offset(oy, ox, out_pw4, Wo)] = (((a + b) + c) + d) * 0.25f;
   }
 }
 
-extern "C" int scf_avgpool2x2_tiled_in(const float* x, float* out, int64_t planes, int Hin, int Win,
-                                       scf_stream_t stream) {
-  if (!x || !out || planes <= 0 || Hin < 4 || Win < 8 || (Win & 7) || (Hin & 3)) return SCF_EINVAL;
+int scf_avgpool2x2_layout(const float* x, float* out, int64_t planes, int Hin, int Win, int in_tiled,
+                          int out_tiled, hipStream_t st) {
+  if (!x || !out || planes <= 0 || Hin < 2 || Win < 2) return SCF_EINVAL;
   const int Ho = Hin / 2, Wo = Win / 2;
+  const int in_pw = (Win + 7) / 8 * 8, in_ph = (Hin + 3) / 4 * 4;
+  const int out_pw = (Wo + 7) / 8 * 8, out_ph = (Ho + 3) / 4 * 4;
   const long long total = (long long)planes * Ho * Wo;
   const int grid = (int)(scf_cdiv(total, 256) < 262144 ? scf_cdiv(total, 256) : 262144);
-  scf_launch(avgpool2x2_tiled_in_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), x, out,
-                     (long long)planes, Hin, Win, Ho, Wo);
+  scf_launch(avgpool2x2_layout_kernel, dim3(grid), dim3(256), 0, st, x, out, (long long)planes, Win,
+             in_tiled ? in_pw * 4 : 0, in_tiled ? in_ph * in_pw : Hin * Win, Ho, Wo,
+             out_tiled ? out_pw * 4 : 0, out_tiled ? out_ph * out_pw : Ho * Wo);
   return scf_launch_status();
 }
 

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/scflow_hip.h"
+#include "../../include/scflow_hip_prof.h"
 
 #define SCF_WAVE 64
 

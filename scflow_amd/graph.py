@@ -26,15 +26,18 @@ class GraphedRefiner:
     def __init__(self, model, example: Dict[str, torch.Tensor], warmup: int = 2) -> None:
         self.model = model
         self.static_in = {k: example[k].clone().contiguous() for k in _INPUTS}
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):            # warm-up: packs weights, primes the allocator
+        # warm-up and capture run on ONE private stream: the side stream that belongs to it
+        # (ops.side_stream keys side streams by main stream) is created during the warm-up, never
+        # inside the capture
+        cs = torch.cuda.Stream()
+        cs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):              # warm-up: packs weights, primes the allocator
             for _ in range(warmup):
                 self._run()
-        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.current_stream().wait_stream(cs)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=cs):
             self.static_out = self._run()
         torch.cuda.synchronize()
 

@@ -40,11 +40,22 @@ class HipModule(nn.Module):
     """nn.Module with a kernel-layout copy of its parameters (``packed``).
 
     The copy is keyed on the identity AND version of every tensor it was built from
-    (``(data_ptr, _version)`` of ``_pack_sources()``), so it follows every way weights can
+    (``(data_ptr, _version)`` of ``_pack_sources()``), so it follows the ways weights normally
     change: ``.to()``, ``load_state_dict`` on this module or on any wrapper / parent (mmcv's
     ``load_checkpoint`` recurses through ``_load_from_state_dict`` and never calls this
-    class's ``load_state_dict``), ``param.data.copy_`` and ``nn.init`` -- all of them bump
-    ``_version`` or replace the storage."""
+    class's ``load_state_dict``), in-place ops on the parameter under ``torch.no_grad()``
+    (``weight.mul_``, ``weight.copy_``) and ``nn.init`` -- all of them bump ``_version`` or replace
+    the storage.  NOT covered: edits through ``param.data`` (``param.data.copy_(...)``,
+    ``param.data.mul_(...)``): ``.data`` is a detached alias with its own version counter, so the
+    parameter's ``_version`` stays put.  After such an edit call ``invalidate_packed()``."""
+
+    def invalidate_packed(self) -> None:
+        """drop every kernel-layout weight copy held by this module and its children; they are
+        rebuilt from the current parameters at the next forward.  Needed only after weight edits
+        the version key cannot see (``param.data.copy_`` and friends)."""
+        self._drop_packed()
+        for m in self.modules():
+            m.__dict__.pop('_ctx_cache', None)
 
     def _drop_packed(self) -> None:
         for m in self.modules():
@@ -245,10 +256,10 @@ class CorrelationPyramid(HipModule):
         super().__init__()
         self.num_levels = num_levels
 
-    def forward(self, feat1: Tensor, feat2: Tensor, level0_tiled: bool = False) -> List[Tensor]:
-        """``level0_tiled`` (decoder-internal): level 0 in the lookup's 8x4-tile layout; the
-        default is the reference's row-major pyramid."""
-        return ops.corr_build(feat1, feat2, self.num_levels, level0_tiled=level0_tiled)
+    def forward(self, feat1: Tensor, feat2: Tensor, tiled_levels: int = 0) -> List[Tensor]:
+        """``tiled_levels`` (decoder-internal, ``ops.pyramid_layout``): those levels in the lookup's
+        8x4-tile layout; the default is the reference's row-major pyramid."""
+        return ops.corr_build(feat1, feat2, self.num_levels, tiled_levels=tiled_levels)
 
 
 class CorrLookup(HipModule):
@@ -262,15 +273,15 @@ class CorrLookup(HipModule):
         self.r = radius
 
     def forward(self, corr_pyramid: Sequence[Tensor], flow: Tensor,
-                level0_tiled: bool = False) -> Tensor:
-        return ops.corr_lookup(corr_pyramid, flow, self.r, level0_tiled=level0_tiled)
+                tiled_levels: int = 0) -> Tensor:
+        return ops.corr_lookup(corr_pyramid, flow, self.r, tiled_levels=tiled_levels)
 
 
-def _use_tiled_level0(feat: Tensor, radius: int, allow: bool = True) -> bool:
-    """the decoders keep the pyramid to themselves, so they are free to pick the tiled level-0
-    layout whenever the map shape allows it (``decoder.tiled_level0 = False`` forces the
-    reference layout: A/B measurements in tools/)."""
-    return allow and ops.tiled_level0_ok(feat.shape[-2], feat.shape[-1], radius)
+def _pyramid_layout(feat: Tensor, radius: int, num_levels: int, allow: bool = True) -> int:
+    """the decoders keep the pyramid to themselves, so they are free to store it in the layout the
+    lookup likes best (``decoder.tiled_pyramid = False`` forces the reference layout: A/B
+    measurements in tools/)."""
+    return ops.pyramid_layout(feat.shape[-2], feat.shape[-1], radius, num_levels) if allow else 0
 
 
 class MotionEncoder(HipModule):
@@ -290,12 +301,13 @@ class MotionEncoder(HipModule):
         self.out_channels = [126]
 
     def forward(self, corr: Tensor, flow: Tensor, out: Optional[Tensor] = None,
-                overlap: bool = False, cf: Optional[Tensor] = None) -> Tensor:
+                overlap: bool = False, cf: Optional[Tensor] = None, fork=None) -> Tensor:
         """raft_decoder.py:152-166.  -> (N, 128, h, w) = [out_net(126) | flow(2)], optionally
         written into ``out`` (a channel slice of the GRU input buffer).  ``overlap`` (small
-        batches): the flow branch runs on the side stream, from the caller's ``ops.fork_point()``;
-        the caller then also passes ``cf`` (N, 256, h, w), allocated BEFORE that fork point (the
-        side branch writes it: see SCFlowRefiner.extract_feat for the allocator rule)."""
+        batches): the flow branch runs on the side stream, from the caller's ``fork`` event
+        (``ops.fork_point()``, taken once ``flow`` is enqueued); the caller then also passes ``cf``
+        (N, 256, h, w), allocated BEFORE that fork point (the side branch writes it: see
+        SCFlowRefiner.extract_feat for the allocator rule)."""
         n, _, h, w = flow.shape
         dev = flow.device
         if out is None:
@@ -304,7 +316,7 @@ class MotionEncoder(HipModule):
             if overlap:
                 raise ValueError('overlap=True needs a cf buffer allocated before the fork point')
             cf = torch.empty((n, 256, h, w), dtype=torch.float32, device=dev)
-        br = ops.side_stream(overlap)
+        br = ops.side_stream(overlap, after=fork)
         with br:
             f1 = self.flow_net[0](flow)
             self.flow_net[1](f1, out=cf[:, 192:])
@@ -516,7 +528,7 @@ class SCFlowDecoder(HipModule):
                                                 ConvBlock(128, 64, 3, padding=1, act_cfg=act_cfg))
         self.mask_encoder = nn.Sequential(ConvBlock(1, 64, 3, padding=1, act_cfg=act_cfg),
                                           ConvBlock(64, 32, 3, padding=1, act_cfg=act_cfg))
-        self.tiled_level0 = True      # decoder-internal pyramid layout (see _use_tiled_level0)
+        self.tiled_pyramid = True     # decoder-internal pyramid layout (see _pyramid_layout)
         self.hoist_context = True     # GRU: convolve the (iteration-invariant) context channels once per pair
 
     def _pack_sources(self):
@@ -542,8 +554,8 @@ class SCFlowDecoder(HipModule):
         dev = depth.device
         f32 = dict(dtype=torch.float32, device=dev)
 
-        tiled = _use_tiled_level0(feat_render, self.radius, self.tiled_level0)
-        pyramid = self.corr_block(feat_render, feat_real, level0_tiled=tiled)      # :172
+        tiled = _pyramid_layout(feat_render, self.radius, self.num_levels, self.tiled_pyramid)
+        pyramid = self.corr_block(feat_render, feat_real, tiled_levels=tiled)      # :172
         # GRU buffer [h | cxt | motion(126) | flow(2)]: the caller's own buffer only when the
         # refiner says it may be consumed (_consume_state); the public forward never mutates
         # its inputs (the reference decoder does not either)
@@ -561,10 +573,9 @@ class SCFlowDecoder(HipModule):
         for _ in range(self.iters):
             flow_lr = ops.resize_bilinear(flow, (h, w), mul=1.0 / scale)           # :196-197
             cf = torch.empty((n, 256, h, w), **f32)      # before the fork (the side branch writes it)
-            if ov_flow:
-                ops.fork_point()             # the motion encoder's flow branch starts here
-            corr = self.corr_lookup(pyramid, flow_lr, level0_tiled=tiled)          # :198
-            self.encoder(corr, flow_lr, out=hx[:, hc + cc:], overlap=ov_flow, cf=cf)   # :206
+            fork = ops.fork_point() if ov_flow else None    # the motion encoder's flow branch starts here
+            corr = self.corr_lookup(pyramid, flow_lr, tiled_levels=tiled)          # :198
+            self.encoder(corr, flow_lr, out=hx[:, hc + cc:], overlap=ov_flow, cf=cf, fork=fork)   # :206
             hv = self.gru.forward_inplace(hx, ctx, cc)                             # :207-208
             ops.conv2d(self.packed, hv, out=heads, act=ACT_RELU)
             d_flow = self.flow_pred.predict(heads[:, :256])                        # :210
@@ -625,7 +636,7 @@ class _RAFTDecoderBase(HipModule):
         self.flow_pred = XHead(self.h_channels, [256], 2, x='flow')
         self.mask_pred = XHead(self.h_channels, [256], self.mask_channels, x='mask')
         self.convex_upsample_flow = convex_unsample_flow
-        self.tiled_level0 = True      # decoder-internal pyramid layout (see _use_tiled_level0)
+        self.tiled_pyramid = True     # decoder-internal pyramid layout (see _pyramid_layout)
         self.hoist_context = True     # GRU: convolve the (iteration-invariant) context channels once per pair
         if self.mask_channels != 9 * (2 ** (num_levels - 1)) ** 2:
             raise NotImplementedError('convex up-sampling kernel: 9 x 8 x 8 mask (radius 4, 4 levels)')
@@ -634,10 +645,10 @@ class _RAFTDecoderBase(HipModule):
         hc, cc = self.h_channels, self.cxt_channels
         return self.gru.context_terms(hx[:, hc:hc + cc]) if self.hoist_context else None
 
-    def _step(self, pyramid, flow, hx, tiled=False, ctx=None):
+    def _step(self, pyramid, flow, hx, tiled=0, ctx=None):
         """one update: lookup, motion encoder, GRU (in place in hx), flow += delta."""
         hc, cc = self.h_channels, self.cxt_channels
-        corr = self.corr_lookup(pyramid, flow, level0_tiled=tiled)
+        corr = self.corr_lookup(pyramid, flow, tiled_levels=tiled)
         self.encoder(corr, flow, out=hx[:, hc + cc:])
         hv = self.gru.forward_inplace(hx, ctx, cc)
         d_flow = self.flow_pred(hv)
@@ -658,8 +669,8 @@ class RAFTDecoder(_RAFTDecoderBase):
 
     def forward(self, feat1: Tensor, feat2: Tensor, flow: Tensor, h_feat: Tensor,
                 cxt_feat: Tensor, _consume_state: bool = False) -> List[Tensor]:
-        tiled = _use_tiled_level0(feat1, self.radius, self.tiled_level0)
-        pyramid = self.corr_block(feat1, feat2, level0_tiled=tiled)
+        tiled = _pyramid_layout(feat1, self.radius, self.num_levels, self.tiled_pyramid)
+        pyramid = self.corr_block(feat1, feat2, tiled_levels=tiled)
         hx = _as_gru_buffer(h_feat, cxt_feat, self.h_channels + self.cxt_channels + 128,
                             _consume_state)
         scale = float(2 ** (self.num_levels - 1))
@@ -683,8 +694,8 @@ class RAFTDecoderMask(_RAFTDecoderBase):
 
     def forward(self, feat1: Tensor, feat2: Tensor, flow: Tensor, h_feat: Tensor,
                 cxt_feat: Tensor, _consume_state: bool = False):
-        tiled = _use_tiled_level0(feat1, self.radius, self.tiled_level0)
-        pyramid = self.corr_block(feat1, feat2, level0_tiled=tiled)
+        tiled = _pyramid_layout(feat1, self.radius, self.num_levels, self.tiled_pyramid)
+        pyramid = self.corr_block(feat1, feat2, tiled_levels=tiled)
         hx = _as_gru_buffer(h_feat, cxt_feat, self.h_channels + self.cxt_channels + 128,
                             _consume_state)
         scale = float(2 ** (self.num_levels - 1))

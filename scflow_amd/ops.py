@@ -25,7 +25,7 @@ from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_GRU_Q, CONV_G
 
 Tensor = torch.Tensor
 
-__all__ = ['PackedConv', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision',
+__all__ = ['PackedConv', 'pyramid_layout', 'untile_level', 'level_storage_shape', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision',
            'get_conv_precision', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
            'instance_norm', 'group_norm_relu', 'linear', 'pose_update', 'reproject_flow',
            'unproject_depth', 'linear_pair', 'resize_bilinear', 'convex_upsample', 'avgpool2x2', 'copy_channels',
@@ -81,8 +81,7 @@ def _opt(t: Optional[Tensor], name: str) -> Optional[int]:
 # At batch 1 every kernel of the path fills a fraction of the chip (a 32x32 map is 8-32 blocks on 256
 # CUs), so independent branches are put on a second HIP stream and run side by side; hipGraph
 # capture records the fork / join as graph dependencies.  Large batches keep one stream.
-_SIDE = {}
-_FORK = {}
+_SIDE = {}      # (device, main stream handle) -> that stream's side stream
 
 
 OVERLAP_BRANCHES = {'context', 'flow', 'mask', 'upsample'}      # tools/lab switches these off one by one
@@ -94,42 +93,51 @@ def small_work(n: int, h: int, w: int, branch: Optional[str] = None) -> bool:
     return n * h * w <= 4 * 256 * 256 and (branch is None or branch in OVERLAP_BRANCHES)
 
 
-def fork_point() -> None:
-    """mark the point of the current stream from which the next ``side_stream`` block may start."""
+def fork_point() -> 'torch.cuda.Event':
+    """record and RETURN an event at this point of the current stream; hand it to
+    ``side_stream(after=...)`` to let a side branch start from here instead of from where the
+    branch is opened.  The event travels explicitly (no module-level state): an event that is never
+    consumed -- an exception between the two calls, a disabled branch -- cannot leak into a later,
+    unrelated branch."""
     ev = torch.cuda.Event()
     ev.record()
-    _FORK[torch.cuda.current_device()] = ev
+    return ev
 
 
 class side_stream:
-    """``br = side_stream(enabled); with br: <branch>`` enqueues the block on this device's second
-    stream, ordered after the last ``fork_point()`` (or after everything enqueued so far);
+    """``br = side_stream(enabled, after=ev); with br: <branch>`` enqueues the block on the second
+    stream that belongs to (this device, the current stream), ordered after ``ev`` (a
+    ``fork_point()`` of the current stream) or, without one, after everything enqueued so far;
     ``br.join()`` -- called once the OTHER branch has been enqueued on the main stream -- makes the
-    main stream wait for it.  Tensors the branch writes into are allocated before the block;
-    tensors it allocates itself must not escape it.  ``enabled=False``: plain in-order execution."""
+    main stream wait for it.  Tensors the branch writes into are allocated before the fork point;
+    tensors it allocates itself must not escape it.  ``enabled=False``: plain in-order execution.
+    One side stream per main stream: a user stream and e.g. GraphedRefiner's warm-up stream never
+    share one."""
 
-    def __init__(self, enabled: bool = True) -> None:
-        self.enabled, self.ctx, self.side = enabled, None, None
+    def __init__(self, enabled: bool = True, after: Optional['torch.cuda.Event'] = None) -> None:
+        self.enabled, self.after, self.ctx, self.side = enabled, after, None, None
 
     def __enter__(self):
         if not self.enabled:
             return self
-        dev = torch.cuda.current_device()
-        self.side = _SIDE.get(dev)
+        main = torch.cuda.current_stream()
+        key = (torch.cuda.current_device(), main.cuda_stream)
+        self.side = _SIDE.get(key)
         if self.side is None:
-            self.side = _SIDE[dev] = torch.cuda.Stream(device=dev)
-        ev = _FORK.pop(dev, None)
+            self.side = _SIDE[key] = torch.cuda.Stream(device=key[0])
+        ev, self.after = self.after, None
         if ev is not None:
             self.side.wait_event(ev)
         else:
-            self.side.wait_stream(torch.cuda.current_stream())
+            self.side.wait_stream(main)
         self.ctx = torch.cuda.stream(self.side)
         self.ctx.__enter__()
         return self
 
     def __exit__(self, *exc):
-        if self.enabled:
+        if self.enabled and self.ctx is not None:
             self.ctx.__exit__(*exc)
+            self.ctx = None
         return False
 
     def join(self) -> None:
@@ -498,64 +506,85 @@ def time_first_kernel(fn) -> float:
 
 
 # ----------------------------------------------------- correlation volume
-def tiled_level0_ok(h: int, w: int, radius: int = 4) -> bool:
-    """whether the 8x4-tiled level-0 layout (scf_corr_build_ex) applies to an h x w map."""
-    return w % 8 == 0 and h % 4 == 0 and h > 2 * radius + 2 and w > 2 * radius + 2
+def pyramid_layout(h: int, w: int, radius: int = 4, num_levels: int = 4) -> int:
+    """the pyramid layout the lookup kernel is fastest with: bit l set = level l stored in 8x4-float
+    tiles of 128 B (``scf_corr_preferred_layout``: every level whose rows are >= 24 floats and that
+    does not fit the lookup window whole).  0 = the reference's row-major pyramid."""
+    return int(_lib.load().scf_corr_preferred_layout(h, w, radius, num_levels))
+
+
+def level_storage_shape(h: int, w: int, level: int, tiled: bool) -> Tuple[int, int]:
+    """(rows, cols) a query's level-``level`` map occupies: the map itself, or -- tiled -- the map
+    padded to 4 rows x 8 columns."""
+    lh, lw = h >> level, w >> level
+    return ((lh + 3) // 4 * 4, (lw + 7) // 8 * 8) if tiled else (lh, lw)
+
+
+def untile_level(level: Tensor, lh: int, lw: int) -> Tensor:
+    """torch view-shuffle of a tiled pyramid level (q, 1, PH, PW) back to the reference's row-major
+    (q, 1, lh, lw) (tests / debugging only; the hot path never untiles)."""
+    q, _, ph, pw = level.shape
+    return (level.reshape(q, ph // 4, pw // 8, 4, 8).permute(0, 1, 3, 2, 4).reshape(q, 1, ph, pw)
+            [:, :, :lh, :lw].contiguous())
 
 
 def untile_level0(level0: Tensor) -> Tensor:
-    """torch view-shuffle of a tiled level 0 back to the reference's row-major layout (tests /
-    debugging only; the hot path never untiles)."""
-    q, _, h, w = level0.shape
-    return (level0.reshape(q, h // 4, w // 8, 4, 8).permute(0, 1, 3, 2, 4).reshape(q, 1, h, w)
-            .contiguous())
+    return untile_level(level0, level0.shape[-2], level0.shape[-1])
+
+
+def _pyramid_shapes(n: int, h: int, w: int, num_levels: int, tiled_levels: int):
+    return [(n * h * w, 1, *level_storage_shape(h, w, l, bool((tiled_levels >> l) & 1)))
+            for l in range(num_levels)]
 
 
 def corr_build(feat1: Tensor, feat2: Tensor, num_levels: int = 4,
-               out: Optional[List[Tensor]] = None, level0_tiled: bool = False) -> List[Tensor]:
-    """CorrelationPyramid.forward (raft_decoder.py:35-58) -> list of
-    (N*h*w, 1, h>>l, w>>l).  ``level0_tiled`` stores level 0 in 128-byte 8x4 tiles for the
-    lookup (same values, permuted inside each query's map; pass the same flag to
-    ``corr_lookup``)."""
+               out: Optional[List[Tensor]] = None, tiled_levels: int = 0) -> List[Tensor]:
+    """CorrelationPyramid.forward (raft_decoder.py:35-58) -> list of (N*h*w, 1, h>>l, w>>l).
+    ``tiled_levels`` (bit mask, see ``pyramid_layout``): those levels are stored in 128-byte 8x4
+    tiles for the lookup -- same values, permuted inside each query's map, the map padded to 4 rows x
+    8 columns (``level_storage_shape``); pass the same mask to ``corr_lookup``."""
     p1 = _dense(feat1, 'feat1')
     p2 = _dense(feat2, 'feat2')
     if feat1.shape != feat2.shape or feat1.dim() != 4:
         raise _lib.ScflowHipError('feat1/feat2 must be equal-shape NCHW')
     n, c, h, w = feat1.shape
+    shapes = _pyramid_shapes(n, h, w, num_levels, tiled_levels)
     if out is None:
-        out = [torch.empty((n * h * w, 1, h >> l, w >> l), dtype=torch.float32,
-                           device=feat1.device) for l in range(num_levels)]
+        out = [torch.empty(sh, dtype=torch.float32, device=feat1.device) for sh in shapes]
+    for l, (t, sh) in enumerate(zip(out, shapes)):
+        if tuple(t.shape) != sh:
+            raise _lib.ScflowHipError(f'pyramid level {l} has shape {tuple(t.shape)}, expected {sh}')
     arr = (C.c_void_p * num_levels)(*[_dense(t, 'level') for t in out])
-    _lib.check(_lib.load().scf_corr_build_ex(p1, p2, arr, n, c, h, w, num_levels,
-                                             1 if level0_tiled else 0, _stream()),
-               'scf_corr_build')
+    _lib.check(_lib.load().scf_corr_build_ex(p1, p2, arr, n, c, h, w, num_levels, int(tiled_levels),
+                                             _stream()), 'scf_corr_build')
     return out
 
 
 def corr_lookup(pyramid: Sequence[Tensor], flow: Tensor, radius: int = 4,
-                out: Optional[Tensor] = None, level0_tiled: bool = False) -> Tensor:
+                out: Optional[Tensor] = None, tiled_levels: int = 0) -> Tensor:
     """CorrLookup.forward (corr_lookup.py:102-136) -> (N, L*(2r+1)^2, h, w)."""
     pf = _dense(flow, 'flow')
     n, two, h, w = flow.shape
     if two != 2:
         raise _lib.ScflowHipError('flow must be (N,2,h,w)')
     L = len(pyramid)
-    for l, lv in enumerate(pyramid):
-        if tuple(lv.shape) != (n * h * w, 1, h >> l, w >> l):
-            raise _lib.ScflowHipError(f'pyramid level {l} has shape {tuple(lv.shape)}')
+    for l, (lv, sh) in enumerate(zip(pyramid, _pyramid_shapes(n, h, w, L, tiled_levels))):
+        if tuple(lv.shape) != sh:
+            raise _lib.ScflowHipError(f'pyramid level {l} has shape {tuple(lv.shape)}, expected {sh}')
     k = L * (2 * radius + 1) ** 2
     if out is None:
         out = torch.empty((n, k, h, w), dtype=torch.float32, device=flow.device)
     arr = (C.c_void_p * L)(*[_dense(t, 'level') for t in pyramid])
-    if _LOOKUP_TIMERS is not None:      # bench.py: a HIP start/stop event pair bound to this launch
-        _lib.check(_lib.load().scf_corr_lookup_timed(arr, pf, _dense(out, 'out'), n, h, w, radius, L,
-                                                     1 if level0_tiled else 0,
-                                                     _LOOKUP_TIMERS.take(), _stream()),
-                   'scf_corr_lookup_timed')
-        return out
-    _lib.check(_lib.load().scf_corr_lookup_ex(arr, pf, _dense(out, 'out'), n, h, w, radius, L,
-                                              1 if level0_tiled else 0, _stream()),
-               'scf_corr_lookup')
+    lib = _lib.load()
+    timed = _LOOKUP_TIMERS is not None      # bench.py: a HIP start/stop event pair bound to this launch
+    if timed:
+        lib.scf_timer_arm(_LOOKUP_TIMERS.take())
+    try:
+        _lib.check(lib.scf_corr_lookup_ex(arr, pf, _dense(out, 'out'), n, h, w, radius, L,
+                                          int(tiled_levels), _stream()), 'scf_corr_lookup')
+    finally:
+        if timed:
+            lib.scf_timer_arm(None)
     return out
 
 

@@ -75,20 +75,22 @@ class SCFlowRefiner(HipModule):
         # its memory must not be a block the allocator recycles from main-stream temporaries that
         # are enqueued after the fork (they could still be running when the side branch writes)
         hx = torch.empty((n, hc + cc + 128, H // sc, W // sc), dtype=torch.float32, device=dev)
+        # ... and so is everything the side branch READS: a non-contiguous render_images is
+        # materialised here, on the main stream, before the fork event (a copy enqueued after it
+        # would not be ordered before the side branch's first read)
+        rend = render_images.contiguous()
         ov_ctx = small_work(n, H, W, 'context')
-        if ov_ctx:
-            ops.fork_point()                            # the context encoder may start from here
+        fork = ops.fork_point() if ov_ctx else None     # the context encoder may start from here
         if self.seperate_encoder:
-            render_feat = self.render_encoder(render_images.contiguous())
+            render_feat = self.render_encoder(rend)
             real_feat = self.real_encoder(real_images.contiguous())
         else:
             both = torch.empty((2 * n, 3, H, W), dtype=torch.float32, device=dev)
-            ops.copy_channels(render_images, both[:n])
-            ops.copy_channels(real_images, both[n:])
+            ops.copy_channels(rend, both[:n])
+            ops.copy_channels(real_images.contiguous(), both[n:])
             feats = self.render_encoder(both)
             render_feat, real_feat = feats[:n], feats[n:]
-        rend = render_images.contiguous()
-        br = ops.side_stream(ov_ctx)                    # small batches: next to the feature encoder
+        br = ops.side_stream(ov_ctx, after=fork)        # small batches: next to the feature encoder
         with br:
             self.context(rend, out=hx[:, :hc + cc], head_act=ACT_TANH,
                          head_act2=ACT_RELU, head_split=hc)
@@ -120,8 +122,12 @@ class SCFlowRefiner(HipModule):
         # the reference's index_select (pose_head.py:209) raises on an out-of-range class id;
         # the pose-update kernel cannot raise (it clamps), so the check lives at this entry
         nc = self.decoder.pose_pred.num_class
-        if labels.numel() and (int(labels.min()) < 0 or int(labels.max()) >= nc):
-            raise IndexError(f'label out of range [0, {nc}): min {int(labels.min())}, max {int(labels.max())}')
+        # (one reduction, one device->host transfer; skipped while the stream is being captured
+        # into a hipGraph, where a synchronising read is illegal: validate before capturing)
+        if labels.numel() and not (labels.is_cuda and torch.cuda.is_current_stream_capturing()):
+            lo, hi = torch.stack(torch.aminmax(labels)).tolist()
+            if lo < 0 or hi >= nc:
+                raise IndexError(f'label out of range [0, {nc}): min {lo}, max {hi}')
         iters = self.decoder.iters
         self.decoder.iters = self.test_iter_num
         try:

@@ -1,5 +1,5 @@
-"""CPU: libscflow_hip.so loads and exports every symbol include/scflow_hip.h declares
-(no compute calls -- there is no GPU here)."""
+"""CPU: libscflow_hip.so loads and exports every symbol include/scflow_hip.h (operator ABI) and
+include/scflow_hip_prof.h (measurement aids) declare (no compute calls -- there is no GPU here)."""
 import os
 import re
 
@@ -10,10 +10,13 @@ from scflow_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, 'include', 'scflow_hip.h')).read()
-    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(scf_[a-z0-9_]+)\s*\(', text)))
+def _declared_symbols(headers=('scflow_hip.h', 'scflow_hip_prof.h')):
+    out = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, 'include', h)).read()
+        text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+        out |= set(re.findall(r'\b(scf_[a-z0-9_]+)\s*\(', text))
+    return sorted(out)
 
 
 def test_library_built():
@@ -31,9 +34,20 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert name in declared, f'{name} bound in _lib.py but not declared in the header'
 
 
+def test_operator_header_holds_no_measurement_entry_points():
+    ops_abi = _declared_symbols(('scflow_hip.h',))
+    assert not [n for n in ops_abi if n.startswith('scf_timer') or n.endswith(('_timed', '_query'))]
+    prof = set(_declared_symbols(('scflow_hip_prof.h',))) - set(ops_abi)
+    assert prof == {'scf_timer_create', 'scf_timer_destroy', 'scf_timer_arm', 'scf_timer_elapsed_us',
+                    'scf_conv2d_query'}
+
+
 def test_version_and_error_strings():
     lib = _lib.load()
-    assert lib.scf_version() >= 100
+    text = open(os.path.join(ROOT, 'include', 'scflow_hip.h')).read()
+    major = int(re.search(r'#define\s+SCF_ABI_MAJOR\s+(\d+)', text).group(1))
+    assert lib.scf_version() // 100 == major == _lib.ABI_MAJOR      # header, library and binding agree
+    assert int(re.search(r'#define\s+SCF_MAX_LEVELS\s+(\d+)', text).group(1)) == _lib.MAX_LEVELS
     assert lib.scf_error_string(0) == b'ok'
     assert b'invalid' in lib.scf_error_string(-1)
 
@@ -80,6 +94,19 @@ def test_c_weight_packers_match_host_packers():
     assert lib.scf_pack_conv_weight_size(4, 4, 3, 3, 5) < 0
     assert lib.scf_pack_conv_weight_a4_size(4, 4, 3, 3, 3) < 0
     assert lib.scf_pack_conv_weight(None, 4, 4, 3, 3, 8, None) < 0
+
+
+def test_pyramid_layout_helpers_run_on_the_host():
+    """scf_corr_level_floats / scf_corr_preferred_layout are plain host functions."""
+    lib = _lib.load()
+    assert lib.scf_corr_level_floats(60, 80, 0, 1) == 60 * 80
+    assert lib.scf_corr_level_floats(60, 80, 1, 1) == 32 * 40 and lib.scf_corr_level_floats(60, 80, 1, 0) == 30 * 40
+    assert lib.scf_corr_level_floats(60, 80, 3, 1) == 8 * 16 and lib.scf_corr_level_floats(60, 80, 3, 0) == 7 * 10
+    assert lib.scf_corr_level_floats(8, 8, 4, 0) < 0          # an empty level
+    assert lib.scf_corr_preferred_layout(32, 32, 4, 4) == 0b0001
+    assert lib.scf_corr_preferred_layout(60, 80, 4, 4) == 0b0011
+    assert lib.scf_corr_preferred_layout(128, 160, 4, 4) == 0b0111
+    assert lib.scf_corr_preferred_layout(30, 44, 4, 4) == 0b0000      # level 0 is never padded; level 1 is 22 wide
 
 
 def test_ops_reject_cpu_tensors():

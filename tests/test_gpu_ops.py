@@ -47,7 +47,7 @@ def test_corr_build_golden(golden_dir):
 
 
 @pytest.mark.parametrize('n,h,w,r,L', [(2, 16, 16, 4, 4), (1, 12, 20, 4, 3), (3, 32, 32, 4, 4),
-                                       (1, 16, 16, 3, 4), (1, 8, 24, 4, 2)])
+                                       (1, 16, 16, 3, 4), (1, 8, 24, 4, 2), (37, 4, 4, 2, 2), (5, 4, 8, 1, 2)])
 def test_corr_lookup(n, h, w, r, L):
     f1, f2 = rnd((n, 32, h, w), 3), rnd((n, 32, h, w), 4)
     pyr = oracle.correlation_pyramid(f1, f2, L)
@@ -72,35 +72,118 @@ def test_corr_lookup_golden_and_channel_order(golden_dir):
     assert int(got[0, :81, 8, 8].argmax()) == 9 * 1 + 6      # x_off=-3 -> a=1, y_off=+2 -> b=6
 
 
-@pytest.mark.parametrize('n,c,h,w', [(2, 32, 16, 16), (1, 64, 12, 24), (2, 256, 32, 32), (1, 20, 20, 40)])
-def test_corr_tiled_level0_is_a_permutation_and_looks_up_identically(n, c, h, w):
-    """scf_corr_build_ex / scf_corr_lookup_ex with level0_tiled=1: level 0 is the reference map
-    bit-for-bit after untiling, levels >= 1 are bit-identical, and the lookup output is
-    bit-identical to the reference-layout lookup (same loads, same arithmetic order)."""
-    assert ops.tiled_level0_ok(h, w, 4)
-    f1, f2 = rnd((n, c, h, w), 11).to(DEV), rnd((n, c, h, w), 12).to(DEV)
-    ref = ops.corr_build(f1, f2, 4)
-    til = ops.corr_build(f1, f2, 4, level0_tiled=True)
-    assert torch.equal(ops.untile_level0(til[0]), ref[0])
-    for a, b in zip(til[1:], ref[1:]):
-        assert torch.equal(a, b)
-    flow = rnd((n, 2, h, w), 13, 4.0)
+def _edge_flow(n, h, w, seed, scale=4.0):
+    flow = rnd((n, 2, h, w), seed, scale)
     flow[0, :, 0, 0] = torch.tensor([-40., 3.])
     flow[0, :, 1, 1] = torch.tensor([float(w), float(h)])
     flow[0, :, 2, 2] = torch.tensor([1e9, -1e9])
     flow[0, :, 3, 3] = torch.tensor([-3.5, -2.25])
-    flow = flow.to(DEV)
+    return flow
+
+
+# mask None = the layout the decoders pick (ops.pyramid_layout); explicit masks also tile levels the
+# rule would leave row-major (small maps, padded 30x40 / 15x20 / 4x4 levels)
+@pytest.mark.parametrize('n,c,h,w,mask', [(2, 32, 16, 16, 0b0001), (1, 64, 12, 24, None), (2, 256, 32, 32, None),
+                                          (1, 20, 20, 40, None), (1, 32, 60, 80, None), (1, 32, 60, 80, 0b1111),
+                                          (2, 32, 32, 32, 0b1111), (1, 16, 24, 48, 0b0110), (1, 32, 44, 56, 0b0010)])
+def test_corr_tiled_levels_are_a_permutation_and_look_up_identically(n, c, h, w, mask):
+    """scf_corr_build_ex / scf_corr_lookup_ex with a tile mask: every tiled level is the reference
+    map bit-for-bit after untiling (padding dropped), row-major levels are bit-identical, and the
+    lookup output is bit-identical to the reference-layout lookup (same loads, same arithmetic)."""
+    if mask is None:
+        mask = ops.pyramid_layout(h, w, 4, 4)
+        assert mask & 1, 'these shapes tile at least level 0'
+    f1, f2 = rnd((n, c, h, w), 11).to(DEV), rnd((n, c, h, w), 12).to(DEV)
+    ref = ops.corr_build(f1, f2, 4)
+    til = ops.corr_build(f1, f2, 4, tiled_levels=mask)
+    for l, (a, b) in enumerate(zip(til, ref)):
+        if (mask >> l) & 1:
+            assert tuple(a.shape[-2:]) == ops.level_storage_shape(h, w, l, True)
+            assert torch.equal(ops.untile_level(a, h >> l, w >> l), b), f'level {l}'
+        else:
+            assert torch.equal(a, b), f'level {l}'
+    flow = _edge_flow(n, h, w, 13).to(DEV)
     want = ops.corr_lookup(ref, flow, 4)
-    got = ops.corr_lookup(til, flow, 4, level0_tiled=True)
+    got = ops.corr_lookup(til, flow, 4, tiled_levels=mask)
     assert torch.equal(got, want)
     close(got, oracle.corr_lookup([p.cpu() for p in ref], flow.cpu().clone(), 4), atol=5e-5,
           what='tiled lookup vs oracle')
 
 
-def test_corr_tiled_rejects_unaligned_maps():
+def test_pyramid_layout_rule():
+    """levels whose rows are >= 24 floats and that do not fit the 10x10 window are tiled."""
+    assert ops.pyramid_layout(32, 32, 4, 4) == 0b0001          # 256x256 crops: level 1 is 16 wide
+    assert ops.pyramid_layout(60, 80, 4, 4) == 0b0011          # 480x640: 60x80 and 30x40
+    assert ops.pyramid_layout(16, 16, 4, 4) == 0
+    assert ops.pyramid_layout(30, 40, 4, 2) == 0               # level 0 is not a whole number of tiles, level 1 is 20 wide
+    assert ops.pyramid_layout(62, 96, 4, 3) == 0b0110          # 31x48 and 15x24 are tiled (padded to 32x48, 16x24)
+    assert ops.level_storage_shape(60, 80, 1, True) == (32, 40)
+    assert ops.level_storage_shape(60, 80, 2, True) == (16, 24)
+    assert ops.level_storage_shape(60, 80, 2, False) == (15, 20)
+
+
+def test_corr_tiled_rejects_unaligned_level0():
     f = rnd((1, 8, 10, 12), 1).to(DEV)
     with pytest.raises(Exception):
-        ops.corr_build(f, f, 2, level0_tiled=True)
+        ops.corr_build(f, f, 2, tiled_levels=1)
+    with pytest.raises(Exception):          # a level list in the wrong storage shape is refused too
+        ops.corr_lookup(ops.corr_build(f, f, 2), torch.zeros((1, 2, 10, 12), device=DEV), 4, tiled_levels=2)
+
+
+@pytest.mark.parametrize('n,h,w,r,L,mask', [(1, 24, 24, 5, 3, 0), (2, 16, 16, 7, 2, 0), (1, 24, 32, 6, 3, 0b001),
+                                            (1, 192, 192, 4, 4, 0), (1, 192, 192, 4, 2, 0b011), (1, 16, 16, 1, 5, 0)])
+def test_corr_lookup_generic_kernel(n, h, w, r, L, mask):
+    """operator-seam generality (CorrLookup(radius, ...) on any pyramid, corr_lookup.py:91-102):
+    radius > 4 and maps of more than 32767 floats take the plain gather kernel -- same oracle, same
+    tolerance, both layouts."""
+    f1, f2 = rnd((n, 8, h, w), 3).to(DEV), rnd((n, 8, h, w), 4).to(DEV)
+    ref = ops.corr_build(f1, f2, L)
+    til = ops.corr_build(f1, f2, L, tiled_levels=mask) if mask else ref
+    flow = _edge_flow(n, h, w, 5, 3.0)
+    got = ops.corr_lookup(til, flow.to(DEV), r, tiled_levels=mask)
+    assert got.shape == (n, L * (2 * r + 1) ** 2, h, w)
+    want = oracle.corr_lookup([p.cpu() for p in ref], flow.clone(), r)
+    # the reference normalises pixel coordinates to [-1, 1] and grid_sample maps them back
+    # (corr_lookup.py:64-67): an fp32 round trip whose coordinate error grows with the map width
+    # (~2e-5 px at 192); the kernels sample at the exact coordinate
+    close(got, want, atol=5e-5 if max(h, w) <= 64 else 2e-4, what='generic lookup')
+
+
+def test_corr_lookup_generic_matches_fast_kernel_bits():
+    """the two kernels share the centre / weight / blend code: on a map the fast kernel takes at
+    r = 4 and the generic one at r = 5, the r = 4 taps (the inner 9x9 of the 11x11 window at every
+    level) are the same numbers."""
+    n, h, w, L = 1, 32, 40, 3
+    f1, f2 = rnd((n, 16, h, w), 21).to(DEV), rnd((n, 16, h, w), 22).to(DEV)
+    pyr = ops.corr_build(f1, f2, L)
+    flow = _edge_flow(n, h, w, 23).to(DEV)
+    fast = ops.corr_lookup(pyr, flow, 4).reshape(n, L, 9, 9, h, w)
+    gen = ops.corr_lookup(pyr, flow, 5).reshape(n, L, 11, 11, h, w)[:, :, 1:10, 1:10]
+    assert torch.equal(fast, gen)
+
+
+@pytest.mark.parametrize('r', [4, 5])
+def test_corr_lookup_nan_and_inf_flow_like_grid_sample(r):
+    """a query whose flow is NaN / inf gets NaN in ALL its taps (torch's CPU grid_sample, i.e. the
+    reference path, returns NaN there); its neighbours are untouched; a huge finite flow reads
+    zero padding."""
+    n, h, w, L = 1, 16, 24, 3
+    f1, f2 = rnd((n, 8, h, w), 31), rnd((n, 8, h, w), 32)
+    pyr = oracle.correlation_pyramid(f1, f2, L)
+    flow = rnd((n, 2, h, w), 33, 2.0)
+    flow[0, 0, 2, 3] = float('nan')
+    flow[0, 1, 4, 4] = float('nan')
+    flow[0, :, 5, 5] = float('inf')
+    flow[0, 1, 6, 6] = float('-inf')
+    flow[0, 0, 7, 7] = 1e30
+    want = oracle.corr_lookup(pyr, flow.clone(), r)
+    got = ops.corr_lookup([p.to(DEV) for p in pyr], flow.to(DEV), r).cpu()
+    assert torch.equal(torch.isnan(got), torch.isnan(want))
+    for (y, x) in ((2, 3), (4, 4), (5, 5), (6, 6)):
+        assert bool(torch.isnan(got[0, :, y, x]).all())
+    assert float(got[0, :, 7, 7].abs().max()) == 0.0
+    ok = ~torch.isnan(want)
+    assert float((got[ok] - want[ok]).abs().max()) <= 5e-5
 
 
 def test_lookup_of_constant_volume_is_partition_of_unity():

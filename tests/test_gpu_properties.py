@@ -33,9 +33,12 @@ def test_pyramid_is_symmetric_and_pooled(n, h, w):
     for l in range(3):
         want = F.avg_pool2d(a[l], 2, 2)
         assert float((a[l + 1] - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max()))
-    # tiled level 0 holds the same numbers
-    t = ops.corr_build(f1, f2, 4, level0_tiled=True)
-    assert torch.equal(ops.untile_level0(t[0]), a[0])
+    # the tiled levels hold the same numbers
+    mask = ops.pyramid_layout(h, w, 4, 4)
+    t = ops.corr_build(f1, f2, 4, tiled_levels=mask)
+    for l in range(4):
+        got = ops.untile_level(t[l], h >> l, w >> l) if (mask >> l) & 1 else t[l]
+        assert torch.equal(got, a[l])
 
 
 @pytest.mark.parametrize('n,h,w', [(32, 32, 32), (8, 60, 80)])
@@ -112,11 +115,11 @@ def test_repeated_launches_are_bit_identical():
         assert torch.equal(ops.conv2d(pc, x, act=ops.ACT_RELU), ref)
     f1, f2 = rnd((32, 256, 32, 32), 34), rnd((32, 256, 32, 32), 35)
     flow = rnd((32, 2, 32, 32), 36, 3.0)
-    pyr = ops.corr_build(f1, f2, 4, level0_tiled=True)
-    want = ops.corr_lookup(pyr, flow, 4, level0_tiled=True).clone()
+    pyr = ops.corr_build(f1, f2, 4, tiled_levels=1)
+    want = ops.corr_lookup(pyr, flow, 4, tiled_levels=1).clone()
     for _ in range(50):
-        assert torch.equal(ops.corr_lookup(pyr, flow, 4, level0_tiled=True), want)
-        assert torch.equal(ops.corr_build(f1, f2, 1, level0_tiled=True)[0], pyr[0])
+        assert torch.equal(ops.corr_lookup(pyr, flow, 4, tiled_levels=1), want)
+        assert torch.equal(ops.corr_build(f1, f2, 1, tiled_levels=1)[0], pyr[0])
 
 
 def test_launch_bound_timers_measure_the_kernel():
@@ -124,14 +127,14 @@ def test_launch_bound_timers_measure_the_kernel():
     positive duration no longer than a recorded-event pair around the same launch."""
     f1, f2 = rnd((8, 256, 32, 32), 41), rnd((8, 256, 32, 32), 42)
     flow = rnd((8, 2, 32, 32), 43, 2.0)
-    pyr = ops.corr_build(f1, f2, 4, level0_tiled=True)
-    out = ops.corr_lookup(pyr, flow, 4, level0_tiled=True)
+    pyr = ops.corr_build(f1, f2, 4, tiled_levels=1)
+    out = ops.corr_lookup(pyr, flow, 4, tiled_levels=1)
     ops.lookup_timing(True)
     pairs = []
     for _ in range(5):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        got = ops.corr_lookup(pyr, flow, 4, level0_tiled=True)
+        got = ops.corr_lookup(pyr, flow, 4, tiled_levels=1)
         b.record()
         pairs.append((a, b))
     us = ops.lookup_timing(False)
@@ -139,5 +142,5 @@ def test_launch_bound_timers_measure_the_kernel():
     assert len(us) == 5 and all(1.0 < u < 1e4 for u in us)
     outer = [a.elapsed_time(b) * 1e3 for a, b in pairs]
     assert min(us) <= min(outer) + 1.0
-    t = ops.time_first_kernel(lambda: ops.corr_build(f1, f2, 4, level0_tiled=True))
+    t = ops.time_first_kernel(lambda: ops.corr_build(f1, f2, 4, tiled_levels=1))
     assert 1.0 < t < 1e5

@@ -27,6 +27,7 @@ def close(got, want, atol, rtol=1e-5, what=''):
     got = got.detach().cpu()
     assert got.shape == want.shape, (what, got.shape, want.shape)
     err = (got - want).abs()
+    print(f'[measured] {what}: max abs err {float(err.max()):.3e} (atol {atol:g})')     # pytest -s / -rP shows it
     assert bool((err <= atol + rtol * want.abs()).all()), \
         f'{what}: max err {float(err.max()):.3e} > atol {atol}'
 
@@ -52,7 +53,8 @@ def test_encoder_golden(golden_dir, kind):
                                      if k.startswith(pre)}, seed=3)
     enc.load_state_dict(sd, strict=True)
     enc = enc.to(DEV).eval()
-    close(enc(g['x'].to(DEV)), g['out'], atol=1e-4, what=f'encoder {kind}')
+    # tolerances here and below: <= 3x the error measured on the MI355X (gpurun r3b), not looser
+    close(enc(g['x'].to(DEV)), g['out'], atol={'IN': 6e-5, 'BN': 2e-5}[kind], what=f'encoder {kind}')
 
 
 def test_update_block_golden(golden_dir, model):
@@ -66,11 +68,11 @@ def test_update_block_golden(golden_dir, model):
     dec = dec.to(DEV)
     corr, flow = g['corr'].to(DEV), g['flow'].to(DEV)
     motion = dec.encoder(corr, flow)
-    close(motion, g['motion'], atol=3e-5, what='motion')
+    close(motion, g['motion'], atol=8e-6, what='motion')
     h_new = dec.gru(g['h'].to(DEV), torch.cat([g['cxt'].to(DEV), motion], 1))
-    close(h_new, g['h_new'], atol=3e-5, what='gru')
-    close(dec.flow_pred(h_new.contiguous()), g['d_flow'], atol=3e-5, what='flow head')
-    close(dec.mask_pred(h_new.contiguous()), g['mask_logit'], atol=3e-5, what='mask head')
+    close(h_new, g['h_new'], atol=3e-6, what='gru')
+    close(dec.flow_pred(h_new.contiguous()), g['d_flow'], atol=2e-6, what='flow head')
+    close(dec.mask_pred(h_new.contiguous()), g['mask_logit'], atol=2e-6, what='mask head')
 
 
 def test_pose_head_golden_label_quirk(golden_dir):
@@ -82,10 +84,10 @@ def test_pose_head_golden_label_quirk(golden_dir):
     head = head.to(DEV)
     x = torch.randn((3, 224, 32, 32), generator=torch.Generator().manual_seed(int(g['x_seed'])))
     r, t = head(x.to(DEV), g['label'].to(DEV))
-    close(r, g['rot'], atol=2e-5, what='rot (mixed labels -> label[0])')
-    close(t, g['trans'], atol=2e-5, what='trans')
+    close(r, g['rot'], atol=5e-7, what='rot (mixed labels -> label[0])')
+    close(t, g['trans'], atol=5e-7, what='trans')
     r5, t5 = head(x.to(DEV), torch.tensor([5, 5, 5], device=DEV))
-    close(r5, g['rot_label5'], atol=2e-5, what='rot label 5')
+    close(r5, g['rot_label5'], atol=5e-7, what='rot label 5')
 
 
 def test_full_refiner_golden(golden_dir, model):
@@ -94,17 +96,18 @@ def test_full_refiner_golden(golden_dir, model):
     inp = {k: v.to(DEV) for k, v in scflow_amd.make_inputs(int(g['n']), 256, 256,
                                                            seed=int(g['input_seed'])).items()}
     fr, fl, hf, cf = model.extract_feat(inp['render_images'], inp['real_images'])
-    close(fr[:, ::8], g['feat_render'], atol=2e-4, what='feat_render')
-    close(fl[:, ::8], g['feat_real'], atol=2e-4, what='feat_real')
-    close(hf[:, ::8], g['h_feat'], atol=2e-4, what='h_feat')
-    close(cf[:, ::8], g['cxt_feat'], atol=2e-4, what='cxt_feat')
+    close(fr[:, ::8], g['feat_render'], atol=9e-5, what='feat_render')
+    close(fl[:, ::8], g['feat_real'], atol=9e-5, what='feat_real')
+    close(hf[:, ::8], g['h_feat'], atol=2.5e-5, what='h_feat')
+    close(cf[:, ::8], g['cxt_feat'], atol=2e-5, what='cxt_feat')
     model.decoder.iters = int(g['iters'])
     outs = model.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'],
                           inp['ref_translation'], inp['depth'], inp['internel_k'], inp['label'])
     names = ['flow_from_pose', 'flow_from_pred', 'rotation', 'translation', 'mask',
              'delta_rotation', 'delta_translation']
-    tol = dict(flow_from_pose=1e-3, flow_from_pred=2e-3, rotation=1e-5, translation=5e-3,
-               mask=2e-4, delta_rotation=2e-5, delta_translation=2e-5)
+    # measured (px, px, -, mm, -, -, -): 9.2e-5, 8.0e-5, 1.8e-7, 3.1e-4, 2.0e-6, 1.2e-7, 2.6e-7
+    tol = dict(flow_from_pose=3e-4, flow_from_pred=2.5e-4, rotation=6e-7, translation=1e-3,
+               mask=6e-6, delta_rotation=4e-7, delta_translation=8e-7)
     for nm, seq in zip(names, outs):
         assert len(seq) == int(g['iters'])
         st = torch.stack(list(seq))
@@ -135,6 +138,123 @@ def test_full_refiner_vs_oracle_epe(golden_dir, model, n, iters):
     close(got[2][-1], want[2][-1], atol=2e-5, what='final rotation')
     close(got[3][-1], want[3][-1], atol=1e-2, rtol=2e-5, what='final translation (mm)')
     assert float((got[0][-1].cpu()[:, :, ~valid[0]] if n == 1 else torch.zeros(1)).abs().max()) == 0.0
+
+
+def test_config2_full_size_vs_oracle(golden_dir, model):
+    """BASELINE configs[2] at its STATED size: 32 pairs x 8 iterations, every pair against the CPU
+    oracle (batch 32 selects other convolution tiles / K splits than the N = 1, 2 cases above).
+    Mixed labels: the whole batch is decoded with class label[0] (pose_head.py:209-210), in the
+    oracle as in the HIP path."""
+    import bench
+    n, iters = 32, 8
+    sd = scflow_amd.fill_state_dict(_shapes(golden_dir), seed=0)
+    inp = scflow_amd.make_inputs(n, 256, 256, seed=1000)            # bench.py's rank-0 batch
+    torch.set_num_threads(bench.host_cores())
+    with torch.no_grad():
+        want = oracle.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'],
+                               inp['ref_translation'], inp['depth'], inp['internel_k'],
+                               inp['label'], sd, iters=iters)
+    model.decoder.iters = iters
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    got = model.get_pose(d['render_images'], d['real_images'], d['ref_rotation'],
+                         d['ref_translation'], d['depth'], d['internel_k'], d['label'])
+    valid = inp['depth'] > 0
+    worst = 0.0
+    for it in range(iters):
+        for s_ in range(n):             # per pair, not a batch average
+            epe_pose = oracle.end_point_error(got[0][it][s_:s_ + 1].cpu(), want[0][it][s_:s_ + 1], valid[s_:s_ + 1])
+            epe_pred = oracle.end_point_error(got[1][it][s_:s_ + 1].cpu(), want[1][it][s_:s_ + 1])
+            worst = max(worst, epe_pose, epe_pred)
+            assert epe_pose <= 1e-3 and epe_pred <= 1e-3, f'iter {it} pair {s_}: EPE {epe_pose:.2e} / {epe_pred:.2e}'
+    print(f'[measured] configs[2] worst per-pair EPE over {iters} iterations: {worst:.2e} px')
+    close(got[2][-1], want[2][-1], atol=2e-5, what='final rotation, 32 pairs')
+    close(got[3][-1], want[3][-1], atol=1e-2, rtol=2e-5, what='final translation (mm), 32 pairs')
+    close(got[4][-1], want[4][-1], atol=2e-4, what='final mask, 32 pairs')
+
+
+def test_checkpoint_file_to_hip_refiner_vs_oracle(golden_dir, tmp_path):
+    """SURVEY 8(f2) end to end on the GPU: an mmcv-layout FILE holding an mmflow RAFT checkpoint
+    (ONE `encoder.*`, DDP `module.` prefix, 576-channel convex-up-sampling `mask_pred` head, no pose
+    head / delta-flow / mask encoders: what configs/refine_models/scflow.py:109-112 initialises from,
+    converted by tools/mmflow_ckpt_converter.py:30-35) -> load_checkpoint(from_mmflow=True) -> HIP
+    refiner -> same outputs as the oracle run on the dict the loader is specified to produce."""
+    from scflow_amd.checkpoint import load_checkpoint
+    enc = dict(type='RAFTEncoder', in_channels=3, out_channels=256, net_type='Basic')
+    raft = scflow_amd.build_refiner(dict(
+        type='RAFTRefinerFlow', cxt_channels=128, h_channels=128, seperate_encoder=False,
+        encoder=dict(enc, norm_cfg=dict(type='IN')), cxt_encoder=dict(enc, norm_cfg=dict(type='BN')),
+        decoder=dict(type='RAFTDecoder', net_type='Basic', num_levels=4, radius=4, iters=12,
+                     corr_lookup_cfg=dict(align_corners=True), gru_type='SeqConv',
+                     act_cfg=dict(type='ReLU'))))
+    raft_sd = scflow_amd.fill_state_dict({k: v.shape for k, v in raft.state_dict().items()}, seed=17)
+    assert raft_sd['decoder.mask_pred.predict_layer.weight'].shape[0] == 576
+    mm = {'module.' + k.replace('render_encoder', 'encoder'): v for k, v in raft_sd.items()
+          if not k.startswith('real_encoder.')}
+    path = os.path.join(tmp_path, 'raft_mmflow.pth')
+    torch.save({'state_dict': mm, 'meta': {'note': 'synthetic'}, 'optimizer': {}}, path)
+
+    m = scflow_amd.build_refiner(scflow_amd.scflow_model_cfg(iters=4))
+    base = scflow_amd.fill_state_dict(_shapes(golden_dir), seed=23)       # what the model holds before
+    m.load_state_dict(base, strict=True)
+    m = m.to(DEV)
+    inp = scflow_amd.make_inputs(2, 256, 256, seed=29)
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    run = lambda: m.get_pose(d['render_images'], d['real_images'], d['ref_rotation'], d['ref_translation'],
+                             d['depth'], d['internel_k'], d['label'])
+    before = run()[0][-1].clone()           # also builds the kernel-layout weights that must be dropped
+    missing, unexpected, mismatched = load_checkpoint(m, path, from_mmflow=True)
+    assert not unexpected
+    assert sorted(k for k, _, _ in mismatched) == ['decoder.mask_pred.predict_layer.bias',
+                                                   'decoder.mask_pred.predict_layer.weight']
+    own_only = ('decoder.pose_pred.', 'decoder.delta_flow_encoder.', 'decoder.mask_encoder.',
+                'decoder.mask_pred.predict_layer.')
+    assert missing and all(k.startswith(own_only) for k in missing)
+    # the dict the loader is specified to leave in the model: checkpoint tensors where key and shape
+    # match (encoder.* under both names), the previous tensors everywhere else
+    want_sd = dict(base)
+    skipped = {k for k, _, _ in mismatched}
+    for k, v in raft_sd.items():
+        if k in want_sd and k not in skipped:
+            want_sd[k] = v
+    for k in want_sd:
+        if k.startswith('real_encoder.'):
+            want_sd[k] = want_sd[k.replace('real_encoder.', 'render_encoder.')]
+    for k, v in m.state_dict().items():
+        assert torch.equal(v.cpu(), want_sd[k]), k
+    got = run()
+    assert not torch.equal(got[0][-1], before)
+    with torch.no_grad():
+        want = oracle.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'],
+                               inp['ref_translation'], inp['depth'], inp['internel_k'],
+                               inp['label'], want_sd, iters=4)
+    valid = inp['depth'] > 0
+    for it in range(4):
+        assert oracle.end_point_error(got[0][it].cpu(), want[0][it], valid) <= 1e-3
+        assert oracle.end_point_error(got[1][it].cpu(), want[1][it]) <= 1e-3
+    close(got[2][-1], want[2][-1], atol=2e-5, what='rotation after checkpoint ingestion')
+    close(got[3][-1], want[3][-1], atol=1e-2, rtol=2e-5, what='translation after checkpoint ingestion')
+
+
+def test_non_contiguous_images_at_batch_1(golden_dir, model):
+    """ADVICE r2: at small batches the context encoder runs on a side stream from a fork point;
+    a non-contiguous render_images must be materialised BEFORE that point.  Same bits as the
+    contiguous call, run after run."""
+    inp = {k: v.to(DEV) for k, v in scflow_amd.make_inputs(1, 256, 256, seed=31).items()}
+    model.decoder.iters = 2
+    args = (inp['ref_rotation'], inp['ref_translation'], inp['depth'], inp['internel_k'], inp['label'])
+    want = model.get_pose(inp['render_images'], inp['real_images'], *args)
+    nhwc_r = inp['render_images'].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)      # NCHW view of NHWC memory
+    wide = torch.zeros((1, 3, 256, 300), device=DEV)
+    wide[..., 7:263] = inp['real_images']
+    strided_real = wide[..., 7:263]                                                        # row stride 300
+    assert not nhwc_r.is_contiguous() and not strided_real.is_contiguous()
+    for rep in range(6):
+        got = model.get_pose(nhwc_r, strided_real, *args)
+        torch.cuda.synchronize()
+        for ws, gs in zip(want, got):
+            for wt, gt in zip(ws, gs):
+                assert torch.equal(wt, gt), f'run {rep}'
+    model.decoder.iters = 8
 
 
 def test_forward_single_pass_api(golden_dir, model):
@@ -239,8 +359,9 @@ def test_decoder_forward_does_not_mutate_its_inputs(golden_dir, model):
 
 
 def test_repacks_after_in_place_weight_change(golden_dir):
-    """kernel-layout weights must follow every way a parameter can change, including
-    param.data.copy_ and a PARENT's load_state_dict (mmcv's load_checkpoint route)."""
+    """kernel-layout weights follow a PARENT's load_state_dict (mmcv's load_checkpoint
+    route) and in-place edits of a parameter; an edit through ``param.data`` (invisible to the
+    version key) needs ``invalidate_packed()``."""
     m = scflow_amd.build_refiner(scflow_amd.scflow_model_cfg(iters=1))
     sd = scflow_amd.fill_state_dict(_shapes(golden_dir), seed=0)
     m.load_state_dict(sd, strict=True)
@@ -262,8 +383,13 @@ def test_repacks_after_in_place_weight_change(golden_dir):
     assert torch.equal(b, want)
     with torch.no_grad():                                # direct in-place edit of one parameter
         m.decoder.flow_pred.predict_layer.weight.mul_(0.5)
-    c = run()[1][-1]
+    c = run()[1][-1].clone()
     assert not torch.equal(b, c)
+    w = m.decoder.flow_pred.predict_layer.weight
+    w.data.copy_(w.data * 3.0)                          # .data: the parameter's _version does not move
+    m.invalidate_packed()
+    e = run()[1][-1]
+    assert not torch.equal(c, e)
 
 
 def test_get_pose_is_deterministic_and_hoisting_is_equivalent(golden_dir, model):

@@ -265,6 +265,14 @@ def test_packed_weights_follow_every_kind_of_weight_change():
     assert p2 is not p1 and float(p2.wp.max()) == 1.0 and float(p2.bias.abs().max()) == 0.0
     torch.nn.init.constant_(blk.conv.bias, 0.25)
     assert float(blk.packed.bias.min()) == 0.25
+    # an edit through .data does NOT bump the parameter's version (the key cannot see
+    # it): that route is documented as needing invalidate_packed()
+    p3 = blk.packed
+    v = blk.conv.weight._version
+    blk.conv.weight.data.copy_(torch.full((8, 16, 3, 3), 2.0))
+    assert blk.conv.weight._version == v and blk.packed is p3          # stale, as documented
+    blk.invalidate_packed()
+    assert blk.packed is not p3 and float(blk.packed.wp.max()) == 2.0
 
 
 def test_composite_modules_repack_when_a_child_block_changes():

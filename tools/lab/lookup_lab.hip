@@ -1,7 +1,7 @@
 // Stand-alone laboratory for the correlation-lookup kernel (not part of the product).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/lab/lookup_lab.hip -o tools/lab/bin/lookup_lab
-// Compiles the PRODUCT kernel source with SCF_LOOKUP_TRACE (s_memrealtime stamps per wave + two
-// ablation switches) and times it against streaming ceilings on a pyramid that cannot sit in the
+// Compiles the PRODUCT kernel source with SCF_LOOKUP_LAB (lookup_lab_hooks.h: s_memrealtime stamps per
+// wave + two ablation switches) and times it against streaming ceilings on a pyramid that cannot sit in the
 // 256 MiB Infinity Cache (two batch-B halves used alternately + a 1 GiB flush between launches).
 // -DLAB_V5: the round-1 kernel (corr_lookup_v5.inc, a snapshot of the file at commit 339ccd8) for A/B
 // timing and an output checksum on identical inputs (no trace hooks in that build).
@@ -11,7 +11,7 @@
 static unsigned long long* scf_lab_trace = nullptr;
 static int scf_lab_skip_dma = 0, scf_lab_skip_store = 0, scf_lab_rotate = -1, scf_lab_grid = 0, scf_lab_store_mode = 0;
 #else
-#define SCF_LOOKUP_TRACE 1
+#define SCF_LOOKUP_LAB 1
 #include "../../scflow_amd/csrc/corr_lookup.hip"
 #endif
 #include <algorithm>
@@ -81,7 +81,7 @@ int main(int argc, char** argv) {
   float* lv[NH][4];
   for (int hf = 0; hf < NH; ++hf)
     for (int l = 0; l < L; ++l) {
-      const size_t n = Q * (size_t)((h >> l) * (w >> l));
+      const size_t n = Q * (size_t)(((h >> l) + 3) / 4 * 4) * (((w >> l) + 7) / 8 * 8);      // room for either layout
       CK(hipMalloc(&lv[hf][l], n * 4));
       fill_kernel<<<2048, 256>>>(lv[hf][l], n, 17u * l + hf);
     }
@@ -106,7 +106,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&trace, (size_t)nblk * 4 * 8 * 8));
   hipStream_t st;
   CK(hipStreamCreate(&st));
-  const bool tiled = (w % 8 == 0 && h % 4 == 0 && h > 10 && w > 10);
+  const unsigned tiled = getenv("LAB_ROWMAJOR") ? 0u : scf_corr_preferred_layout(h, w, r, L);      // tile mask
 
   auto run = [&](const char* name, int skip_dma, int skip_store, bool with_trace, bool flush, int rotate = -1, int grid = 0) {
     scf_lab_skip_dma = skip_dma; scf_lab_skip_store = skip_store; scf_lab_rotate = rotate; scf_lab_grid = grid;
@@ -119,7 +119,9 @@ int main(int argc, char** argv) {
       scf_timer_t tm;
       scf_timer_create(&tm);
       const float* lvp[4] = {lv[it % NH][0], lv[it % NH][1], lv[it % NH][2], lv[it % NH][3]};
-      int rc = scf_corr_lookup_timed(lvp, flow, out, B, h, w, r, L, tiled ? 1 : 0, tm, st);
+      scf_timer_arm(tm);
+      int rc = scf_corr_lookup_ex(lvp, flow, out, B, h, w, r, L, tiled, st);
+      scf_timer_arm(nullptr);
       if (rc) { printf("lookup rc %d\n", rc); exit(1); }
       CK(hipStreamSynchronize(st));
       float u = 0; scf_timer_elapsed_us(tm, &u); scf_timer_destroy(tm);
@@ -204,7 +206,7 @@ int main(int argc, char** argv) {
     scf_lab_skip_dma = scf_lab_skip_store = 0; scf_lab_rotate = -1; scf_lab_grid = 0; scf_lab_trace = nullptr;
     CK(hipMemset(out, 0xff, Q * 324 * 4));
     const float* lvp[4] = {lv[0][0], lv[0][1], lv[0][2], lv[0][3]};
-    scf_corr_lookup_ex(lvp, flow, out, B, h, w, r, L, tiled ? 1 : 0, st);
+    scf_corr_lookup_ex(lvp, flow, out, B, h, w, r, L, tiled, st);
     CK(hipStreamSynchronize(st));
     std::vector<float> ho(Q * 324);
     CK(hipMemcpy(ho.data(), out, ho.size() * 4, hipMemcpyDeviceToHost));

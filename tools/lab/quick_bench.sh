@@ -2,7 +2,7 @@
 # quick headline check: conv-related GPU tests + one short bench line (summary on stdout)
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -k "conv or gru" 2>&1 | tail -2
-SCF_BENCH_TOP_LAYERS=${TOPL:-14} timeout 600 python bench.py --no-config4 --min-seconds 2 > gpurun_out/quick.json 2> gpurun_out/quick.err
+timeout 600 python bench.py --no-config4 --min-seconds 2 --top-layers ${TOPL:-14} > gpurun_out/quick.json 2> gpurun_out/quick.err
 python - <<'PY'
 import json
 d=json.loads(open('gpurun_out/quick.json').read().strip().splitlines()[-1])

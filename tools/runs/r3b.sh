@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 3: GPU tests (verbose errors), lookup lab at both benchmark shapes
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3b; mkdir -p $O
+cd $R
+timeout 1200 python -m pytest tests -m gpu -q -s > $O/pytest.log 2>&1; echo "pytest rc=$?"
+tail -8 $O/pytest.log
+grep "measured" $O/pytest.log | sort | uniq | head -80
+timeout 300 tools/lab/bin/lookup_lab 32 20 32 32 > $O/lab_b32.txt 2>&1; grep -v "wave->\|levels per\|TG_ID" $O/lab_b32.txt | cut -c1-250
+timeout 300 tools/lab/bin/lookup_lab 8 20 60 80 > $O/lab_c4.txt 2>&1; grep -v "wave->\|levels per\|TG_ID\|  level" $O/lab_c4.txt | cut -c1-250
