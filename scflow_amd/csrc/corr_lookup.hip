@@ -92,19 +92,30 @@ __device__ __forceinline__ const void* lk_sgpr_ptr(const void* p) {
   return (const void*)(((unsigned long long)hi << 32) | lo);
 }
 
-// One half of a query's footprint: voff = byte offset inside the query's map, or >= 0x20000 when
-// the tap is outside the map (a 0x8000 table entry): those lanes stay off.  Everything that
-// touches EXEC / M0 sits in one statement; the compiler does not count these loads (the caller
-// waits on vmcnt itself).
-__device__ __forceinline__ void lk_dma_tap(const void* sbase, unsigned voff, unsigned lds,
-                                           unsigned long long live) {
-  asm volatile("v_cmp_gt_u32_e32 vcc, 0x20000, %1\n\t"
-               "s_and_b64 exec, vcc, %3\n\t"
-               "s_mov_b32 m0, %2\n\t"
+// Footprint gather through a raw buffer descriptor (base = ONE query's map, num_records = its size
+// in bytes, at most 128 KB): `buffer_load_dword voff, rsrc, 0 offen lds` moves one dword per lane
+// from base + voff to LDS byte M0 + 4 * lane, and a lane whose offset is past num_records gets ZERO
+// written to its cell (checked on gfx950: tools/lab/buf_lds_test.hip).  Taps outside the map carry
+// an offset >= 0x20000 (a 0x8000 table entry), so zero padding needs no EXEC mask per instruction
+// and no pre-zeroed staging; stepping to the next query is two scalar adds on the descriptor.  The whole gather phase runs under ONE divergent branch
+// (the footprint's FS elements are split into equal shares of LPS <= 64 lanes; lanes >= LPS sit it out).  The compiler does not
+// count these loads: the caller waits on vmcnt itself.
+typedef int lk_rsrc_t __attribute__((ext_vector_type(4)));
+#define LK_OOB 0x8000u        // table marker (floats): (row + column) << 2 >= 0x20000 > any num_records
+__device__ __forceinline__ lk_rsrc_t lk_make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  lk_rsrc_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu));   // stride 0: raw buffer
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);                             // num_records (bytes)
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void lk_dma_tap(lk_rsrc_t rsrc, unsigned voff, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %2\n\t"
                "s_nop 0\n\t"
-               "global_load_lds_dword %1, %0 nt\n\t"
-               "s_mov_b64 exec, -1"
-               : : "s"(sbase), "v"(voff), "s"(lds), "s"(live) : "memory", "vcc", "scc");   // s_and writes SCC
+               "buffer_load_dword %1, %0, 0 offen lds"
+               : : "s"(rsrc), "v"(voff), "s"(lds) : "memory");
 }
 // contiguous variant with an explicit lane mask (whole small maps)
 __device__ __forceinline__ void lk_dma_mask(const void* sbase, unsigned voff, unsigned lds,
@@ -236,9 +247,10 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
   constexpr int D = 2 * R + 1;        // window width
   constexpr int QB = 32;              // queries per group
   constexpr int NSET = (FS + 63) / 64;  // DMA instructions per query footprint
+  constexpr int LPS = FS / NSET;      // lanes per DMA instruction (equal shares: 50 + 50 at r = 4)
+  static_assert(LPS * NSET == FS && LPS <= 64, "the footprint splits into equal lane shares");
   constexpr int TQ = 2 * FW;          // table entries (u16) per query: FW row + FW column offsets
   extern __shared__ __attribute__((aligned(16))) float lds_fp[];
-  typedef float __attribute__((ext_vector_type(4))) f4;
 
   const bool skip_dma = LK_SKIP_DMA, skip_store = LK_SKIP_STORE;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -253,14 +265,11 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
   const lds_u16p_t tbl = (lds_u16p_t)(myfp + QB * FSP);   // [QB][TQ]
   lds_cu16p_t trow[NSET];
   lds_cu16p_t tcol[NSET];
-  unsigned long long live[NSET];
 #pragma unroll
   for (int s = 0; s < NSET; ++s) {
-    const int e = lane + 64 * s;
-    const int er = e < FS ? e / FW : 0, ec = e < FS ? e - (e / FW) * FW : 0;
-    trow[s] = tbl + er;
-    tcol[s] = tbl + FW + ec;
-    live[s] = __ballot(e < FS);
+    const int e = (lane < LPS ? lane : 0) + LPS * s;      // lanes >= LPS are switched off in the gather phase
+    trow[s] = tbl + e / FW;
+    tcol[s] = tbl + FW + (e - (e / FW) * FW);
   }
 
   // query indices fit 31 bits (the launcher refuses more): 32-bit divisions only
@@ -315,13 +324,7 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
       // EVERY tap lands exactly on index 0 (corr_lookup.py:64-67).
       const bool flat_x = lw == 1, flat_y = lh == 1;
       const bool small = !tiled && (lh <= FW && lw <= FW);
-      // the staging area is cleared BEFORE the first use of the flow (whose load is still in flight)
-      if (small) {
-        if (lane < lw) (myfp + QB * (msz | 1))[lane] = 0.f;            // the shared zero row
-      } else {
-        for (int i = lane; i < QB * FSP / 4; i += 64)
-          ((__attribute__((address_space(3))) f4*)myfp)[i] = f4{0.f, 0.f, 0.f, 0.f};
-      }
+      if (small && lane < lw) (myfp + QB * (msz | 1))[lane] = 0.f;       // the shared zero row
       const float inv = 1.0f / (float)(1 << lvl);
       const LkCentre c = lk_centre<R>(xf + fx, yf + fy, inv, flat_x, flat_y);   // first use of the flow
       const int x0 = c.x0, y0 = c.y0;
@@ -353,11 +356,11 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
           rowp[r] = (unsigned)yy < (unsigned)lh ? f + yy * lw : (lds_cfp_t)zrow;
         }
       } else {
-        // ---- zero-padded footprints, stride FSP; two DMA instructions per query ----
+        // ---- zero-padded footprints, stride FSP; NSET DMA instructions per query ----
         // offset tables: half-wave 0 writes this query's FW row offsets, half-wave 1 its FW column
-        // offsets (in floats, inside the query's map; 0x8000 = outside).  The map layout lives
-        // here and nowhere else: row-major, or 8x4-float tiles of 128 B (rows / columns past the
-        // map's real size -- tile padding -- count as outside like everything else past it).
+        // offsets (in floats, inside the query's map; LK_OOB = outside).  The map layout lives here
+        // and nowhere else: row-major, or 8x4-float tiles of 128 B (rows / columns past the map's
+        // real size -- tile padding -- count as outside like everything else past it).
         {
           const int c0 = half ? x0 : y0, lim = half ? lw : lh;
           const bool flat = half ? flat_x : flat_y;
@@ -373,15 +376,18 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
               const bool ok = qvalid && (unsigned)v < (unsigned)lim;
               // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): |v| <= 30010, factors < 2^15
               const int val = tiled ? __mul24(v >> sh, mula) + __mul24(v & msk, mulb) : __mul24(v, mulb);
-              pr |= (ok ? (unsigned)val : 0x8000u) << (16 * jj);
+              pr |= (ok ? (unsigned)val : LK_OOB) << (16 * jj);
             }
             *(__attribute__((address_space(3))) unsigned*)(tq + j) = pr;
           }
         }
-        __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): zeros and tables are in LDS
+        const unsigned mbytes = (unsigned)msz * 4u;
+        __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): the tables are in LDS
         __builtin_amdgcn_wave_barrier();
         LK_TRACE(2);
-        if (!skip_dma) {
+        // ONE exec setup for the whole phase: an ordinary divergent branch (the compiler owns EXEC,
+        // nothing it schedules into the region runs with the wrong lanes)
+        if (!skip_dma && (LPS == 64 || lane < LPS)) {
           constexpr int QBATCH = 4;                      // table reads of a batch issue together
 #pragma unroll
           for (int qb = 0; qb < QB; qb += QBATCH) {
@@ -396,12 +402,10 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
 #pragma unroll
             for (int qi = 0; qi < QBATCH; ++qi) {
               const int qq = qb + qi;
-              const char* mb = lbase + (size_t)qq * msz * 4;
+              const lk_rsrc_t rsrc = lk_make_rsrc(lbase + (size_t)qq * mbytes, mbytes);
 #pragma unroll
-              for (int s = 0; s < NSET; ++s) {
-                const unsigned voff = (tr_[qi][s] + tc_[qi][s]) << 2;
-                lk_dma_tap(mb, voff, st0 + (unsigned)(qq * FSP + 64 * s) * 4u, live[s]);
-              }
+              for (int s = 0; s < NSET; ++s)
+                lk_dma_tap(rsrc, (tr_[qi][s] + tc_[qi][s]) << 2, st0 + (unsigned)(qq * FSP + LPS * s) * 4u);
             }
           }
         }
@@ -512,7 +516,7 @@ static int lookup_launch(const float* const* levels, const float* flow, float* o
     if (msz > 0x7fffffffLL) return SCF_EUNSUPPORTED;
     p.msz[l] = (int)msz;
     p.pw4[l] = tiled ? ((lw + 7) / 8 * 8) * 4 : 0;
-    if (msz > 32767) fast = false;                       // u16 offset tables (floats inside one map)
+    if (msz > 32767) fast = false;                       // u16 offset tables; one map = one descriptor of < 128 KB
   }
   for (int l = L; l < SCF_MAX_LEVELS; ++l) { p.lvl[l] = nullptr; p.lh[l] = p.lw[l] = p.pw4[l] = p.msz[l] = 0; }
   p.flow = flow;
