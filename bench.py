@@ -67,6 +67,13 @@ def parse_args(argv=None):
     ap.add_argument('--no-config4', action='store_true')
     ap.add_argument('--top-layers', type=int, default=14,
                     help='convolution layers listed in roofline_conv.top_layers')
+    ap.add_argument('--share-device', action='store_true',
+                    help='N ranks on ONE GPU (every rank uses cuda:0, collectives over gloo): exercises the '
+                         'multi-process path -- self-launch, concurrent library load, barriers, max-over-ranks '
+                         'timing, pose gather with device tensors -- where only one GPU is reachable.  The '
+                         'line is marked "share_device": true and is NOT a scaling measurement')
+    ap.add_argument('--dump-poses', default=None,
+                    help='rank 0 writes the gathered final poses of one extra step (torch.save) here')
     ap.add_argument('--standin', action='store_true',
                     help='launcher self-test (tests/test_bench_launcher.py): the step is a CPU '
                          'stand-in, backend gloo; the line is marked "standin": true and is not a '
@@ -87,7 +94,7 @@ def maybe_self_launch(args) -> None:
     ``tools/dist_test.sh`` -> ``torch.distributed.launch`` -> test.py:100-127."""
     if args.gpus <= 1 or 'WORLD_SIZE' in os.environ:
         return
-    if not args.standin:
+    if not args.standin and not args.share_device:
         import torch
         have = torch.cuda.device_count()
         if have < args.gpus:
@@ -237,6 +244,7 @@ def config4_block(device: str, reps_min_s: float = 2.0):
         m.get_flow(rend, real)
     torch.cuda.synchronize()
     ops.lookup_timing(True, reserve=iters * 64)
+    ops.corr_build_timing(True, reserve=64)
     t0 = time.perf_counter()
     done = 0
     while done < 3 or time.perf_counter() - t0 < reps_min_s:
@@ -247,19 +255,12 @@ def config4_block(device: str, reps_min_s: float = 2.0):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     lk = ops.lookup_timing(False)
+    cbs = ops.corr_build_timing(False)
     q = n * h * w
     lk_us = sum(lk) / len(lk)
     gbs = LOOKUP_BYTES_PER_QUERY * q / lk_us / 1e3
-    # correlation build alone at hw = 4800 (level-0 contraction, launch-bound timer)
-    fa = torch.randn((n, 256, h, w), device=device)
-    fb = torch.randn((n, 256, h, w), device=device)
-    lv0 = [torch.empty((n * h * w, 1, h, w), device=device)]
-    tiled = ops.pyramid_layout(h, w, 4, 1)
-    for _ in range(2):
-        ops.corr_build(fa, fb, 1, out=lv0, tiled_levels=tiled)
-    cb = [ops.time_first_kernel(lambda: ops.corr_build(fa, fb, 1, out=lv0, tiled_levels=tiled))
-          for _ in range(5)]
-    cb_us = sum(cb) / len(cb)
+    # the correlation GEMM of the step at hw = 4800 (fused first pool; launch-bound timers)
+    cb_us = sum(cbs) / len(cbs)
     cb_fl = 2.0 * 256 * (h * w) ** 2 * n
     pyr_mib = sum(n * h * w * (h >> l) * (w >> l) * 4 for l in range(4)) / 2 ** 20
     return {
@@ -275,7 +276,9 @@ def config4_block(device: str, reps_min_s: float = 2.0):
         'roofline_corr_build': {'bound': 'mfma', 'achieved': round(cb_fl / cb_us / 1e6, 1),
                                 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                 'frac': round(cb_fl / cb_us / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
-                                'avg_launch_us': round(cb_us, 1), 'hw': h * w},
+                                'avg_launch_us': round(cb_us, 1), 'launches_timed': len(cbs), 'hw': h * w,
+                                'kernel': 'corr_gemm_kernel<true, true> inside the step'},
+        'pyramid_tiles': f'{ops.pyramid_layout(h, w, 4, 4):04b}',
     }
 
 
@@ -288,8 +291,10 @@ def main():
     import torch.distributed as dist
     from scflow_amd.dist import gather_poses, init_from_env
 
-    if args.standin:
-        os.environ.setdefault('SCF_DIST_BACKEND', 'gloo')
+    if args.standin or args.share_device:
+        os.environ.setdefault('SCF_DIST_BACKEND', 'gloo')      # RCCL cannot put two ranks on one device
+    if args.share_device:
+        os.environ['LOCAL_RANK'] = '0'                          # every rank drives cuda:0
     rank, world, local = init_from_env()
     if world != args.gpus:
         if rank == 0:
@@ -305,7 +310,7 @@ def main():
         from scflow_amd import ops
         ops.set_conv_precision(args.precision)
         ndev = torch.cuda.device_count()
-        if ndev < 1 or (world > 1 and ndev < world):
+        if ndev < 1 or (world > 1 and ndev < world and not args.share_device):
             print(f'[bench] rank {rank}: {ndev} GPU(s) visible for {world} ranks', file=sys.stderr)
             sys.exit(2)
         dev_index = local            # one process per GPU (torchrun LOCAL_RANK)
@@ -319,8 +324,9 @@ def main():
     if world > 1:
         dist.all_gather_object(rank_map, {'rank': rank, 'local_rank': local, 'device': device,
                                           'name': dev_name, 'pid': os.getpid()})
-        one = torch.ones(1, device=device)
-        parts = [torch.zeros(1, device=device) for _ in range(world)]
+        cdev = 'cpu' if dist.get_backend() == 'gloo' else device
+        one = torch.ones(1, device=cdev)
+        parts = [torch.zeros(1, device=cdev) for _ in range(world)]
         dist.all_gather(parts, one)
         coll_world = int(sum(float(p.item()) for p in parts))
     else:
@@ -362,12 +368,14 @@ def main():
 
     def allmax(x: float) -> float:
         if world > 1:
-            t = torch.tensor([x], device=device, dtype=torch.float64)
+            t = torch.tensor([x], device='cpu' if dist.get_backend() == 'gloo' else device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
         return x
 
-    def timed(precision):
+    corr_us = []      # correlation GEMM launches of the timed steps (the kernel the step runs)
+
+    def timed(precision, corr_out=None):
         """-> (block seconds list, lookup launch durations in us, warm-up steps done)"""
         lookups = []
         if standin:
@@ -377,14 +385,25 @@ def main():
             return blocks, lookups, wdone
         ops.set_conv_precision(precision)
         ops.lookup_timing(True, reserve=args.steps * args.iters)   # timers created BEFORE the loop
+        ops.corr_build_timing(True, reserve=args.steps)
         bt = BlockTimer(step, fence, allmax, args.steps, args.warmup, args.min_seconds,
                         args.min_warmup_seconds)
-        blocks, wdone = bt.run(before_block=ops.lookup_timing_reset,
-                               after_block=lambda: lookups.extend(ops.lookup_timing_read()))
+
+        def before():
+            ops.lookup_timing_reset()
+            ops.corr_build_timing_reset()
+
+        def after():
+            lookups.extend(ops.lookup_timing_read())
+            if corr_out is not None:
+                corr_out.extend(ops.corr_build_timing_read())
+
+        blocks, wdone = bt.run(before_block=before, after_block=after)
         ops.lookup_timing(False)
+        ops.corr_build_timing(False)
         return blocks, lookups, wdone
 
-    blocks, lookup_us, warm_done = timed(args.precision)
+    blocks, lookup_us, warm_done = timed(args.precision, corr_us)
     dt = _median(blocks)
 
     result = None
@@ -454,6 +473,17 @@ def main():
         if standin:
             result['standin'] = True
             result['metric'] = 'LAUNCHER SELF-TEST (CPU stand-in step, not a measurement)'
+        if args.share_device:
+            result['share_device'] = True
+            result['scaling'] = 'none (ranks share one GPU)'
+            result['config']['parallelism'] = (f'batch-split x{world} over ONE shared GPU (gloo): a functional run '
+                                               'of the multi-process path, NOT a scaling measurement')
+    if args.dump_poses:
+        rot, trans = step()
+        sync()
+        if rank == 0:
+            torch.save({'rotation': rot.cpu(), 'translation': trans.cpu(), 'world': world,
+                        'batch_per_rank': args.batch, 'seeds': [1000 + r for r in range(world)]}, args.dump_poses)
     if rank == 0 and not standin:
         pmc = {}
         pmc_path = os.path.join(ROOT, 'profiles', 'lookup_pmc.json')
@@ -482,16 +512,26 @@ def main():
                 f"the committed kernel trace of this command averages {rk['avg_us']} us = "
                 f"{LOOKUP_BYTES_PER_QUERY * q / rk['avg_us'] / 1e3 / HBM_PEAK_GBS:.3f} of peak")
         cb_fl = 2.0 * 256 * 1024 * 1024 * args.batch
-        if cb_us:
+        if corr_us:
+            in_us = sum(corr_us) / len(corr_us)
             result['roofline_corr_build'] = {
-                'kernel': 'correlation build, level 0 (fmap1 . fmap2^T / sqrt(C), 8x4-tiled store)',
+                'kernel': 'corr_gemm_kernel<true, true>: fmap1 . fmap2^T / sqrt(C), 8x4-tiled level-0 store, '
+                          'first 2x2 pool fused -- the launch the step runs',
                 'bound': 'mfma',
-                'achieved': round(cb_fl / (cb_us * 1e-6) / 1e12, 1), 'peak': MFMA_F32_PEAK_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(cb_fl / (cb_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                'avg_launch_us': round(cb_us, 1), 'launches_timed': len(cb_ev),
+                'achieved': round(cb_fl / (in_us * 1e-6) / 1e12, 1), 'peak': MFMA_F32_PEAK_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(cb_fl / (in_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                'avg_launch_us': round(in_us, 1), 'launches_timed': len(corr_us),
+                'median_launch_us': round(_median(corr_us), 1),
                 'algorithmic_flops_per_launch': cb_fl,
-                'note': f'2*C*(h*w)^2 flops per pair, C=256, h=w=32, {args.batch} pairs; the launch also '
-                        'writes the 4*(h*w)^2 B volume per pair'}
+                'note': f'2*C*(h*w)^2 flops per pair, C=256, h=w=32, {args.batch} pairs; HIP start/stop events '
+                        'bound to the GEMM launch of every timed step (one per step); the launch also writes '
+                        'the 4*(h*w)^2 B volume and its first pooled level per pair'}
+            if cb_us:      # the same contraction alone (no pool), launched back to back on a warm cache
+                result['roofline_corr_build']['standalone_level0_only'] = {
+                    'kernel': 'corr_gemm_kernel<true, false>', 'avg_launch_us': round(cb_us, 1),
+                    'launches_timed': len(cb_ev),
+                    'achieved': round(cb_fl / (cb_us * 1e-6) / 1e12, 1),
+                    'frac': round(cb_fl / (cb_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
         if conv_launches:
             c_us = sum(e[0] for e in conv_launches)
             c_fl = sum(e[1] for e in conv_launches)

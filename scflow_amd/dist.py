@@ -53,19 +53,23 @@ def gather_poses(rotation: torch.Tensor, translation: torch.Tensor, total: Optio
         return rotation, translation
     world = dist.get_world_size()
     n_r = rotation.shape[0]
+    dev = rotation.device
+    # gloo gathers host tensors only (RCCL/"nccl" takes device tensors): stage through the host there
+    cdev = torch.device('cpu') if dist.get_backend() == 'gloo' else dev
     if total is None:
-        cnt = torch.tensor([n_r], device=rotation.device, dtype=torch.int64)
+        cnt = torch.tensor([n_r], device=cdev, dtype=torch.int64)
         dist.all_reduce(cnt)
         total = int(cnt.item())
     per = (total + world - 1) // world
-    packed = torch.zeros((per, 12), dtype=torch.float32, device=rotation.device)
+    packed = torch.zeros((per, 12), dtype=torch.float32, device=dev)
     packed[:n_r, :9] = rotation.reshape(n_r, 9)
     packed[:n_r, 9:] = translation
+    packed = packed.to(cdev)
     parts = [torch.empty_like(packed) for _ in range(world)]
     dist.all_gather(parts, packed)
     rows = []
     for r in range(world):
         lo, hi = shard_range(total, r, world)
         rows.append(parts[r][:hi - lo])
-    allp = torch.cat(rows, 0)
+    allp = torch.cat(rows, 0).to(dev)
     return allp[:, :9].reshape(-1, 3, 3), allp[:, 9:]

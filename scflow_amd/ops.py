@@ -555,8 +555,16 @@ def corr_build(feat1: Tensor, feat2: Tensor, num_levels: int = 4,
         if tuple(t.shape) != sh:
             raise _lib.ScflowHipError(f'pyramid level {l} has shape {tuple(t.shape)}, expected {sh}')
     arr = (C.c_void_p * num_levels)(*[_dense(t, 'level') for t in out])
-    _lib.check(_lib.load().scf_corr_build_ex(p1, p2, arr, n, c, h, w, num_levels, int(tiled_levels),
-                                             _stream()), 'scf_corr_build')
+    lib = _lib.load()
+    timed = _CORR_TIMERS is not None      # bench.py: a timer bound to the FIRST launch = the contraction
+    if timed:
+        lib.scf_timer_arm(_CORR_TIMERS.take())
+    try:
+        _lib.check(lib.scf_corr_build_ex(p1, p2, arr, n, c, h, w, num_levels, int(tiled_levels),
+                                         _stream()), 'scf_corr_build')
+    finally:
+        if timed:
+            lib.scf_timer_arm(None)
     return out
 
 
@@ -630,6 +638,40 @@ class _TimerPool:
 
 
 _LOOKUP_TIMERS: Optional[_TimerPool] = None
+_CORR_TIMERS: Optional[_TimerPool] = None
+
+
+def corr_build_timing(enable: bool, reserve: int = 16):
+    """like ``lookup_timing`` for the correlation build: every ``corr_build`` call from now on carries a
+    timer bound to its first kernel launch -- the contraction (with the layout the decoders use: the
+    GEMM with the fused first pool, ``corr_gemm_kernel<true, true>``), not the pooling cascade behind
+    it.  enable=False: stop, synchronise, return the durations in microseconds."""
+    global _CORR_TIMERS
+    if enable:
+        if _CORR_TIMERS is not None:
+            _CORR_TIMERS.destroy()
+        _CORR_TIMERS = _TimerPool(reserve)
+        return None
+    pool, _CORR_TIMERS = _CORR_TIMERS, None
+    if pool is None:
+        return []
+    torch.cuda.synchronize()
+    out = pool.read()
+    pool.destroy()
+    return out
+
+
+def corr_build_timing_reset() -> None:
+    if _CORR_TIMERS is not None:
+        torch.cuda.synchronize()
+        _CORR_TIMERS.reset()
+
+
+def corr_build_timing_read():
+    if _CORR_TIMERS is None:
+        return []
+    torch.cuda.synchronize()
+    return _CORR_TIMERS.read()
 
 
 def lookup_timing(enable: bool, reserve: int = 64):

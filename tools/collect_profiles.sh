@@ -13,6 +13,8 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_f
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_f16x3 -o f16x3 -- $B --precision f16x3 --no-config4 > $OUT/bench_f16x3.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- $B > /dev/null 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- $B > /dev/null 2>&1
+# matrix-core utilisation of the correlation GEMM and the convolution kernels (SQ: 7 of 8 slots, GRBM: 1 of 2)
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_mfma -o m -- $B --no-config4 > $OUT/pmc_mfma.log 2>&1
 # calibration of both counters on the lookup's access types: tools/lab/calib_run.sh (own, time-bounded call)
 rm -f $OUT/*/*_kernel_trace.csv.bak
 find $OUT -name "*.csv" | head -40
