@@ -55,7 +55,7 @@ enum {
  * SCF_ABI_MAJOR before its first call; structs additionally carry no size field,
  * so a mismatch must be refused, not worked around. */
 #define SCF_ABI_MAJOR 3
-#define SCF_VERSION (SCF_ABI_MAJOR * 100 + 0)
+#define SCF_VERSION (SCF_ABI_MAJOR * 100 + 1)
 int scf_version(void);
 const char* scf_error_string(int code);
 /* number of HIP devices visible (>=0) or SCF_ENODEVICE */
@@ -165,6 +165,11 @@ typedef struct scf_conv_desc {
   int32_t out_tile8x4;                  /* 1: store every output plane in 8(x) x 4(y)-float tiles
                                            of 128 B (tile-major, row-major inside) instead of
                                            row-major; needs Wo % 8 == 0 and Ho % 4 == 0          */
+  const float* wp_taps;                 /* optional packing for thin INPUTS (Cin <= 4: the 7x7 stems, the
+                                           2 -> 128 7x7 and 1 -> 64 3x3 first layers): [Kp][Mld] floats,
+                                           row k = ci * KH*KW + t, Kp = Cin*KH*KW rounded up to a multiple of
+                                           8, zero padded; selects the kernel that contracts over taps x channels
+                                           as one dense K dimension                                  */
 } scf_conv_desc;
 
 int scf_conv2d(const scf_conv_desc* desc, scf_stream_t stream);
@@ -180,6 +185,10 @@ int64_t scf_pack_conv_weight_size(int Cout, int Cin, int KH, int KW, int KC);
 int scf_pack_conv_weight(const float* w, int Cout, int Cin, int KH, int KW, int KC, float* out);
 int64_t scf_pack_conv_weight_a4_size(int Cout, int Cin, int KH, int KW, int groups);
 int scf_pack_conv_weight_a4(const float* w, int Cout, int Cin, int KH, int KW, int groups, float* out);
+/*   taps packing (scf_conv_desc.wp_taps, Cin <= 4): out[(ci*KH*KW + t)*Mld + co] = w[co][ci][t], Mld = Cout
+ *   rounded up to 32, rows rounded up to a multiple of 8, zeros elsewhere */
+int64_t scf_pack_conv_weight_taps_size(int Cout, int Cin, int KH, int KW);
+int scf_pack_conv_weight_taps(const float* w, int Cout, int Cin, int KH, int KW, float* out);
 
 /* ---------------------------------------------------------------------------------
  * Convolutional GRU update, whole cell.     replaces ConvGRU.forward

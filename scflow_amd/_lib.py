@@ -48,6 +48,7 @@ class ConvDesc(C.Structure):
         ('a4s_groups', C.c_int32),
         ('wp_thin', _fp),
         ('out_tile8x4', C.c_int32),
+        ('wp_taps', _fp),
     ]
 
 
@@ -90,6 +91,8 @@ SIGNATURES = {
     'scf_pack_conv_weight': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'scf_pack_conv_weight_a4_size': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'scf_pack_conv_weight_a4': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'scf_pack_conv_weight_taps_size': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'scf_pack_conv_weight_taps': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'scf_sepconv_gru': (C.c_int, [_fp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.POINTER(GruPass), C.c_int, _fp, _fp, _fp]),
     'scf_sepconv_gru_ctx': (C.c_int, [_fp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -64,6 +64,24 @@ extern "C" int scf_pack_conv_weight_a4(const float* w, int Cout, int Cin, int KH
   return SCF_OK;
 }
 
+extern "C" int64_t scf_pack_conv_weight_taps_size(int Cout, int Cin, int KH, int KW) {
+  if (Cout <= 0 || Cin <= 0 || Cin > 4 || KH <= 0 || KW <= 0) return SCF_EINVAL;
+  const int64_t kp = ((int64_t)Cin * KH * KW + 7) / 8 * 8, mld = (Cout + 31) / 32 * 32;
+  return kp * mld;
+}
+
+extern "C" int scf_pack_conv_weight_taps(const float* w, int Cout, int Cin, int KH, int KW, float* out) {
+  const int64_t total = scf_pack_conv_weight_taps_size(Cout, Cin, KH, KW);
+  if (!w || !out || total < 0) return SCF_EINVAL;
+  const int T = KH * KW;
+  const int64_t mld = (Cout + 31) / 32 * 32;
+  for (int64_t i = 0; i < total; ++i) out[i] = 0.f;
+  for (int co = 0; co < Cout; ++co)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int t = 0; t < T; ++t) out[((int64_t)ci * T + t) * mld + co] = w[((int64_t)co * Cin + ci) * T + t];
+  return SCF_OK;
+}
+
 // ---- launch-bound timers (measurement aid, see scf_common.h) ----
 ScfTimer*& scf_armed_timer() {
   static thread_local ScfTimer* slot = nullptr;

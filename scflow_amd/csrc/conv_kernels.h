@@ -355,6 +355,8 @@ __device__ __forceinline__ void scf_conv_epilogue_tile(const ConvK& p, const Con
 // falls back to fp32).  info (optional): {WM, WN, blocks, MFMAs per wave per chunk}.
 int scf_conv_f16x3_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st);
 
+// conv_taps.hip: Cin <= 4 layers, contraction over taps x channels (wt = the [Kp][Mld] taps packing).
+int scf_conv_taps_dispatch(ConvK k, const float* wt, int N, bool dry_run, int* info, hipStream_t st);
 // conv_thin.hip: Cout <= 4 layers on the vector ALUs.
 int scf_conv_thin_dispatch(ConvK k, int N, bool dry_run, hipStream_t st);
 // conv_dma.hip: same contract for the stride-1 LDS-DMA fp32 kernel.

@@ -547,6 +547,10 @@ extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
     const int rt = scf_conv_thin_dispatch(pl.k, d->N, false, scf_stream(stream));
     if (rt != SCF_EUNSUPPORTED) return rt;
   }
+  if (d->wp_taps) {
+    const int rp = scf_conv_taps_dispatch(pl.k, d->wp_taps, d->N, false, nullptr, scf_stream(stream));
+    if (rp != SCF_EUNSUPPORTED) return rp;
+  }
   if (want_f16x3(d)) {
     const int r16 = scf_conv_f16x3_dispatch(pl.k, d->N, false, nullptr, scf_stream(stream));
     if (r16 != SCF_EUNSUPPORTED) return r16;
@@ -680,6 +684,10 @@ extern "C" int scf_conv2d_query(const scf_conv_desc* d, int32_t* info) {
   if (rc != SCF_OK) return rc;
   if (scf_conv_thin_dispatch(pl.k, d->N, true, nullptr) == SCF_OK) {
     info[0] = info[1] = 0; info[2] = 0; info[3] = -1;      // vector-ALU thin-output kernel
+    return SCF_OK;
+  }
+  if (d->wp_taps && scf_conv_taps_dispatch(pl.k, d->wp_taps, d->N, true, info, nullptr) == SCF_OK) {
+    info[3] = -info[3];      // negative: the thin-input kernel will run, KC of d is irrelevant
     return SCF_OK;
   }
   if (want_f16x3(d) && scf_conv_f16x3_dispatch(pl.k, d->N, true, info, nullptr) == SCF_OK) {

@@ -1,0 +1,220 @@
+// Thin-INPUT convolution (Cin <= 4): the 7x7 stems of the RAFT encoders (3 -> 64, stride 2,
+// raft_encoder.py:210-217), the 7x7 first layers of the flow / delta-flow encoders (2 -> 128,
+// raft_decoder.py:141-148, scflow_decoder.py:102-103) and the mask encoder's first 3x3 (1 -> 64,
+// scflow_decoder.py:104-105).
+//
+// The channel-chunked kernels (conv_mfma.hip / conv_dma.hip) contract over channels chunk by chunk;
+// with 1-3 channels that is a single short chunk -- no pipeline at all, every block a chain of
+// dependent round trips (2 -> 128 7x7: 19 us per launch for 6 us of matrix work) -- and the
+// 2-channel k-step of the fp32 MFMA leaves a third of it multiplying zeros at Cin = 3.  Here the
+// contraction runs over TAPS x channels as one dense K = Cin * KH * KW dimension:
+//     D[cout, pixel] = sum_k W[k][cout] * X[k][pixel],   k = c * T + t   (k-steps of 2, K padded to a multiple of 8)
+//   block   = BM = 32 WM output channels x 128 pixels (4 waves x one 32-pixel fragment = FR rows x
+//             FC columns of the output, like the other kernels), 2-3 blocks per CU;
+//   staging = ONCE per block, all of it requested up front by LDS-DMA (buffer descriptors: out-of-image
+//             taps are zero-filled by the range check): the whole [Kp][BM] weight slab, the input patch of
+//             all channels, and a table koff[k] = offset of tap k inside the patch; then a
+//             single MFMA loop over Kp / 2 steps with every operand in LDS (lane half h takes row
+//             k = 2 ks + h: exactly the A[l&31][l>>5] / B[l>>5][l&31] operand layout);
+//   epilogue = the shared fused epilogue (conv_kernels.h).
+// Blocks overlap each other's staging; nothing is chunk-pipelined because nothing needs to be.
+#include "scf_common.h"
+#include "conv_kernels.h"
+
+typedef float ct_f32x16 __attribute__((ext_vector_type(16)));
+
+// LDS-DMA through a raw buffer descriptor (as in conv_dma.hip): a lane whose offset is past
+// num_records gets ZEROS written to its LDS cell -- zero padding and the areas' tail cells for free.
+typedef int ct_rsrc_t __attribute__((ext_vector_type(4)));
+#define CT_OOB 0x80000000u
+__device__ __forceinline__ unsigned ct_lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ ct_rsrc_t ct_make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  ct_rsrc_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu));
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void ct_dma_b128(ct_rsrc_t rsrc, unsigned voff, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %0, 0 offen lds"
+               : : "s"(rsrc), "v"(voff), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void ct_dma_b32(ct_rsrc_t rsrc, unsigned voff, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %0, 0 offen lds"
+               : : "s"(rsrc), "v"(voff), "s"(lds_base) : "memory");
+}
+
+template <int WM>
+__global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvK p, const float* __restrict__ wt, int Kp, int PWp) {
+  extern __shared__ __attribute__((aligned(16))) float ct_lds[];
+  constexpr int BM = WM * 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, half = lane >> 5;
+
+  const int lb = scf_xcd_remap(blockIdx.x, gridDim.x);
+  const int mblk = __builtin_amdgcn_readfirstlane(lb % p.mblocks);
+  const int tile = __builtin_amdgcn_readfirstlane(lb / p.mblocks);
+  const int m0 = mblk * BM;
+  const int FC = 1 << p.fc_log2, FR = 32 >> p.fc_log2, TR = 4 * FR;
+  const int txi = __builtin_amdgcn_readfirstlane(tile % p.tiles_x);
+  const int t2 = tile / p.tiles_x;
+  const int tyi = __builtin_amdgcn_readfirstlane(t2 % p.tiles_y);
+  const int n = __builtin_amdgcn_readfirstlane(t2 / p.tiles_y);
+  const int ty0 = tyi * TR, tx0 = txi * FC;
+  const int st = p.stride;
+  const int iy0 = ty0 * st - p.pad_h, ix0 = tx0 * st - p.pad_w;
+  const int PH = p.PH, PHW = PH * PWp, T = p.T;
+  // LDS: weights [Kp][BM] | patch [Cin][PH][PWp] | tap table [Kp]; the first two are filled by LDS-DMA in
+  // whole wave-instructions (64 cells), so each area is padded to a multiple of 64 cells: lanes past an
+  // area's end carry an out-of-range offset and write zeros into the padding
+  const int q4 = BM / 4, n4 = Kp * q4;                     // weight cells (float4)
+  const int w_cells = (n4 + 63) & ~63;
+  const int PE = p.Cin * PHW;                              // patch cells (floats)
+  const int x_cells = (PE + 63) & ~63;
+  float* Ws = ct_lds;
+  float* Xs = Ws + w_cells * 4;
+  int* koff = (int*)(Xs + x_cells);
+
+  // ---- everything is requested up front (asynchronous memory -> LDS copies), then ONE wait ----
+  {
+    const ct_rsrc_t wrs = ct_make_rsrc(wt + m0, (unsigned)(((long long)(Kp - 1) * p.Mld + BM) * 4));
+    const unsigned wl = ct_lds_addr(Ws);
+    for (int c0 = wave * 64; c0 < w_cells; c0 += 256) {   // wave-uniform trip count
+      const int e = c0 + lane;
+      const int row = e / q4, c4 = e - row * q4;
+      const unsigned voff = e < n4 ? (unsigned)((row * p.Mld + 4 * c4) * 4) : CT_OOB;
+      ct_dma_b128(wrs, voff, wl + (unsigned)c0 * 16u);
+    }
+    const int HW = p.H * p.W;
+    const ct_rsrc_t xrs = ct_make_rsrc(p.in0 + (long long)n * p.in0_ns, (unsigned)((long long)p.Cin * HW * 4));
+    const unsigned xl = ct_lds_addr(Xs);
+    const float rPHW = 1.0f / (float)PHW, rPW = 1.0f / (float)PWp;
+    for (int c0 = wave * 64; c0 < x_cells; c0 += 256) {
+      const int e = c0 + lane;
+      int c = (int)((float)e * rPHW);
+      int r = e - c * PHW;
+      if (r < 0) { --c; r += PHW; } else if (r >= PHW) { ++c; r -= PHW; }
+      int py = (int)((float)r * rPW);
+      int px = r - py * PWp;
+      if (px < 0) { --py; px += PWp; } else if (px >= PWp) { ++py; px -= PWp; }
+      const int iy = iy0 + py, ix = ix0 + px;
+      const bool ok = e < PE && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      ct_dma_b32(xrs, ok ? (unsigned)((c * HW + iy * p.W + ix) * 4) : CT_OOB, xl + (unsigned)c0 * 4u);
+    }
+  }
+  // ---- tap table: k = c * T + t -> patch offset; padding rows (k >= Cin * T: zero weights) read cell 0 ----
+  for (int k = tid; k < Kp; k += 256) {
+    int o = 0;
+    if (k < p.Cin * T) {
+      const int c = k / T, t = k - c * T;
+      const int ky = t / p.KW, kx = t - ky * p.KW;
+      o = c * PHW + ky * PWp + kx;
+    }
+    koff[k] = o;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's copies have landed
+  __syncthreads();
+
+  ct_f32x16 acc[WM][1];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+  const int fr = l32 >> p.fc_log2, fc = l32 & (FC - 1);
+  const float* xb = Xs + ((wave * FR + fr) * st) * PWp + fc * st;      // this lane's pixel, tap (0, 0)
+  const float* wb = Ws + half * BM + l32;                               // row k = 2 ks + half
+  const int* kb = koff + half;
+  // Kp is a multiple of 8: trips of four k-steps, software-pipelined by hand -- while trip t is on the
+  // matrix pipe, the operands of trip t+1 and the table entries of trip t+2 are already being read (the
+  // table -> operand-address dependency is the only chain; hipcc left to itself issues each operand
+  // read right in front of its MFMA and waits for it).  The last trips re-read the final one instead of
+  // branching around the prefetch.
+  const int ntrip = Kp >> 3;
+  int oN[4];
+  float bC[4], aC[4][WM];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) oN[u] = kb[2 * u];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    bC[u] = xb[oN[u]];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) aC[u][i] = wb[2 * u * BM + 32 * i];
+  }
+  {
+    const int t1 = ntrip > 1 ? 1 : 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) oN[u] = kb[8 * t1 + 2 * u];
+  }
+  for (int t = 0; t < ntrip; ++t) {
+    const int tn = t + 1 < ntrip ? t + 1 : ntrip - 1, tnn = t + 2 < ntrip ? t + 2 : ntrip - 1;
+    float bN[4], aN[4][WM];
+    int oNN[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bN[u] = xb[oN[u]];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) aN[u][i] = wb[(8 * tn + 2 * u) * BM + 32 * i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) oNN[u] = kb[8 * tnn + 2 * u];
+    __builtin_amdgcn_sched_barrier(0);       // keep the reads AHEAD of this trip's MFMAs
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aC[u][i], bC[u], acc[i][0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bC[u] = bN[u];
+      oN[u] = oNN[u];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) aC[u][i] = aN[u][i];
+    }
+  }
+
+  const ConvEpi epi = scf_conv_epi(p, n);
+  int pix[1];
+  {
+    const int oy = ty0 + wave * FR + fr, ox = tx0 + fc;
+    pix[0] = (oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
+  }
+  scf_conv_epilogue_tile<WM, 1>(p, epi, acc, m0, half, pix, p.out_div != 1.0f);
+}
+
+// Tile selection + launch; SCF_EUNSUPPORTED -> the caller goes on to the channel-chunked kernels.
+int scf_conv_taps_dispatch(ConvK k, const float* wt, int N, bool dry_run, int* info, hipStream_t st) {
+  if (!wt || k.Cin > 4 || k.in1 || k.w_ns != 0 || k.out_tile || (k.Mld & 3) || ((uintptr_t)wt & 15)) return SCF_EUNSUPPORTED;
+  const int FC = 1 << k.fc_log2, FR = 32 / FC, TR = 4 * FR;
+  const int frags_m = (k.Cout + 31) / 32;
+  const int Kp = (k.Cin * k.T + 7) & ~7;         // rows of the packing: a whole number of four-k-step trips
+  const int PH = (TR - 1) * k.stride + k.KH, PWin = (FC - 1) * k.stride + k.KW;
+  const int PWp = PWin | 1;                        // odd row pitch: stride-2 column reads spread over the banks
+  const long long tiles = (long long)N * ((k.Ho + TR - 1) / TR) * ((k.Wo + FC - 1) / FC);
+  // 64 output channels per block when that still gives every CU two blocks, else 32
+  int WM = (frags_m % 2 == 0 && tiles * (frags_m / 2) >= 2LL * scf_cu_count()) ? 2 : 1;
+  size_t ldsb = 0;
+  for (;; WM = 1) {
+    const size_t wc = ((size_t)Kp * WM * 8 + 63) & ~(size_t)63, xc = ((size_t)k.Cin * PH * PWp + 63) & ~(size_t)63;
+    ldsb = (wc * 4 + xc + Kp) * sizeof(float);          // weight cells are float4, patch cells floats
+    if (ldsb <= 64 * 1024 || WM == 1) break;
+  }
+  if (ldsb > 64 * 1024) return SCF_EUNSUPPORTED;
+  k.PH = PH; k.PW = PWp; k.PWin = PWin;
+  k.tiles_y = (k.Ho + TR - 1) / TR;
+  k.tiles_x = (k.Wo + FC - 1) / FC;
+  k.mblocks = frags_m / WM;
+  const long long nblk = tiles * k.mblocks;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
+  if (info) { info[0] = WM; info[1] = 1; info[2] = (int)nblk; info[3] = Kp / 2 * WM; }
+  if (dry_run) return SCF_OK;
+  if (WM == 2) scf_launch((conv_taps_kernel<2>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, wt, Kp, PWp);
+  else scf_launch((conv_taps_kernel<1>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, wt, Kp, PWp);
+  return scf_launch_status();
+}

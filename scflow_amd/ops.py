@@ -237,6 +237,18 @@ def pack_conv_weight_thin(weight: Tensor) -> Tensor:
     return flat
 
 
+def pack_conv_weight_taps(weight: Tensor) -> Tensor:
+    """(Cout, Cin <= 4, KH, KW) -> [Kp][Mld] (conv_taps.hip): row k = ci * KH*KW + t, Kp = Cin*KH*KW rounded
+    up to a multiple of 8, Mld = Cout rounded up to 32; zero padded."""
+    cout, cin, kh, kw = weight.shape
+    t = kh * kw
+    kp = (cin * t + 7) // 8 * 8
+    mld = (cout + 31) // 32 * 32
+    out = torch.zeros((kp, mld), dtype=torch.float32, device=weight.device)
+    out[:cin * t, :cout] = weight.reshape(cout, cin * t).t().float()
+    return out.contiguous()
+
+
 _CONV_PRECISION = 'f32'
 
 
@@ -281,6 +293,7 @@ class PackedConv:
     wthin: Optional[Tensor] = None    # [Cin][T][CO] packing (Cout <= 4)
     wp4s: Optional[Tensor] = None     # small-grid LDS-DMA packing (bigger chunks)
     g4s: int = 0
+    wtaps: Optional[Tensor] = None    # [Cin*T][Mld] packing (Cin <= 4: contraction over taps)
 
     @staticmethod
     def from_weight(weight: Tensor, bias: Optional[Tensor], stride: int = 1,
@@ -308,7 +321,7 @@ class PackedConv:
         return PackedConv(wp, None if bias is None else bias.float().contiguous(), scale, shift,
                           cin, cout, kh, kw, stride, ph, pw, kc, mld, wp_alt, {}, wp16, wp4, g4,
                           pack_conv_weight_thin(weight) if (cout <= 4 and stride == 1 and cin >= 32) else None,
-                          wp4s, g4s)
+                          wp4s, g4s, pack_conv_weight_taps(weight) if (cin <= 4 and dma_packing) else None)
 
     def out_hw(self, h: int, w: int) -> Tuple[int, int]:
         return ((h + 2 * self.pad_h - self.kh) // self.stride + 1,
@@ -371,6 +384,8 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
         d.wp_f16 = pc.wp16.data_ptr()
     if pc.wthin is not None:
         d.wp_thin = pc.wthin.data_ptr()
+    if pc.wtaps is not None and x1 is None:
+        d.wp_taps = pc.wtaps.data_ptr()
     if pc.wp4 is not None:
         d.wp_a4, d.a4_groups, d.a4_mld = pc.wp4.data_ptr(), pc.g4, pc.mld
     if pc.wp4s is not None:

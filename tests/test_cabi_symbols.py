@@ -91,6 +91,15 @@ def test_c_weight_packers_match_host_packers():
             out = torch.full((n,), float('nan'))
             assert lib.scf_pack_conv_weight_a4(w.data_ptr(), cout, cin, kh, kw, grp, out.data_ptr()) == 0
             assert torch.equal(out, want.reshape(-1))
+    for cout, cin, kh, kw in ((64, 3, 7, 7), (128, 2, 7, 7), (64, 1, 3, 3), (40, 4, 3, 3)):
+        w = torch.randn((cout, cin, kh, kw), generator=g).contiguous()
+        want = ops.pack_conv_weight_taps(w)
+        n = lib.scf_pack_conv_weight_taps_size(cout, cin, kh, kw)
+        assert n == want.numel() and want.shape[0] % 8 == 0
+        out = torch.full((n,), float('nan'))
+        assert lib.scf_pack_conv_weight_taps(w.data_ptr(), cout, cin, kh, kw, out.data_ptr()) == 0
+        assert torch.equal(out, want.reshape(-1))
+    assert lib.scf_pack_conv_weight_taps_size(8, 5, 3, 3) < 0
     assert lib.scf_pack_conv_weight_size(4, 4, 3, 3, 5) < 0
     assert lib.scf_pack_conv_weight_a4_size(4, 4, 3, 3, 3) < 0
     assert lib.scf_pack_conv_weight(None, 4, 4, 3, 3, 8, None) < 0

@@ -220,6 +220,13 @@ CONV_CASES = [
     (3, 128, 128, (3, 3), 2, (1, 1), 8, 8),
     (1, 16, 40, (3, 3), 1, (1, 1), 12, 20),
     (1, 64, 64, (3, 3), 1, (1, 1), 128, 128),
+    # thin inputs (Cin <= 4): the tap-contracting kernel (conv_taps.hip), both tile widths, ragged tiles
+    (8, 3, 64, (7, 7), 2, (3, 3), 128, 128),
+    (32, 2, 128, (7, 7), 1, (3, 3), 32, 32),
+    (32, 1, 64, (3, 3), 1, (1, 1), 32, 32),
+    (3, 4, 40, (3, 3), 1, (1, 1), 12, 20),
+    (2, 2, 96, (5, 5), 2, (2, 2), 30, 22),
+    (1, 3, 64, (7, 7), 2, (3, 3), 480, 640),
 ]
 
 

@@ -15,6 +15,14 @@ LAYERS = [  # name, cin, cout, (kh,kw), stride, pad, H, W, batch multiplier
     ('1x1 324>256', 324, 256, (1, 1), 1, (0, 0), 32, 32, 1),
     ('pose c0 3x3s2 224>128', 224, 128, (3, 3), 2, (1, 1), 32, 32, 1),
     ('flow_pred 3x3 256>2', 256, 2, (3, 3), 1, (1, 1), 32, 32, 1),
+    ('stem 7x7s2 3>64 @256', 3, 64, (7, 7), 2, (3, 3), 256, 256, 2),
+    ('flow 7x7 2>128', 2, 128, (7, 7), 1, (3, 3), 32, 32, 1),
+    ('mask 3x3 1>64', 1, 64, (3, 3), 1, (1, 1), 32, 32, 1),
+    ('pose c1 3x3s2 128>128 @16', 128, 128, (3, 3), 2, (1, 1), 16, 16, 1),
+    ('pose c2 3x3s2 128>128 @8', 128, 128, (3, 3), 2, (1, 1), 8, 8, 1),
+    ('enc 3x3 128>64', 128, 64, (3, 3), 1, (1, 1), 32, 32, 1),
+    ('menc 3x3 64>32', 64, 32, (3, 3), 1, (1, 1), 32, 32, 1),
+    ('ds 1x1s2 64>96 @128', 64, 96, (1, 1), 2, (0, 0), 128, 128, 2),
 ]
 sel = sys.argv[1:] 
 for name, cin, cout, k, s, p, H, W, bm in LAYERS:
@@ -28,7 +36,19 @@ for name, cin, cout, k, s, p, H, W, bm in LAYERS:
     out = ops.conv2d(pc, x, act=ops.ACT_RELU)
     flops = 2.0 * cin * k[0] * k[1] * cout * out.shape[2] * out.shape[3] * n
     res = []
-    for prec in ('f32', 'f16x3'):
+    if pc.wtaps is not None:        # thin input: A/B of the tap-contracting kernel against the chunked one,
+        import copy                 # kernel durations from launch-bound timers
+        for tag, q in (('taps', pc), ('chunked', copy.copy(pc))):
+            if tag == 'chunked':
+                q.wtaps = None
+            for _ in range(3):
+                ops.conv2d(q, x, out=out, act=ops.ACT_RELU)
+            ops.conv_timing(True)
+            for _ in range(15):
+                ops.conv2d(q, x, out=out, act=ops.ACT_RELU)
+            ts = sorted(e[0] for e in ops.conv_timing(False))
+            res.append(f'{tag}: {ts[len(ts) // 2]:7.1f} us kernel')
+    for prec in (('f32', 'f16x3') if not os.environ.get('F32_ONLY') else ('f32',)):
         ops.set_conv_precision(prec)
         for _ in range(3):
             ops.conv2d(pc, x, out=out, act=ops.ACT_RELU)
