@@ -33,8 +33,15 @@ __all__ = ['PackedConv', 'pyramid_layout', 'untile_level', 'level_storage_shape'
            'CONV_GRU_Q']
 
 
+# The two queries every launch makes -- current device, its current stream -- go straight to torch's C
+# layer: torch.cuda.current_stream() builds a Stream object through four Python frames per call (~3 us),
+# a fifth of the host cost of an eager batch-1 pass (tools/lab/host_profile.py).
+_cur_dev = torch._C._cuda_getDevice
+_raw_stream = torch._C._cuda_getCurrentRawStream
+
+
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return _raw_stream(_cur_dev())
 
 
 def _dev(t: Tensor, name: str) -> None:
@@ -45,10 +52,10 @@ def _dev(t: Tensor, name: str) -> None:
         raise _lib.ScflowHipError(f'{name}: expected float32, got {t.dtype}')
     # launches go to the CURRENT device's current stream: a tensor on another GPU would be
     # touched through peer access (or fault) from the wrong device's stream
-    if t.device.index != torch.cuda.current_device():
+    if t.device.index != _cur_dev():
         raise _lib.ScflowHipError(
             f'{name} lives on cuda:{t.device.index} but the current device is '
-            f'cuda:{torch.cuda.current_device()}: wrap the call in torch.cuda.device(tensor.device)')
+            f'cuda:{_cur_dev()}: wrap the call in torch.cuda.device(tensor.device)')
 
 
 def _dense(t: Tensor, name: str) -> int:
@@ -294,6 +301,7 @@ class PackedConv:
     wp4s: Optional[Tensor] = None     # small-grid LDS-DMA packing (bigger chunks)
     g4s: int = 0
     wtaps: Optional[Tensor] = None    # [Cin*T][Mld] packing (Cin <= 4: contraction over taps)
+    desc: Optional[ConvDesc] = None   # scf_conv_desc with this layer's own fields filled (built lazily)
 
     @staticmethod
     def from_weight(weight: Tensor, bias: Optional[Tensor], stride: int = 1,
@@ -328,6 +336,25 @@ class PackedConv:
                 (w + 2 * self.pad_w - self.kw) // self.stride + 1)
 
 
+def _desc_template(pc: 'PackedConv') -> ConvDesc:
+    d = ConvDesc()
+    d.wp, d.w_nstride, d.Mld, d.Cout = pc.wp.data_ptr(), 0, pc.mld, pc.cout
+    d.KH, d.KW, d.stride, d.pad_h, d.pad_w, d.KC = pc.kh, pc.kw, pc.stride, pc.pad_h, pc.pad_w, pc.kc
+    d.bias = None if pc.bias is None else pc.bias.data_ptr()
+    d.scale = None if pc.scale is None else pc.scale.data_ptr()
+    d.shift = None if pc.shift is None else pc.shift.data_ptr()
+    d.out_div = 1.0
+    if pc.wthin is not None:
+        d.wp_thin = pc.wthin.data_ptr()
+    if pc.wtaps is not None:
+        d.wp_taps = pc.wtaps.data_ptr()
+    if pc.wp4 is not None:
+        d.wp_a4, d.a4_groups, d.a4_mld = pc.wp4.data_ptr(), pc.g4, pc.mld
+    if pc.wp4s is not None:
+        d.wp_a4s, d.a4s_groups, d.a4_mld = pc.wp4s.data_ptr(), pc.g4s, pc.mld
+    return d
+
+
 def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optional[Tensor] = None,
            *, res: Optional[Tensor] = None, act: int = ACT_NONE, act2: int = ACT_NONE,
            act_split: int = 0, mode: int = CONV_PLAIN, gru_h: Optional[Tensor] = None,
@@ -351,22 +378,21 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
     if (no, co, oh, ow) != (n, want_c, ho, wo):
         raise _lib.ScflowHipError(f'out has shape {tuple(out.shape)}, expected '
                                   f'{(n, want_c, ho, wo)}')
-    d = ConvDesc()
+    # the layer's own fields (weights in every packing, geometry, bias / BN) are filled once per
+    # PackedConv and copied; a call sets the tensors and the epilogue
+    tmpl = pc.desc
+    if tmpl is None:
+        tmpl = pc.desc = _desc_template(pc)
+    d = ConvDesc.from_buffer_copy(tmpl)
     d.in0, d.in1, d.C0, d.C1 = p0, p1, c0, c1
     d.in0_nstride, d.in1_nstride = s0, s1
     d.N, d.H, d.W = n, h, w
-    d.wp, d.w_nstride, d.Mld, d.Cout = pc.wp.data_ptr(), 0, pc.mld, pc.cout
-    d.KH, d.KW, d.stride, d.pad_h, d.pad_w, d.KC = pc.kh, pc.kw, pc.stride, pc.pad_h, pc.pad_w, pc.kc
     d.out, d.out_nstride = po, so
-    d.bias = None if pc.bias is None else pc.bias.data_ptr()
-    d.scale = None if pc.scale is None else pc.scale.data_ptr()
-    d.shift = None if pc.shift is None else pc.shift.data_ptr()
     if res is not None:
         pr, nr, cr, hr, wr, sr = _nchw(res, 'res')
         if (nr, cr, hr, wr) != (n, pc.cout, ho, wo):
             raise _lib.ScflowHipError('res shape mismatch')
         d.res, d.res_nstride = pr, sr
-    d.out_div = 1.0
     d.act, d.act2, d.act_split, d.mode = act, act2, act_split, mode
     if gru_h is not None:
         ph_, _, _, _, _, sh_ = _nchw(gru_h, 'gru_h')
@@ -382,14 +408,8 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
     # hide.  Stage 32 channels per chunk instead when that packing fits (decided once per shape).
     if _CONV_PRECISION == 'f16x3' and pc.wp16 is not None:
         d.wp_f16 = pc.wp16.data_ptr()
-    if pc.wthin is not None:
-        d.wp_thin = pc.wthin.data_ptr()
-    if pc.wtaps is not None and x1 is None:
-        d.wp_taps = pc.wtaps.data_ptr()
-    if pc.wp4 is not None:
-        d.wp_a4, d.a4_groups, d.a4_mld = pc.wp4.data_ptr(), pc.g4, pc.mld
-    if pc.wp4s is not None:
-        d.wp_a4s, d.a4s_groups, d.a4_mld = pc.wp4s.data_ptr(), pc.g4s, pc.mld
+    if x1 is not None:
+        d.wp_taps = None                # the thin-input kernel takes one input segment
     if pc.wp_alt is not None and (c1 == 0 or c0 % 32 == 0):
         key = (n, h, w, c0, c1, d.wp_f16 is not None)
         use_alt = pc.plans.get(key)

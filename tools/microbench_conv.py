@@ -40,7 +40,7 @@ for name, cin, cout, k, s, p, H, W, bm in LAYERS:
         import copy                 # kernel durations from launch-bound timers
         for tag, q in (('taps', pc), ('chunked', copy.copy(pc))):
             if tag == 'chunked':
-                q.wtaps = None
+                q.wtaps, q.desc = None, None
             for _ in range(3):
                 ops.conv2d(q, x, out=out, act=ops.ACT_RELU)
             ops.conv_timing(True)
