@@ -326,6 +326,12 @@ int scf_convex_upsample(const float* x, const float* mask, float* out, int N, in
 int scf_avgpool2x2(const float* x, float* out, int64_t planes, int Hin, int Win,
                    scf_stream_t stream);
 
+/* out[n, c, :] = x[n, c, :] * mask[n, 0, :]  (mask (N, 1, HW) dense; x / out sample-strided): the
+ * occlusion masking of the looked-up correlation / of the flow, scflow_decoder.py:199-205
+ * (constructor switches mask_corr / mask_flow; both False in configs/refine_models/scflow.py). */
+int scf_mul_mask(const float* x, int64_t x_nstride, const float* mask, float* out,
+                 int64_t out_nstride, int N, int C, int HW, scf_stream_t stream);
+
 /* elementwise helpers used for glue (split tanh/relu of the context features etc.)   */
 int scf_copy_strided(const float* src, int64_t src_nstride, float* dst, int64_t dst_nstride,
                      int N, int64_t count, scf_stream_t stream);

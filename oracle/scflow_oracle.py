@@ -342,15 +342,18 @@ def extract_feat(render_images: Tensor, real_images: Tensor, sd: SD, *, h_channe
 
 def get_pose(render_images: Tensor, real_images: Tensor, ref_rotation: Tensor,
              ref_translation: Tensor, depth: Tensor, internel_k: Tensor, label: Tensor,
-             sd: SD, *, iters: int = 8, init_flow: Tensor | None = None):
+             sd: SD, *, iters: int = 8, init_flow: Tensor | None = None,
+             mask_flow: bool = False, mask_corr: bool = False):
     """refiner/scflow_refiner.py:112-142 ``SCFlowRefiner.get_pose``
-    (invalid_flow_num = 0 at inference, :142)."""
+    (invalid_flow_num = 0 at inference, :142); ``mask_flow`` / ``mask_corr``: the decoder's
+    constructor switches (scflow_decoder.py:199-205, both False in configs/refine_models/scflow.py)."""
     fr, fl, h, c = extract_feat(render_images, real_images, sd)
     if init_flow is None:
         n, _, H, W = real_images.shape
         init_flow = torch.zeros((n, 2, H, W), dtype=torch.float32)
     return scflow_decoder(fr, fl, h, c, ref_rotation, ref_translation, depth, internel_k,
-                          label, init_flow, sd, iters=iters, invalid_flow_num=0.)
+                          label, init_flow, sd, iters=iters, invalid_flow_num=0.,
+                          mask_flow=mask_flow, mask_corr=mask_corr)
 
 
 def end_point_error(flow_a: Tensor, flow_b: Tensor, valid: Tensor | None = None) -> float:

@@ -114,6 +114,7 @@ SIGNATURES = {
     'scf_convex_upsample': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_float, C.c_float, _fp]),
     'scf_avgpool2x2': (C.c_int, [_fp, _fp, C.c_int64, C.c_int, C.c_int, _fp]),
+    'scf_mul_mask': (C.c_int, [_fp, C.c_int64, _fp, _fp, C.c_int64, C.c_int, C.c_int, C.c_int, _fp]),
     'scf_copy_strided': (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int, C.c_int64, _fp]),
 }
 

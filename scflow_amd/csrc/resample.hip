@@ -119,6 +119,32 @@ int scf_avgpool2x2_layout(const float* x, float* out, int64_t planes, int Hin, i
   return scf_launch_status();
 }
 
+// out[n, c, p] = x[n, c, p] * mask[n, 0, p]: the decoder's optional occlusion masking of the looked-up
+// correlation and of the flow (scflow_decoder.py:199-205, mask_corr / mask_flow).  x / out may be
+// sample-strided NCHW views.
+__global__ __launch_bounds__(256) void mul_mask_kernel(const float* __restrict__ x, long long xns,
+                                                       const float* __restrict__ mask,
+                                                       float* __restrict__ out, long long ons, int N,
+                                                       int C, int HW) {
+  const long long per = (long long)C * HW, total = (long long)N * per;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const long long n = idx / per, r = idx - n * per;
+    const int px = (int)(r % HW);
+    out[n * ons + r] = x[n * xns + r] * mask[n * HW + px];
+  }
+}
+
+extern "C" int scf_mul_mask(const float* x, int64_t x_nstride, const float* mask, float* out,
+                            int64_t out_nstride, int N, int C, int HW, scf_stream_t stream) {
+  if (!x || !mask || !out || N <= 0 || C <= 0 || HW <= 0) return SCF_EINVAL;
+  const long long total = (long long)N * C * HW;
+  const int grid = (int)(scf_cdiv(total, 256) < 262144 ? scf_cdiv(total, 256) : 262144);
+  scf_launch(mul_mask_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), x, (long long)x_nstride, mask,
+             out, (long long)out_nstride, N, C, HW);
+  return scf_launch_status();
+}
+
 __global__ __launch_bounds__(256) void copy_strided_kernel(const float* __restrict__ src,
                                                            long long sns, float* __restrict__ dst,
                                                            long long dns, int N, long long count) {

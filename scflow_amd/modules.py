@@ -506,8 +506,7 @@ class SCFlowDecoder(HipModule):
         super().__init__()
         if net_type != 'Basic':
             raise NotImplementedError("SCFlowDecoder: net_type='Basic'")
-        if mask_flow or mask_corr:
-            raise NotImplementedError('mask_flow / mask_corr (both False in scflow.py) are not built')
+        self.mask_flow, self.mask_corr = bool(mask_flow), bool(mask_corr)      # scflow_decoder.py:199-205
         if depth_transform != 'exp':
             raise NotImplementedError("depth_transform='exp' only")
         self.net_type, self.num_levels, self.radius, self.iters = net_type, num_levels, radius, iters
@@ -570,12 +569,18 @@ class SCFlowDecoder(HipModule):
         ctx = self.gru.context_terms(hx[:, hc:hc + cc]) if self.hoist_context else None
         # small batches: independent branches side by side
         ov_flow, ov_mask, ov_up = (ops.small_work(n, H, W, b) for b in ('flow', 'mask', 'upsample'))
+        # occlusion mask of the previous iteration (ones before the first: the 1/8 bilinear
+        # down-sampling of a ones map, :188-190), used only with mask_flow / mask_corr
+        mask = torch.ones((n, 1, h, w), **f32) if (self.mask_flow or self.mask_corr) else None
         for _ in range(self.iters):
             flow_lr = ops.resize_bilinear(flow, (h, w), mul=1.0 / scale)           # :196-197
             cf = torch.empty((n, 256, h, w), **f32)      # before the fork (the side branch writes it)
+            flow_in = ops.mul_mask(flow_lr, mask) if self.mask_flow else flow_lr   # :203-204
             fork = ops.fork_point() if ov_flow else None    # the motion encoder's flow branch starts here
             corr = self.corr_lookup(pyramid, flow_lr, tiled_levels=tiled)          # :198
-            self.encoder(corr, flow_lr, out=hx[:, hc + cc:], overlap=ov_flow, cf=cf, fork=fork)   # :206
+            if self.mask_corr:
+                ops.mul_mask(corr, mask, out=corr)                                 # :200-201
+            self.encoder(corr, flow_in, out=hx[:, hc + cc:], overlap=ov_flow, cf=cf, fork=fork)   # :206
             hv = self.gru.forward_inplace(hx, ctx, cc)                             # :207-208
             ops.conv2d(self.packed, hv, out=heads, act=ACT_RELU)
             d_flow = self.flow_pred.predict(heads[:, :256])                        # :210

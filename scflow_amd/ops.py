@@ -889,6 +889,21 @@ def avgpool2x2(x: Tensor) -> Tensor:
     return out
 
 
+def mul_mask(x: Tensor, mask: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """x * mask with mask (N, 1, H, W) broadcast over the channels (scflow_decoder.py:199-205)."""
+    px, n, c, h, w, sx = _nchw(x, 'x')
+    if tuple(mask.shape) != (n, 1, h, w):
+        raise _lib.ScflowHipError(f'mask has shape {tuple(mask.shape)}, expected {(n, 1, h, w)}')
+    if out is None:
+        out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    po, n2, c2, h2, w2, so = _nchw(out, 'out')
+    if (n2, c2, h2, w2) != (n, c, h, w):
+        raise _lib.ScflowHipError('mul_mask: out shape mismatch')
+    _lib.check(_lib.load().scf_mul_mask(px, sx, _dense(mask, 'mask'), po, so, n, c, h * w, _stream()),
+               'scf_mul_mask')
+    return out
+
+
 def copy_channels(src: Tensor, dst: Tensor) -> Tensor:
     """copy a sample-strided NCHW tensor into another (same N, C, H, W)."""
     ps, n, c, h, w, ss = _nchw(src, 'src')

@@ -205,6 +205,34 @@ def main():
 
 
 @torch.no_grad()
+def main_masked():
+    """the decoder's non-default branches mask_flow / mask_corr (scflow_decoder.py:199-205): the
+    reference refiner with both switched on, same weights / inputs as refiner_full.npz."""
+    cfg = dict(runpy.run_path(_refshim.REFERENCE_ROOT + '/configs/refine_models/scflow.py')['model'])
+    cfg['renderer'] = None
+    cfg['pose_loss_cfg'] = cfg['flow_loss_cfg']
+    cfg['decoder'] = dict(cfg['decoder'], mask_flow=True, mask_corr=True)
+    model = build_from_cfg(cfg, REFINERS).eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(fill_state_dict(shapes, seed=0), strict=True)
+    iters = 3
+    inp = make_inputs(3, 256, 256, seed=7)
+    model.decoder.iters = iters
+    outs = model.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'],
+                          inp['ref_translation'], inp['depth'], inp['internel_k'], inp['label'])
+    names = ['flow_from_pose', 'flow_from_pred', 'rotation', 'translation', 'mask',
+             'delta_rotation', 'delta_translation']
+    arrays = {}
+    for nm, seq in zip(names, outs):
+        st = torch.stack(list(seq))
+        if st.dim() == 5:
+            st = st[..., ::4, ::4]
+        arrays[nm] = st
+    save('refiner_masked.npz', SHIM, iters=iters, input_seed=7, weight_seed=0, n=3,
+         label=inp['label'], mask_flow=1, mask_corr=1, **arrays)
+
+
+@torch.no_grad()
 def main_next():
     """fixtures of the SURVEY 8(f) rows: pose-free RAFT decoders, cal_epe."""
     from models.decoder.raft_decoder import RAFTDecoder
@@ -305,6 +333,8 @@ def main_poseerr():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'poseerr':
         main_poseerr()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'masked':
+        main_masked()
     elif len(sys.argv) > 1 and sys.argv[1] == 'next':
         main_next()
     elif len(sys.argv) > 1 and sys.argv[1] == 'gtflow':

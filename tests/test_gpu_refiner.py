@@ -116,6 +116,42 @@ def test_full_refiner_golden(golden_dir, model):
         close(st, g[nm], atol=tol[nm], what=nm)
 
 
+def test_masked_branches_golden(golden_dir):
+    """mask_flow / mask_corr (scflow_decoder.py:199-205, off in the SCFlow config): against the
+    reference's own output with both switched on, and against the oracle at batch 1 (side-stream
+    overlap active)."""
+    g = _g(golden_dir, 'refiner_masked.npz')
+    cfg = scflow_amd.scflow_model_cfg(iters=int(g['iters']))
+    cfg['decoder'].update(mask_flow=True, mask_corr=True)
+    m = scflow_amd.build_refiner(cfg)
+    sd = scflow_amd.fill_state_dict(_shapes(golden_dir), seed=0)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    inp = scflow_amd.make_inputs(int(g['n']), 256, 256, seed=int(g['input_seed']))
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    outs = m.get_pose(d['render_images'], d['real_images'], d['ref_rotation'], d['ref_translation'],
+                      d['depth'], d['internel_k'], d['label'])
+    names = ['flow_from_pose', 'flow_from_pred', 'rotation', 'translation', 'mask',
+             'delta_rotation', 'delta_translation']
+    tol = dict(flow_from_pose=3e-4, flow_from_pred=3e-4, rotation=1e-6, translation=1e-3,
+               mask=1e-5, delta_rotation=1e-6, delta_translation=2e-6)
+    for nm, seq in zip(names, outs):
+        st = torch.stack(list(seq))
+        if st.dim() == 5:
+            st = st[..., ::4, ::4]
+        close(st, g[nm], atol=tol[nm], what='masked ' + nm)
+    one = {k: v[:1].contiguous() for k, v in inp.items()}
+    with torch.no_grad():
+        want = oracle.get_pose(one['render_images'], one['real_images'], one['ref_rotation'],
+                               one['ref_translation'], one['depth'], one['internel_k'], one['label'],
+                               sd, iters=int(g['iters']), mask_flow=True, mask_corr=True)
+    d1 = {k: v.to(DEV) for k, v in one.items()}
+    got = m.get_pose(d1['render_images'], d1['real_images'], d1['ref_rotation'], d1['ref_translation'],
+                     d1['depth'], d1['internel_k'], d1['label'])
+    for it in range(int(g['iters'])):
+        assert oracle.end_point_error(got[1][it].cpu(), want[1][it]) <= 1e-3
+
+
 @pytest.mark.parametrize('n,iters', [(1, 8), (2, 8)])
 def test_full_refiner_vs_oracle_epe(golden_dir, model, n, iters):
     """BASELINE configs 1/2 shape: 256x256, 8 GRU iterations.  EPE <= 1e-3 px."""

@@ -90,9 +90,12 @@ def test_packed_cache_invalidation():
 
 def test_unsupported_options_fail_loudly():
     cfg = scflow_amd.scflow_model_cfg()
-    cfg['decoder']['mask_corr'] = True
+    cfg['decoder']['net_type'] = 'Small'
     with pytest.raises(NotImplementedError):
         scflow_amd.build_refiner(cfg)
+    cfg = scflow_amd.scflow_model_cfg()
+    cfg['decoder']['mask_corr'] = cfg['decoder']['mask_flow'] = True       # built since round 3
+    assert scflow_amd.build_refiner(cfg).decoder.mask_corr
     model = scflow_amd.build_refiner(scflow_amd.scflow_model_cfg())
     x = torch.zeros(1, 3, 64, 64)
     with pytest.raises(scflow_amd._lib.ScflowHipError):

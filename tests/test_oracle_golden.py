@@ -137,3 +137,25 @@ def test_full_refiner(golden_dir):
         if st.dim() == 5:
             st = st[..., ::4, ::4]
         _close(st, g[nm], atol=tol[nm])
+
+
+def test_full_refiner_masked_branches(golden_dir):
+    """decoder switches mask_flow / mask_corr (scflow_decoder.py:199-205; both False in the SCFlow
+    config): the oracle against the reference run with both on."""
+    g = _load(golden_dir, 'refiner_masked.npz')
+    keys = json.load(open(os.path.join(golden_dir, 'state_dict_keys.json')))['shapes']
+    sd = fill_state_dict(keys, seed=int(g['weight_seed']))
+    inp = make_inputs(int(g['n']), 256, 256, seed=int(g['input_seed']))
+    with torch.no_grad():
+        outs = oracle.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'],
+                               inp['ref_translation'], inp['depth'], inp['internel_k'],
+                               inp['label'], sd, iters=int(g['iters']), mask_flow=True, mask_corr=True)
+    names = ['flow_from_pose', 'flow_from_pred', 'rotation', 'translation', 'mask',
+             'delta_rotation', 'delta_translation']
+    tol = dict(flow_from_pose=1e-3, flow_from_pred=1e-3, rotation=1e-5, translation=2e-3,
+               mask=1e-4, delta_rotation=1e-5, delta_translation=1e-5)
+    for nm, seq in zip(names, outs):
+        st = torch.stack(list(seq))
+        if st.dim() == 5:
+            st = st[..., ::4, ::4]
+        _close(st, g[nm], atol=tol[nm])
