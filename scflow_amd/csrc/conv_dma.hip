@@ -15,6 +15,7 @@
 //
 // Zero padding: the patch areas are zero-filled once per block and out-of-image positions are
 // never written afterwards (the gather table is chunk-invariant).
+#include <stdlib.h>
 #include "scf_common.h"
 #include <atomic>
 
@@ -539,9 +540,8 @@ static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st
 // Tile selection + launch.  k comes from conv_plan() (geometry fields are overwritten here).
 // SCF_EUNSUPPORTED -> the caller falls back to the register-staged kernel (thin inputs, 7x7,
 // shapes that exceed the DMA kernel's staging budget).
-//   large grids  (>= 512 blocks): pixel-split tiles, double buffer (co-resident blocks overlap)
-//   small grids  : the same tiles with a 4-deep ring while they still give >= 256 blocks, else
-//                  the K-split tile (32 channels x 32 pixels) with a ring as deep as LDS allows
+//   large grids  (>= 2 blocks per CU): pixel-split tiles, double buffer (co-resident blocks overlap)
+//   small grids  : the K-split tile (32 channels x 32 pixels, 4x the blocks), double buffer too
 int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st) {
   if ((!k.wp4 && !k.wp4s) || (k.stride != 1 && k.stride != 2) || k.w_ns != 0) return SCF_EUNSUPPORTED;
   // byte offsets inside a staged chunk (<= 32 channel planes) are 32-bit and must stay below SCF_DMA_OOB
@@ -618,47 +618,56 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
     if (blk11 >= 256) return SCF_EUNSUPPORTED;
   }
   if (KC) k.nchunk = (k.Cin + KC - 1) / KC;
-  int WM = 1, WN = 1, NST = 2;
+  int WM = 1, WN = 1;
   bool ksp = false, px4 = false;
   long long nblk = 0;
   size_t ldsb = 0;
-  if (best >= 0 && best_blk >= 256) {                  // pixel-split tile
-    WM = cand[best][0]; WN = cand[best][1];
-    nblk = best_blk;
-    ldsb = best_lds;
-    if (!large) {                                      // small grid: deeper ring when it fits one block per CU
-      if (best_lds * 2 <= SCF_DMA_LDS_DEEP && k.nchunk >= 4) { NST = 4; ldsb = best_lds * 2; }
-      else if (best_lds / 2 * 3 <= SCF_DMA_LDS_DEEP && k.nchunk >= 3) { NST = 3; ldsb = best_lds / 2 * 3; }
-      if (!((WM == 1 && WN == 1) || (WM == 2 && WN == 1))) {       // deep rings are instantiated for these tiles
-        NST = 2; ldsb = best_lds;
-      }
-    }
-    const int TR = WN * 4 * FR;
-    k.PH = (TR - 1) * k.stride + k.KH;
-    k.tiles_y = (k.Ho + TR - 1) / TR;
-    px4 = px4_large;
-  } else {                                             // K-split tile: one 32-pixel fragment per block
+  // Grids that do not fill the chip twice over take the K-split tile (32 channels x ONE 32-pixel
+  // fragment per block: 4x the blocks of the smallest pixel-split tile) with the plain double buffer:
+  // several small blocks per CU hide each other's memory round trips better than one block with a
+  // deep ring does (measured, graph replay of get_pose: batch 1 3.84 -> 3.45 ms, batch 4 6.55 -> 5.40,
+  // batch 8 8.95 -> 8.14; the 4- and 6-deep rings of round 2 lost at every batch size).
+  bool use_ksp = !large;
+  const ConvK k_in = k;
+  if (use_ksp) {
     if (k.wp4s && (k.G4s == 1 || k.G4s == 2 || k.G4s == 4) && !(k.in1 && (k.C0 % (8 * k.G4s)) != 0)) {
       k.wp4 = k.wp4s; k.G4 = k.G4s;                    // the small-grid packing: bigger chunks
     } else if (!pix_ok) {
-      return SCF_EUNSUPPORTED;
+      use_ksp = false;
     }
+  }
+  if (use_ksp) {
     G = k.G4; KC = 8 * G;
     k.nchunk = (k.Cin + KC - 1) / KC;
     const int PH = (FR - 1) * k.stride + k.KH, PWin = (FC - 1) * k.stride + k.KW;
     px4 = px4_small;
     const int PW = pitch(PWin, px4);
     const long long PE = (long long)KC * PH * PW, WF4 = (long long)k.T * G * 2 * 32;
-    if (PE > (px4 ? 1024 * SCF_DMA_PU_X4 : 256 * SCF_DMA_PU_KSP) || WF4 > 256 * SCF_DMA_WU_KSP) return SCF_EUNSUPPORTED;
     const size_t stage_b = (size_t)(WF4 * 4 + PE) * sizeof(float);
-    NST = k.nchunk >= 6 && stage_b * 6 <= SCF_DMA_LDS_DEEP ? 6 : k.nchunk >= 3 && stage_b * 4 <= SCF_DMA_LDS_DEEP ? 4 : 2;
-    ldsb = stage_b * NST;
+    ldsb = stage_b * 2;
     if (ldsb < 16 * 1024) ldsb = 16 * 1024;            // cross-wave reduction area
-    if (ldsb > SCF_DMA_LDS_DEEP) return SCF_EUNSUPPORTED;
-    ksp = true;
-    nblk = (long long)N * ((k.Ho + FR - 1) / FR) * ((k.Wo + FC - 1) / FC) * frags_m;
-    k.PH = PH;
-    k.tiles_y = (k.Ho + FR - 1) / FR;
+    if (PE > (px4 ? 1024 * SCF_DMA_PU_X4 : 256 * SCF_DMA_PU_KSP) || WF4 > 256 * SCF_DMA_WU_KSP ||
+        ldsb > SCF_DMA_LDS_MAX) {
+      use_ksp = false;
+    } else {
+      ksp = true;
+      nblk = (long long)N * ((k.Ho + FR - 1) / FR) * ((k.Wo + FC - 1) / FC) * frags_m;
+      k.PH = PH;
+      k.tiles_y = (k.Ho + FR - 1) / FR;
+    }
+  }
+  if (!use_ksp) {                                      // pixel-split tile, double buffer
+    k = k_in;
+    if (best < 0 || best_blk < 256) return SCF_EUNSUPPORTED;
+    G = k.G4; KC = 8 * G;
+    if (KC) k.nchunk = (k.Cin + KC - 1) / KC;
+    WM = cand[best][0]; WN = cand[best][1];
+    nblk = best_blk;
+    ldsb = best_lds;
+    const int TR = WN * 4 * FR;
+    k.PH = (TR - 1) * k.stride + k.KH;
+    k.tiles_y = (k.Ho + TR - 1) / TR;
+    px4 = px4_large;
   }
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
   k.PWin = (FC - 1) * k.stride + k.KW;                       // input columns a tile needs
@@ -671,19 +680,7 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   if (dry_run) return SCF_OK;
 #define SCF_GO(...) return px4 ? launch_dma<__VA_ARGS__, true>(k, (int)nblk, ldsb, st)            \
                                : launch_dma<__VA_ARGS__, false>(k, (int)nblk, ldsb, st)
-  if (ksp) {
-    if (NST == 6) SCF_GO(1, 1, 6, true);
-    if (NST == 4) SCF_GO(1, 1, 4, true);
-    SCF_GO(1, 1, 2, true);
-  }
-  if (NST == 4) {
-    if (WM == 1) SCF_GO(1, 1, 4, false);
-    SCF_GO(2, 1, 4, false);
-  }
-  if (NST == 3) {
-    if (WM == 1) SCF_GO(1, 1, 3, false);
-    SCF_GO(2, 1, 3, false);
-  }
+  if (ksp) SCF_GO(1, 1, 2, true);
 #define SCF_CASE(M, Nn) if (WM == M && WN == Nn) SCF_GO(M, Nn, 2, false);
   SCF_CASE(2, 2) SCF_CASE(3, 1) SCF_CASE(2, 1) SCF_CASE(1, 1)
 #undef SCF_CASE
