@@ -181,6 +181,30 @@ def test_config4_full_size_480x640_12iters_batch8():
     assert torch.equal(fp[-1], f8[-1][perm.to(DEV)]) and torch.equal(op[-1], o8[-1][perm.to(DEV)])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,H,W', [(2, 136, 200), (1, 264, 328), (3, 96, 160)])
+def test_flow_refiner_at_ragged_sizes_vs_oracle(n, H, W):
+    """image sizes whose 1/8 maps are NOT whole numbers of tiles / fragments / float4 groups (17x25,
+    33x41; 12x20 as the aligned control): row-major pyramid levels, dword patch staging, ragged
+    convolution tiles, small-level lookups with odd maps -- every fallback of the layout- and
+    alignment-dependent fast paths, end to end against the oracle."""
+    m = scflow_amd.build_refiner(scflow_amd.raft_model_cfg(iters=3))
+    sd = scflow_amd.fill_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed=9)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(100 + H)
+    rend, real = torch.rand((n, 3, H, W), generator=g), torch.rand((n, 3, H, W), generator=g)
+    flows, occs = m.get_flow(rend.to(DEV), real.to(DEV))
+    assert flows[-1].shape == (n, 2, H, W) and occs[-1].shape == (n, 1, H, W)
+    with torch.no_grad():
+        fr, fl, hf, cf = oracle.extract_feat(rend, real, sd)
+        wf, wo = oracle.raft_decoder_mask(fr, fl, torch.zeros((n, 2, H // 8, W // 8)), hf, cf, sd, iters=3)
+    for it in range(3):
+        epe = oracle.end_point_error(flows[it].cpu(), wf[it])
+        assert epe <= 1e-3, f'{H}x{W} iter {it}: EPE {epe:.2e}'
+    _close(occs[-1], wo[-1], atol=2e-4, what='occlusion')
+
+
 # ------------------------------------------------ ground-truth flow generation (8(f) row 3)
 def test_oracle_gt_flow_matches_reference_fixture(golden_dir):
     g = np.load(os.path.join(golden_dir, 'gt_flow.npz'))
