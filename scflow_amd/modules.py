@@ -61,6 +61,7 @@ class HipModule(nn.Module):
         for m in self.modules():
             if isinstance(m, HipModule):
                 m.__dict__['_packed'] = None
+                m.__dict__.pop('_pack_refs', None)
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
@@ -75,23 +76,39 @@ class HipModule(nn.Module):
     def _pack(self):
         raise NotImplementedError
 
-    def _pack_sources(self):
-        """the tensors ``_pack`` reads (default: this module's own parameters and buffers and
-        those of its non-HipModule children, e.g. nn.Conv2d / norm leaves)."""
-        out = []
-        stack = [self]
+    def _pack_modules(self):
+        """the modules whose own parameters / buffers ``_pack`` reads (default: this module and its
+        non-HipModule descendants, e.g. nn.Conv2d / norm leaves)."""
+        out, stack = [], [self]
         while stack:
             m = stack.pop()
-            out.extend(m._parameters.values())
-            out.extend(m._buffers.values())
+            out.append(m)
             for c in m._modules.values():
-                if c is not None and (m is not self or not isinstance(c, HipModule)):
-                    if not isinstance(c, HipModule):
-                        stack.append(c)
-        return [t for t in out if t is not None]
+                if c is not None and not isinstance(c, HipModule):
+                    stack.append(c)
+        return out
+
+    def _pack_sources(self):
+        """the tensors ``_pack`` reads."""
+        return [t for m in self._pack_modules() for d in (m._parameters, m._buffers)
+                for t in d.values() if t is not None]
 
     def _pack_key(self):
-        return tuple((t.data_ptr(), t._version) for t in self._pack_sources())
+        # (registry dict, name) pairs are resolved once per module (the module TREE is fixed after
+        # construction); the tensors are looked up through them on every call, so a replaced
+        # Parameter object (load_state_dict(assign=True), setattr) is seen like an in-place edit
+        refs = self.__dict__.get('_pack_refs')
+        if refs is None:
+            if type(self)._pack_sources is not HipModule._pack_sources:       # composite modules name their sources
+                return tuple((t.data_ptr(), t._version) for t in self._pack_sources())
+            refs = self.__dict__['_pack_refs'] = [(d, n) for m in self._pack_modules()
+                                                  for d in (m._parameters, m._buffers) for n in d]
+        key = []
+        for d, n in refs:
+            t = d.get(n)
+            if t is not None:
+                key.append((t.data_ptr(), t._version))
+        return tuple(key)
 
     @property
     def packed(self):
@@ -383,15 +400,16 @@ class ConvGRU(HipModule):
         return [ops.conv2d(pk[0], c) for pk in self._ctx_packs(c.shape[1])]
 
     def forward_inplace(self, hx: Tensor, ctx: Optional[Sequence[Tensor]] = None,
-                        ctx_channels: int = 0) -> Tensor:
+                        ctx_channels: int = 0, scratch: Optional[Tensor] = None) -> Tensor:
         """hx: (N, h_ch + x_ch, h, w) = [h | x]; h is updated in place.  One C-ABI call
         (``scf_sepconv_gru``: the launch sequence lives in the library).  ``ctx`` =
         ``context_terms(hx[:, h_ch:h_ch + ctx_channels])`` of this pair: those channels are then
         not convolved again (``scf_sepconv_gru_ctx``)."""
         hc = self.h_channels
         n, _, h, w = hx.shape
-        z = torch.empty((n, hc, h, w), dtype=torch.float32, device=hx.device)
-        rh = torch.empty((n, hc, h, w), dtype=torch.float32, device=hx.device)
+        if scratch is None:          # (2, N, Ch, H, W): the z and r*h buffers (a caller's loop passes its own)
+            scratch = torch.empty((2, n, hc, h, w), dtype=torch.float32, device=hx.device)
+        z, rh = scratch[0], scratch[1]
         if ctx is None:
             ops.sepconv_gru(self.packed, hx, hc, z, rh)
         else:
@@ -572,16 +590,19 @@ class SCFlowDecoder(HipModule):
         # occlusion mask of the previous iteration (ones before the first: the 1/8 bilinear
         # down-sampling of a ones map, :188-190), used only with mask_flow / mask_corr
         mask = torch.ones((n, 1, h, w), **f32) if (self.mask_flow or self.mask_corr) else None
+        # scratch reused by every iteration (allocated once, before any fork point: the side branches
+        # write into cf; z / rh are the GRU's gate buffers)
+        cf = torch.empty((n, 256, h, w), **f32)
+        zbuf = torch.empty((2, n, hc, h, w), **f32)
         for _ in range(self.iters):
             flow_lr = ops.resize_bilinear(flow, (h, w), mul=1.0 / scale)           # :196-197
-            cf = torch.empty((n, 256, h, w), **f32)      # before the fork (the side branch writes it)
             flow_in = ops.mul_mask(flow_lr, mask) if self.mask_flow else flow_lr   # :203-204
             fork = ops.fork_point() if ov_flow else None    # the motion encoder's flow branch starts here
             corr = self.corr_lookup(pyramid, flow_lr, tiled_levels=tiled)          # :198
             if self.mask_corr:
                 ops.mul_mask(corr, mask, out=corr)                                 # :200-201
             self.encoder(corr, flow_in, out=hx[:, hc + cc:], overlap=ov_flow, cf=cf, fork=fork)   # :206
-            hv = self.gru.forward_inplace(hx, ctx, cc)                             # :207-208
+            hv = self.gru.forward_inplace(hx, ctx, cc, scratch=zbuf)               # :207-208
             ops.conv2d(self.packed, hv, out=heads, act=ACT_RELU)
             d_flow = self.flow_pred.predict(heads[:, :256])                        # :210
             mask = self.mask_pred.predict(heads[:, 256:], act=ACT_SIGMOID)         # :212-213
