@@ -55,7 +55,7 @@ enum {
  * SCF_ABI_MAJOR before its first call; structs additionally carry no size field,
  * so a mismatch must be refused, not worked around. */
 #define SCF_ABI_MAJOR 3
-#define SCF_VERSION (SCF_ABI_MAJOR * 100 + 1)
+#define SCF_VERSION (SCF_ABI_MAJOR * 100 + 2)
 int scf_version(void);
 const char* scf_error_string(int code);
 /* number of HIP devices visible (>=0) or SCF_ENODEVICE */
@@ -236,6 +236,69 @@ int scf_sepconv_gru(float* hx, int64_t hx_nstride, int N, int Ch, int Cx, int H,
 int scf_sepconv_gru_ctx(float* hx, int64_t hx_nstride, int N, int Ch, int Cc, int Cx, int H, int W,
                         const scf_gru_pass* passes, int npass, const float* const* ctx,
                         int64_t ctx_nstride, float* z, float* rh, scf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * One whole refinement iteration.           replaces the loop body of SCFlowDecoder.forward
+ *                                           models/decoder/scflow_decoder.py:196-243
+ * The launch sequence of an iteration -- 1/8 flow, lookup, motion encoder, SepConvGRU, flow / mask
+ * heads, delta-flow / mask encoders, full-resolution outputs, pose head, pose update, pose-induced
+ * flow: ~33 launches -- behind ONE call, so that a caller without hipGraph capture is bound by the
+ * launch API and not by its interpreter.  Nothing new is computed: every step is one of the
+ * operator entry points of this header, issued in a fixed order (results are bit-identical to
+ * issuing them one by one).  The caller fills the struct ONCE per decoder pass (all scratch buffers
+ * and convolution descriptors, weights in the packings of scf_conv_desc) and changes only the
+ * "per iteration" pointers between calls.  struct_size = sizeof(scf_scflow_iter) is checked.
+ * overlap_* (small batches): that branch is issued on side_stream between event fork / join points,
+ * beside the main stream's work; the call itself never synchronises (hipGraph-capturable).
+ * --------------------------------------------------------------------------------- */
+typedef struct scf_iter_gn {          /* GroupNorm(G, eps, affine) + ReLU after a pose-head convolution */
+  const float* gamma; const float* beta; float* out;
+  int32_t C, HW, G; float eps;
+} scf_iter_gn;
+
+typedef struct scf_scflow_iter {
+  int32_t struct_size;
+  int32_t N, H, W, h, w;                     /* batch; full-resolution and 1/8-resolution sizes        */
+  /* correlation pyramid (scf_corr_build_ex) and lookup */
+  int32_t L, radius; uint32_t tiled_levels; int32_t corr_channels;   /* L * (2 radius + 1)^2            */
+  const float* levels[SCF_MAX_LEVELS];
+  float* flow_lr;                            /* (N, 2, h, w) scratch                                    */
+  float* corr;                               /* (N, corr_channels, h, w) scratch                        */
+  /* decoder switches mask_flow / mask_corr (:199-205) */
+  int32_t mask_flow, mask_corr;
+  const float* mask_prev;                    /* (N, 1, h, w): previous iteration's mask (ones before the first) */
+  float* flow_masked;                        /* (N, 2, h, w) scratch, mask_flow only                    */
+  /* motion encoder (in / out pointers set; flow0.in0 is replaced by the call) */
+  scf_conv_desc flow0, flow1, corr0, corr1, outn;
+  float* flow_copy_dst;                      /* hx[:, Ch + Cc + 126 ...]: the 2 flow channels of x      */
+  /* SepConvGRU: hx = [h (Ch) | context (Cc) | motion features (Cx)] */
+  float* hx; int64_t hx_nstride; int32_t Ch, Cc, Cx, npass;
+  scf_gru_pass gru[2];
+  const float* ctx[2]; int64_t ctx_nstride;  /* hoisted context terms (scf_sepconv_gru_ctx) or NULLs    */
+  float* z; float* rh;
+  /* heads and their encoders */
+  scf_conv_desc heads, fpred, mpred, menc0, menc1, denc0, denc1;
+  /* pose head: 3 x (conv -> GroupNorm + ReLU), 2 FC layers, rotation / translation heads */
+  scf_conv_desc pose[3];
+  scf_iter_gn gn[3];
+  const float* fc1_w; const float* fc1_b; float* fc1_out; int32_t fc1_K, fc1_O;
+  const float* fc2_w; const float* fc2_b; float* fc2_out; int32_t fc2_O;
+  const float* rot_w; const float* rot_b; float* rot_all; int32_t rot_O;
+  const float* trans_w; const float* trans_b; float* trans_all; int32_t trans_O;
+  const int64_t* label; int32_t num_class, label_mode;
+  /* pose-induced flow */
+  const float* depth; const float* K; const float* R0; const float* t0; float invalid_flow_num;
+  /* ---- per iteration ---- */
+  const float* flow_in;                      /* (N, 2, H, W): the previous pose-induced flow (init_flow first) */
+  const float* R_in; const float* t_in;
+  float* flow_out; float* flow_pred; float* mask_up;       /* (N,2,H,W), (N,2,H,W), (N,1,H,W)           */
+  float* R_out; float* t_out; float* d_rot; float* d_trans;
+  /* ---- two-stream overlap ---- */
+  scf_stream_t side_stream; int32_t overlap_flow, overlap_mask, overlap_up;
+  void* lookup_timer;                        /* optional scf_timer_t (scflow_hip_prof.h) bound to the lookup launch */
+} scf_scflow_iter;
+
+int scf_scflow_iteration(const scf_scflow_iter* iter, scf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * InstanceNorm2d(eps, affine=False) [+ residual] [+ ReLU] over N*C planes of HW floats.

@@ -64,6 +64,43 @@ class GruPass(C.Structure):
     ]
 
 
+class IterGN(C.Structure):
+    """mirror of ``scf_iter_gn``."""
+    _fields_ = [('gamma', _fp), ('beta', _fp), ('out', _fp),
+                ('C', C.c_int32), ('HW', C.c_int32), ('G', C.c_int32), ('eps', C.c_float)]
+
+
+class ScflowIter(C.Structure):
+    """mirror of ``scf_scflow_iter`` (include/scflow_hip.h): one refinement iteration."""
+    _fields_ = [
+        ('struct_size', C.c_int32),
+        ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('h', C.c_int32), ('w', C.c_int32),
+        ('L', C.c_int32), ('radius', C.c_int32), ('tiled_levels', C.c_uint32), ('corr_channels', C.c_int32),
+        ('levels', _fp * MAX_LEVELS),
+        ('flow_lr', _fp), ('corr', _fp),
+        ('mask_flow', C.c_int32), ('mask_corr', C.c_int32), ('mask_prev', _fp), ('flow_masked', _fp),
+        ('flow0', ConvDesc), ('flow1', ConvDesc), ('corr0', ConvDesc), ('corr1', ConvDesc), ('outn', ConvDesc),
+        ('flow_copy_dst', _fp),
+        ('hx', _fp), ('hx_nstride', C.c_int64), ('Ch', C.c_int32), ('Cc', C.c_int32), ('Cx', C.c_int32),
+        ('npass', C.c_int32),
+        ('gru', GruPass * 2), ('ctx', _fp * 2), ('ctx_nstride', C.c_int64), ('z', _fp), ('rh', _fp),
+        ('heads', ConvDesc), ('fpred', ConvDesc), ('mpred', ConvDesc), ('menc0', ConvDesc), ('menc1', ConvDesc),
+        ('denc0', ConvDesc), ('denc1', ConvDesc),
+        ('pose', ConvDesc * 3), ('gn', IterGN * 3),
+        ('fc1_w', _fp), ('fc1_b', _fp), ('fc1_out', _fp), ('fc1_K', C.c_int32), ('fc1_O', C.c_int32),
+        ('fc2_w', _fp), ('fc2_b', _fp), ('fc2_out', _fp), ('fc2_O', C.c_int32),
+        ('rot_w', _fp), ('rot_b', _fp), ('rot_all', _fp), ('rot_O', C.c_int32),
+        ('trans_w', _fp), ('trans_b', _fp), ('trans_all', _fp), ('trans_O', C.c_int32),
+        ('label', _fp), ('num_class', C.c_int32), ('label_mode', C.c_int32),
+        ('depth', _fp), ('K', _fp), ('R0', _fp), ('t0', _fp), ('invalid_flow_num', C.c_float),
+        ('flow_in', _fp), ('R_in', _fp), ('t_in', _fp),
+        ('flow_out', _fp), ('flow_pred', _fp), ('mask_up', _fp),
+        ('R_out', _fp), ('t_out', _fp), ('d_rot', _fp), ('d_trans', _fp),
+        ('side_stream', _fp), ('overlap_flow', C.c_int32), ('overlap_mask', C.c_int32), ('overlap_up', C.c_int32),
+        ('lookup_timer', _fp),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/scflow_hip.h declares
 SIGNATURES = {
     'scf_version': (C.c_int, []),
@@ -98,6 +135,7 @@ SIGNATURES = {
     'scf_sepconv_gru_ctx': (C.c_int, [_fp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.POINTER(GruPass), C.c_int, C.POINTER(_fp),
                                       C.c_int64, _fp, _fp, _fp]),
+    'scf_scflow_iteration': (C.c_int, [C.POINTER(ScflowIter), _fp]),
     'scf_instance_norm': (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int, C.c_float, C.c_int, _fp]),
     'scf_group_norm_relu': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_float, _fp]),

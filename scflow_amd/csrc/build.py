@@ -5,7 +5,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['capi.hip', 'corr_lookup.hip', 'corr_gemm.hip', 'conv_mfma.hip', 'conv_f16x3.hip', 'conv_dma.hip', 'conv_thin.hip', 'conv_taps.hip', 'resample.hip', 'pose.hip',
+SOURCES = ['capi.hip', 'corr_lookup.hip', 'corr_gemm.hip', 'conv_mfma.hip', 'conv_f16x3.hip', 'conv_dma.hip', 'conv_thin.hip', 'conv_taps.hip', 'resample.hip', 'pose.hip', 'scflow_iter.hip',
            'norm.hip']
 OUT = os.path.join(HERE, 'libscflow_hip.so')
 

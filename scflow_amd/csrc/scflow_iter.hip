@@ -1,0 +1,136 @@
+// One whole refinement iteration of SCFlowDecoder.forward (models/decoder/scflow_decoder.py:196-243)
+// behind ONE C entry point: the launch sequence -- 1/8 flow, lookup, motion encoder, SepConvGRU,
+// flow / mask heads, delta-flow / mask encoders, full-resolution outputs, pose head, pose update,
+// pose-induced flow -- lives here instead of in the caller's interpreter.  Nothing new is computed:
+// every step is one of the library's own operator entry points, in the order and with the
+// two-stream overlap scflow_amd/modules.py uses (bit-identical results; tests/test_gpu_refiner.py).
+// At batch 1 an iteration is ~33 launches of a few microseconds each: sequenced from Python the pass
+// is bound by the interpreter (~10 us per launch), sequenced here by the launch API alone.
+#include "scf_common.h"
+
+namespace {
+
+// fork / join events of the optional side-stream branches: a small per-thread pool, created on first
+// use (timing disabled).  Re-recording an event after the wait that used it was enqueued is safe:
+// hipStreamWaitEvent captures the record that precedes it.
+struct IterEvents {
+  hipEvent_t ev[6];
+  bool ok = false;
+  bool init() {
+    if (ok) return true;
+    for (int i = 0; i < 6; ++i)
+      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
+    return ok = true;
+  }
+};
+IterEvents& iter_events() {
+  static thread_local IterEvents e;
+  return e;
+}
+
+#define SCF_TRY(call)                \
+  do {                               \
+    const int rc_ = (call);          \
+    if (rc_ != SCF_OK) return rc_;   \
+  } while (0)
+
+bool fork_to(hipStream_t from, hipStream_t to, hipEvent_t ev) {
+  return hipEventRecord(ev, from) == hipSuccess && hipStreamWaitEvent(to, ev, 0) == hipSuccess;
+}
+
+}  // namespace
+
+extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stream) {
+  if (!it) return SCF_EINVAL;
+  if (it->struct_size != (int32_t)sizeof(scf_scflow_iter)) return SCF_EINVAL;      // header / binding mismatch
+  if (!it->flow_in || !it->flow_out || !it->flow_pred || !it->mask_up || !it->flow_lr || !it->corr ||
+      !it->R_in || !it->t_in || !it->R_out || !it->t_out || !it->d_rot || !it->d_trans || !it->hx ||
+      it->N <= 0 || it->H <= 0 || it->W <= 0 || it->h <= 0 || it->w <= 0 || it->npass <= 0 || it->npass > 2)
+    return SCF_EINVAL;
+  if ((it->mask_flow || it->mask_corr) && !it->mask_prev) return SCF_EINVAL;
+  const bool any_overlap = it->overlap_flow || it->overlap_mask || it->overlap_up;
+  if (any_overlap && !it->side_stream) return SCF_EINVAL;
+  hipStream_t mainq = scf_stream(stream), sideq = scf_stream(it->side_stream);
+  IterEvents& E = iter_events();
+  if (any_overlap && !E.init()) return SCF_ELAUNCH;
+  const int N = it->N, hw = it->h * it->w;
+  const float scale = (float)it->H / (float)it->h;
+
+  // ---- 1/8-resolution flow (scflow_decoder.py:196-197) ----
+  SCF_TRY(scf_resize_bilinear(it->flow_in, nullptr, it->flow_lr, (int64_t)N * 2, it->H, it->W, it->h, it->w,
+                              1.0f / scale, stream));
+  const float* flow_enc = it->flow_lr;              // what the motion encoder sees (:203-206)
+  if (it->mask_flow) {
+    if (!it->flow_masked) return SCF_EINVAL;
+    SCF_TRY(scf_mul_mask(it->flow_lr, (int64_t)2 * hw, it->mask_prev, it->flow_masked, (int64_t)2 * hw, N, 2, hw, stream));
+    flow_enc = it->flow_masked;
+  }
+  if (it->overlap_flow && !fork_to(mainq, sideq, E.ev[0])) return SCF_ELAUNCH;
+  // ---- correlation lookup (:198) ----
+  if (it->lookup_timer) scf_timer_arm(it->lookup_timer);
+  const int rl = scf_corr_lookup_ex(it->levels, it->flow_lr, it->corr, N, it->h, it->w, it->radius, it->L,
+                                    it->tiled_levels, stream);
+  if (it->lookup_timer) scf_timer_arm(nullptr);
+  SCF_TRY(rl);
+  if (it->mask_corr)
+    SCF_TRY(scf_mul_mask(it->corr, (int64_t)it->corr_channels * hw, it->mask_prev, it->corr,
+                         (int64_t)it->corr_channels * hw, N, it->corr_channels, hw, stream));
+  // ---- motion encoder (raft_decoder.py:152-166): flow branch beside the correlation branch ----
+  {
+    scf_stream_t fq = it->overlap_flow ? it->side_stream : stream;
+    scf_conv_desc f0 = it->flow0;
+    f0.in0 = flow_enc;
+    SCF_TRY(scf_conv2d(&f0, fq));
+    SCF_TRY(scf_conv2d(&it->flow1, fq));
+    SCF_TRY(scf_conv2d(&it->corr0, stream));
+    SCF_TRY(scf_conv2d(&it->corr1, stream));
+    if (it->overlap_flow && !fork_to(sideq, mainq, E.ev[1])) return SCF_ELAUNCH;
+    SCF_TRY(scf_conv2d(&it->outn, stream));
+    SCF_TRY(scf_copy_strided(flow_enc, (int64_t)2 * hw, it->flow_copy_dst, it->hx_nstride, N, (int64_t)2 * hw, stream));
+  }
+  // ---- SepConvGRU (:207-208), context part hoisted ----
+  if (it->ctx[0])
+    SCF_TRY(scf_sepconv_gru_ctx(it->hx, it->hx_nstride, N, it->Ch, it->Cc, it->Cx, it->h, it->w, it->gru, it->npass,
+                                it->ctx, it->ctx_nstride, it->z, it->rh, stream));
+  else
+    SCF_TRY(scf_sepconv_gru(it->hx, it->hx_nstride, N, it->Ch, it->Cc + it->Cx, it->h, it->w, it->gru, it->npass,
+                            it->z, it->rh, stream));
+  // ---- heads (:210-213) and their encoders (:216-217) ----
+  SCF_TRY(scf_conv2d(&it->heads, stream));
+  SCF_TRY(scf_conv2d(&it->fpred, stream));
+  SCF_TRY(scf_conv2d(&it->mpred, stream));
+  {
+    scf_stream_t mq = it->overlap_mask ? it->side_stream : stream;
+    if (it->overlap_mask && !fork_to(mainq, sideq, E.ev[2])) return SCF_ELAUNCH;
+    SCF_TRY(scf_conv2d(&it->menc0, mq));
+    SCF_TRY(scf_conv2d(&it->menc1, mq));
+    SCF_TRY(scf_conv2d(&it->denc0, stream));
+    SCF_TRY(scf_conv2d(&it->denc1, stream));
+    if (it->overlap_mask && !fork_to(sideq, mainq, E.ev[3])) return SCF_ELAUNCH;
+  }
+  // ---- full-resolution outputs (:222-227): they feed nothing, beside the pose head ----
+  {
+    scf_stream_t uq = it->overlap_up ? it->side_stream : stream;
+    if (it->overlap_up && !fork_to(mainq, sideq, E.ev[4])) return SCF_ELAUNCH;
+    SCF_TRY(scf_resize_bilinear(it->flow_lr, it->fpred.out, it->flow_pred, (int64_t)N * 2, it->h, it->w, it->H, it->W,
+                                scale, uq));
+    SCF_TRY(scf_resize_bilinear(it->mpred.out, nullptr, it->mask_up, (int64_t)N, it->h, it->w, it->H, it->W, 1.0f, uq));
+  }
+  // ---- pose head (pose_head.py:201-211) ----
+  for (int i = 0; i < 3; ++i) {
+    SCF_TRY(scf_conv2d(&it->pose[i], stream));
+    const scf_iter_gn& g = it->gn[i];
+    SCF_TRY(scf_group_norm_relu(it->pose[i].out, g.gamma, g.beta, g.out, N, g.C, g.HW, g.G, g.eps, stream));
+  }
+  SCF_TRY(scf_linear(it->gn[2].out, it->fc1_w, it->fc1_b, it->fc1_out, N, it->fc1_K, it->fc1_O, SCF_ACT_RELU, stream));
+  SCF_TRY(scf_linear(it->fc1_out, it->fc2_w, it->fc2_b, it->fc2_out, N, it->fc1_O, it->fc2_O, SCF_ACT_RELU, stream));
+  SCF_TRY(scf_linear_pair(it->fc2_out, it->rot_w, it->rot_b, it->rot_all, it->rot_O, it->trans_w, it->trans_b,
+                          it->trans_all, it->trans_O, N, it->fc2_O, SCF_ACT_NONE, stream));
+  // ---- pose update (pose.py:124-169) and the pose-induced flow (pose.py:44-88) ----
+  SCF_TRY(scf_pose_update(it->rot_all, it->trans_all, it->label, it->num_class, it->label_mode, it->R_in, it->t_in,
+                          it->d_rot, it->d_trans, it->R_out, it->t_out, N, stream));
+  SCF_TRY(scf_reproject_flow(it->depth, it->K, it->R0, it->t0, it->R_out, it->t_out, it->flow_out, N, it->H, it->W,
+                             it->invalid_flow_num, stream));
+  if (it->overlap_up && !fork_to(sideq, mainq, E.ev[5])) return SCF_ELAUNCH;
+  return SCF_OK;
+}

@@ -547,6 +547,9 @@ class SCFlowDecoder(HipModule):
                                           ConvBlock(64, 32, 3, padding=1, act_cfg=act_cfg))
         self.tiled_pyramid = True     # decoder-internal pyramid layout (see _pyramid_layout)
         self.hoist_context = True     # GRU: convolve the (iteration-invariant) context channels once per pair
+        # the launch sequence of an iteration issued by ONE C call (scf_scflow_iteration) instead of
+        # ~33 Python-sequenced ones: same kernels, same order, same bits; False = sequence from here
+        self.c_iteration = True
 
     def _pack_sources(self):
         a, b = self.flow_pred.layers[0].conv, self.mask_pred.layers[0].conv
@@ -587,6 +590,9 @@ class SCFlowDecoder(HipModule):
         ctx = self.gru.context_terms(hx[:, hc:hc + cc]) if self.hoist_context else None
         # small batches: independent branches side by side
         ov_flow, ov_mask, ov_up = (ops.small_work(n, H, W, b) for b in ('flow', 'mask', 'upsample'))
+        if self.c_iteration and ops._CONV_EVENTS is None:
+            return self._forward_c(pyramid, tiled, hx, ctx, rot0, trans0, depth, internel_k, label, init_flow,
+                                   invalid_flow_num, (ov_flow, ov_mask, ov_up))
         # occlusion mask of the previous iteration (ones before the first: the 1/8 bilinear
         # down-sampling of a ones map, :188-190), used only with mask_flow / mask_corr
         mask = torch.ones((n, 1, h, w), **f32) if (self.mask_flow or self.mask_corr) else None
@@ -632,6 +638,130 @@ class SCFlowDecoder(HipModule):
             for lst, v in zip(outs, (flow, flow_pred, rot, trans, up_mask, d_rot, d_trans)):
                 lst.append(v)
         return outs
+
+
+def _scflow_forward_c(self, pyramid, tiled, hx, ctx, rot0, trans0, depth, internel_k, label, init_flow,
+                      invalid_flow_num, overlap):
+    """the refinement loop through ``scf_scflow_iteration``: every scratch buffer and convolution
+    descriptor of an iteration is set up ONCE per pass; an iteration is then a handful of pointer
+    updates and one C call.  Mirrors ``SCFlowDecoder.forward``'s Python-sequenced loop launch for
+    launch (``tests/test_gpu_refiner.py::test_c_iteration_is_bit_identical``)."""
+    from ._lib import ScflowIter
+    import ctypes as C
+    hc, cc = self.h_channels, self.cxt_channels
+    n, H, W = depth.shape
+    scale = 2 ** (self.num_levels - 1)
+    h, w = H // scale, W // scale
+    f32 = dict(dtype=torch.float32, device=depth.device)
+    iters = self.iters
+    E = lambda *shape: torch.empty(shape, **f32)
+    enc, ph = self.encoder, self.pose_pred
+    kch = self.num_levels * (2 * self.radius + 1) ** 2
+    # ---- scratch of one iteration (reused by all of them) ----
+    flow_lr, flow_m, corr = E(n, 2, h, w), (E(n, 2, h, w) if self.mask_flow else None), E(n, kch, h, w)
+    f1, c1, cf = E(n, 128, h, w), E(n, 256, h, w), E(n, 256, h, w)
+    zbuf, heads, dm = E(2, n, hc, h, w), E(n, 512, h, w), E(n, 96, h, w)
+    d_flow, mask, m1, d1 = E(n, 2, h, w), E(n, 1, h, w), E(n, 64, h, w), E(n, 128, h, w)
+    ones = torch.ones((n, 1, h, w), **f32) if (self.mask_flow or self.mask_corr) else None
+    hv, xm = hx[:, :hc], hx[:, hc + cc:]
+    # ---- outputs of all iterations: one buffer per kind, a view per iteration ----
+    flows, fpreds, masks = E(iters, n, 2, H, W), E(iters, n, 2, H, W), E(iters, n, 1, H, W)
+    rots, transs, drots, dtranss = E(iters, n, 3, 3), E(iters, n, 3), E(iters, n, 6), E(iters, n, 3)
+    it = ScflowIter()
+    it.struct_size = C.sizeof(ScflowIter)
+    it.N, it.H, it.W, it.h, it.w = n, H, W, h, w
+    it.L, it.radius, it.tiled_levels, it.corr_channels = len(pyramid), self.radius, int(tiled), kch
+    for l, lv in enumerate(pyramid):
+        it.levels[l] = lv.data_ptr()
+    it.flow_lr, it.corr = flow_lr.data_ptr(), corr.data_ptr()
+    it.mask_flow, it.mask_corr = int(self.mask_flow), int(self.mask_corr)
+    it.flow_masked = None if flow_m is None else flow_m.data_ptr()
+    keep = [pyramid, flow_lr, flow_m, corr, f1, c1, cf, zbuf, heads, dm, d_flow, mask, m1, d1, ones, hx, ctx]
+    cd = lambda blk, *a, **k: ops.conv_desc(blk.packed, *a, act=blk.act, **k)[0]
+    it.flow0 = cd(enc.flow_net[0], flow_lr, out=f1)
+    it.flow1 = cd(enc.flow_net[1], f1, out=cf[:, 192:])
+    it.corr0 = cd(enc.corr_net[0], corr, out=c1)
+    it.corr1 = cd(enc.corr_net[1], c1, out=cf[:, :192])
+    it.outn = cd(enc.out_net[0], cf, out=xm[:, :126])
+    it.flow_copy_dst = xm[:, 126:128].data_ptr()
+    it.hx, it.hx_nstride = hx.data_ptr(), hx.stride(0)
+    it.Ch, it.Cc, it.Cx = hc, cc, hx.shape[1] - hc - cc
+    if ctx is not None:
+        packs = [(pk[1], pk[2]) for pk in self.gru._ctx_packs(cc)]
+        for i, t in enumerate(ctx):
+            it.ctx[i] = t.data_ptr()
+        it.ctx_nstride = ctx[0].stride(0)
+    else:
+        packs = self.gru.packed
+    arr = ops.gru_passes(packs)
+    it.npass = len(packs)
+    for i in range(len(packs)):
+        it.gru[i] = arr[i]
+    it.z, it.rh = zbuf[0].data_ptr(), zbuf[1].data_ptr()
+    it.heads = ops.conv_desc(self.packed, hv, out=heads, act=ACT_RELU)[0]
+    it.fpred = ops.conv_desc(self.flow_pred.packed, heads[:, :256], out=d_flow)[0]
+    it.mpred = ops.conv_desc(self.mask_pred.packed, heads[:, 256:], out=mask, act=ACT_SIGMOID)[0]
+    it.menc0 = cd(self.mask_encoder[0], mask, out=m1)
+    it.menc1 = cd(self.mask_encoder[1], m1, out=dm[:, 64:])
+    it.denc0 = cd(self.delta_flow_encoder[0], d_flow, out=d1)
+    it.denc1 = cd(self.delta_flow_encoder[1], d1, out=dm[:, :64])
+    # ---- pose head ----
+    x0, x1 = hv, dm
+    for i, blk in enumerate(ph.conv_layers):
+        if blk.groups is None or blk.act != ACT_RELU:
+            raise NotImplementedError('pose head: conv + GroupNorm + ReLU blocks')
+        d_, y = ops.conv_desc(blk.packed, x0, x1)
+        g = torch.empty_like(y)
+        it.pose[i] = d_
+        it.gn[i].gamma, it.gn[i].beta, it.gn[i].out = blk.gn.weight.data_ptr(), blk.gn.bias.data_ptr(), g.data_ptr()
+        it.gn[i].C, it.gn[i].HW, it.gn[i].G, it.gn[i].eps = y.shape[1], y.shape[2] * y.shape[3], blk.groups, blk.gn.eps
+        keep += [y, g]
+        x0, x1 = g, None
+    fc1, fc2 = ph.fc_layers[0][0], ph.fc_layers[1][0]
+    if fc1.in_features != x0[0].numel():
+        raise _lib_error(f'pose head expects {fc1.in_features} features, the maps give {x0[0].numel()}')
+    y1, y2 = E(n, fc1.out_features), E(n, fc2.out_features)
+    ra, ta = E(n, ph.rotation_pred.out_features), E(n, ph.translation_pred.out_features)
+    keep += [y1, y2, ra, ta]
+    P = lambda t: None if t is None else t.data_ptr()
+    it.fc1_w, it.fc1_b, it.fc1_out, it.fc1_K, it.fc1_O = P(fc1.weight), P(fc1.bias), y1.data_ptr(), fc1.in_features, fc1.out_features
+    it.fc2_w, it.fc2_b, it.fc2_out, it.fc2_O = P(fc2.weight), P(fc2.bias), y2.data_ptr(), fc2.out_features
+    it.rot_w, it.rot_b, it.rot_all, it.rot_O = P(ph.rotation_pred.weight), P(ph.rotation_pred.bias), ra.data_ptr(), ra.shape[1]
+    it.trans_w, it.trans_b, it.trans_all, it.trans_O = (P(ph.translation_pred.weight), P(ph.translation_pred.bias),
+                                                        ta.data_ptr(), ta.shape[1])
+    if not label.is_cuda or label.dtype != torch.int64 or not label.is_contiguous():
+        raise _lib_error('label must be a contiguous int64 GPU tensor')
+    it.label, it.num_class, it.label_mode = label.data_ptr(), ph.num_class, ph.label_mode
+    for name, t in (('depth', depth), ('internel_k', internel_k), ('ref_rotation', rot0), ('ref_translation', trans0),
+                    ('init_flow', init_flow)):
+        ops._dense(t, name)
+    it.depth, it.K, it.R0, it.t0 = depth.data_ptr(), internel_k.data_ptr(), rot0.data_ptr(), trans0.data_ptr()
+    it.invalid_flow_num = float(invalid_flow_num)
+    it.overlap_flow, it.overlap_mask, it.overlap_up = (int(b) for b in overlap)
+    it.side_stream = ops.side_stream_handle() if any(overlap) else None
+    outs = ([], [], [], [], [], [], [])
+    flow, rot, trans = init_flow, rot0, trans0
+    for i in range(iters):
+        it.flow_in, it.R_in, it.t_in = flow.data_ptr(), rot.data_ptr(), trans.data_ptr()
+        it.mask_prev = None if ones is None else (ones if i == 0 else mask).data_ptr()
+        flow, rot, trans = flows[i], rots[i], transs[i]
+        it.flow_out, it.flow_pred, it.mask_up = flow.data_ptr(), fpreds[i].data_ptr(), masks[i].data_ptr()
+        it.R_out, it.t_out, it.d_rot, it.d_trans = rot.data_ptr(), trans.data_ptr(), drots[i].data_ptr(), dtranss[i].data_ptr()
+        ops.scflow_iteration(it)
+        for lst, v in zip(outs, (flow, fpreds[i], rot, trans, masks[i], drots[i], dtranss[i])):
+            lst.append(v)
+    if any(overlap):          # the scratch is freed on return: the side stream's last reads are joined already
+        pass
+    del keep
+    return outs
+
+
+def _lib_error(msg):
+    from ._lib import ScflowHipError
+    return ScflowHipError(msg)
+
+
+SCFlowDecoder._forward_c = _scflow_forward_c
 
 
 class _RAFTDecoderBase(HipModule):

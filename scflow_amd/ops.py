@@ -25,7 +25,7 @@ from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_GRU_Q, CONV_G
 
 Tensor = torch.Tensor
 
-__all__ = ['PackedConv', 'pyramid_layout', 'untile_level', 'level_storage_shape', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision',
+__all__ = ['PackedConv', 'conv_desc', 'gru_passes', 'scflow_iteration', 'side_stream_handle', 'pyramid_layout', 'untile_level', 'level_storage_shape', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision',
            'get_conv_precision', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
            'instance_norm', 'group_norm_relu', 'linear', 'pose_update', 'reproject_flow',
            'unproject_depth', 'linear_pair', 'resize_bilinear', 'convex_upsample', 'avgpool2x2', 'copy_channels',
@@ -355,10 +355,17 @@ def _desc_template(pc: 'PackedConv') -> ConvDesc:
     return d
 
 
+def conv_desc(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optional[Tensor] = None,
+              **kw) -> Tuple[ConvDesc, Tensor]:
+    """the filled ``scf_conv_desc`` of ``conv2d(pc, x0, x1, out, **kw)`` WITHOUT launching it, and the
+    output tensor: for entry points that take whole descriptors (``scf_scflow_iteration``)."""
+    return conv2d(pc, x0, x1, out, _launch=False, **kw)
+
+
 def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optional[Tensor] = None,
            *, res: Optional[Tensor] = None, act: int = ACT_NONE, act2: int = ACT_NONE,
            act_split: int = 0, mode: int = CONV_PLAIN, gru_h: Optional[Tensor] = None,
-           gru_aux: Optional[Tensor] = None, gru_z: Optional[Tensor] = None) -> Tensor:
+           gru_aux: Optional[Tensor] = None, gru_z: Optional[Tensor] = None, _launch: bool = True):
     """implicit-GEMM MFMA convolution with fused epilogue (scf_conv2d).
     input = channel concat of x0 and x1; ``out`` may be a channel slice."""
     p0, n, c0, h, w, s0 = _nchw(x0, 'x0')
@@ -425,6 +432,8 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
             pc.plans[key] = use_alt
         if use_alt:
             d.wp, d.KC = pc.wp_alt.data_ptr(), 32
+    if not _launch:
+        return d, out
     if _CONV_EVENTS is not None:        # bench.py: a timer bound to this launch + algorithmic flops
         lib = _lib.load()
         tm = C.c_void_p()
@@ -460,6 +469,28 @@ def _gru_passes(packs):
         if pzr.wp4s is not None and pq.wp4s is not None and pzr.g4s == pq.g4s:
             g.wp_zr_a4s, g.wp_q_a4s, g.a4s_groups = pzr.wp4s.data_ptr(), pq.wp4s.data_ptr(), pzr.g4s
     return arr
+
+
+gru_passes = _gru_passes
+
+
+def side_stream_handle() -> int:
+    """raw handle of the side stream that belongs to (current device, current stream) -- the stream
+    ``side_stream`` blocks run on; created on first use."""
+    main = torch.cuda.current_stream()
+    key = (torch.cuda.current_device(), main.cuda_stream)
+    side = _SIDE.get(key)
+    if side is None:
+        side = _SIDE[key] = torch.cuda.Stream(device=key[0])
+    return side.cuda_stream
+
+
+def scflow_iteration(it: '_lib.ScflowIter') -> None:
+    """one refinement iteration through ``scf_scflow_iteration`` (the struct is filled by
+    ``SCFlowDecoder``).  With lookup timing enabled (bench.py) the lookup launch carries a timer."""
+    lib = _lib.load()
+    it.lookup_timer = _LOOKUP_TIMERS.take() if _LOOKUP_TIMERS is not None else None
+    _lib.check(lib.scf_scflow_iteration(C.byref(it), _stream()), 'scf_scflow_iteration')
 
 
 def sepconv_gru(packs, hx: Tensor, h_channels: int, z: Tensor, rh: Tensor,

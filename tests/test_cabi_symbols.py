@@ -56,15 +56,16 @@ def test_conv_desc_layout_matches_c():
     """sizeof(scf_conv_desc) from a C compile must equal the ctypes mirror."""
     import ctypes, subprocess, tempfile
     src = ('#include "scflow_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu\\n", '
-           'sizeof(scf_conv_desc), sizeof(scf_gru_pass));return 0;}\n')
+           'sizeof(scf_conv_desc), sizeof(scf_gru_pass));printf("%zu %zu\\n", sizeof(scf_scflow_iter), sizeof(scf_iter_gn));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, 't.c')
         open(c, 'w').write(src)
         exe = os.path.join(d, 't')
         subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe], check=True)
-        size, gsize = map(int, subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split())
+        size, gsize, isize, nsize = map(int, subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split())
     assert size == ctypes.sizeof(_lib.ConvDesc)
     assert gsize == ctypes.sizeof(_lib.GruPass)
+    assert isize == ctypes.sizeof(_lib.ScflowIter) and nsize == ctypes.sizeof(_lib.IterGN)
 
 
 def test_c_weight_packers_match_host_packers():

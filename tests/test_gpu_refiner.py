@@ -271,6 +271,33 @@ def test_checkpoint_file_to_hip_refiner_vs_oracle(golden_dir, tmp_path):
     close(got[3][-1], want[3][-1], atol=1e-2, rtol=2e-5, what='translation after checkpoint ingestion')
 
 
+@pytest.mark.parametrize('n,masked,hoist', [(1, False, True), (3, False, True), (2, True, True), (1, False, False), (5, True, False)])
+def test_c_iteration_is_bit_identical(golden_dir, n, masked, hoist):
+    """scf_scflow_iteration (one C call per refinement iteration, the default) issues the same
+    launches in the same order as the Python-sequenced loop: every output of every iteration is the
+    same bits, with and without the small-batch two-stream overlap, the mask switches and the
+    hoisted GRU context."""
+    cfg = scflow_amd.scflow_model_cfg(iters=3)
+    cfg['decoder'].update(mask_flow=masked, mask_corr=masked)
+    m = scflow_amd.build_refiner(cfg)
+    m.load_state_dict(scflow_amd.fill_state_dict(_shapes(golden_dir), seed=0), strict=True)
+    m = m.to(DEV)
+    m.decoder.hoist_context = hoist
+    d = {k: v.to(DEV) for k, v in scflow_amd.make_inputs(n, 256, 256, seed=40 + n).items()}
+    run = lambda: m.get_pose(d['render_images'], d['real_images'], d['ref_rotation'], d['ref_translation'],
+                             d['depth'], d['internel_k'], d['label'])
+    assert m.decoder.c_iteration
+    a = run()
+    a2 = run()
+    m.decoder.c_iteration = False
+    b = run()
+    torch.cuda.synchronize()
+    for sa, sa2, sb in zip(a, a2, b):
+        assert len(sa) == len(sb) == 3
+        for ta, ta2, tb in zip(sa, sa2, sb):
+            assert ta.shape == tb.shape and torch.equal(ta, tb) and torch.equal(ta, ta2)
+
+
 def test_non_contiguous_images_at_batch_1(golden_dir, model):
     """ADVICE r2: at small batches the context encoder runs on a side stream from a fork point;
     a non-contiguous render_images must be materialised BEFORE that point.  Same bits as the
