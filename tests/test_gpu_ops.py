@@ -261,6 +261,9 @@ DMA_CASES = [
     (8, 128, 128, (3, 3), (1, 1), 60, 80),          # Wo = 80: 16-column fragments (5 x 16 instead of 3 x 32)
     (8, 64, 96, (5, 1), (2, 0), 28, 40),            # Wo = 40: 8-column fragments, 4 rows per fragment
     (8, 96, 64, (3, 3), (1, 1), 120, 160, 2),       # stride 2 onto a 60 x 80 map
+    (32, 64, 32, (3, 3), (1, 1), 32, 32),           # small grid (256 pixel-split blocks): K-split tile, 1024 blocks
+    (48, 48, 32, (3, 3), (1, 1), 25, 32),           # the same with an odd number of rows
+    (40, 40, 64, (1, 5), (0, 2), 18, 24),           # K-split with 16-channel chunks of a 1x5 layer, Wo = 24
 ]
 
 
