@@ -28,9 +28,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SCF_DMA_WU 7    // weight float4 per thread per chunk
 #define SCF_DMA_PU_KSP 24   // K-split tile (small grids: 32-channel chunks, one wave per SIMD: registers are free)
 #define SCF_DMA_WU_KSP 9
-#ifndef SCF_PX4_MODE
-#define SCF_PX4_MODE 3      // bit 0: full-grid tiles, bit 1: small-grid tiles (lab builds vary this)
-#endif
+#define SCF_PX4_MODE 3      // aligned-x4 patch staging: bit 0 full-grid tiles, bit 1 small-grid tiles
 #define SCF_DMA_PU_X4 8     // PX4: float4 patch cells per thread per chunk (256 * 8 * 4 floats)
 #define SCF_DMA_LDS_MAX (80 * 1024)   // two blocks per CU (160 KB)
 
@@ -118,25 +116,10 @@ __device__ __forceinline__ int fast_div(int e, int d, float rd) {
   return q;
 }
 
-#ifdef SCF_CONV_TRACE      /* lab builds only (tools/lab/conv_trace*.py): s_memrealtime stamps of the first blocks */
-__device__ unsigned long long* scf_conv_trace_ptr = nullptr;
-__device__ int scf_conv_trace_nblk = 0;
-extern "C" int scf_conv_trace_set(unsigned long long* p, int nblk) {
-  if (hipMemcpyToSymbol(HIP_SYMBOL(scf_conv_trace_nblk), &nblk, sizeof(nblk)) != hipSuccess) return -3;
-  return hipMemcpyToSymbol(HIP_SYMBOL(scf_conv_trace_ptr), &p, sizeof(p)) == hipSuccess ? 0 : -3;
-}
-// [block][wave][128]: slot 0 entry, 1 setup, 2 prologue, 3 end, 4 + 4c.. chunk c (wait, barrier, stage, mfma),
-// slot 127 = HW_ID | XCC_ID << 32
-#define CTRACE(slot)                                                                              \
-  do {                                                                                            \
-    if (scf_conv_trace_ptr && (int)blockIdx.x < scf_conv_trace_nblk && (threadIdx.x & 63) == 0 && (slot) < 125) { \
-      unsigned long long* tp_ = scf_conv_trace_ptr + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 128; \
-      tp_[slot] = __builtin_amdgcn_s_memrealtime();                                               \
-      if ((slot) == 0 || (slot) == 3) tp_[(slot) == 0 ? 125 : 126] = __builtin_readcyclecounter();  /* shader clock */ \
-      if ((slot) == 0) tp_[127] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) | \
-                                  ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32); \
-    }                                                                                             \
-  } while (0)
+// tools/lab/conv_trace*.py build this file with a per-chunk timeline (tools/lab/conv_lab_hooks.h);
+// the product build sees an empty hook.
+#ifdef SCF_CONV_LAB
+#include "../../tools/lab/conv_lab_hooks.h"
 #else
 #define CTRACE(slot) do { } while (0)
 #endif
@@ -605,9 +588,6 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
     }
   }
   const bool large = best >= 0 && best_blk >= slots;
-#ifdef SCF_NO_SMALL_GRID           /* experiment builds only: round-1 behaviour */
-  if (best < 0 || best_blk < 256 || k.T == 1) return SCF_EUNSUPPORTED;
-#endif
   // dense 1x1 on a full grid: stride 1 runs here since the aligned-x4 staging (90 vs 78 TF/s for the
   // register-staged KC = 32 kernel); stride 2 would stage four times the columns it uses
   if (k.T == 1 && large && (k.stride != 1 || !px4_large)) return SCF_EUNSUPPORTED;

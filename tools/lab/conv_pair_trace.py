@@ -1,4 +1,4 @@
-"""Timelines of ALL blocks of one full-grid convolution launch (library built with -DSCF_CONV_TRACE):
+"""Timelines of ALL blocks of one full-grid convolution launch (library built with -DSCF_CONV_LAB):
 which blocks share a CU (HW_ID / XCC_ID), and for how much of the kernel neither of the two waves
 that share a SIMD is inside its MFMA phase (matrix pipe necessarily idle)."""
 import sys, os, ctypes as C, torch, collections

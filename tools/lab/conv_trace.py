@@ -1,7 +1,7 @@
 """Per-chunk timeline of the small-grid (K-split) convolution kernel: block 0's four waves stamp
 s_memrealtime (10 ns) at entry, after setup, after the prologue staging, and per chunk after the
 vmcnt wait / the barrier / the staging of chunk c+NST-1 / the MFMA phase.  Needs the library built
-with -DSCF_CONV_TRACE (tools/lab/build_exp.sh)."""
+with -DSCF_CONV_LAB (tools/lab/build_exp.sh)."""
 import sys, os, ctypes as C, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from scflow_amd import ops, _lib

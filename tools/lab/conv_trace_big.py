@@ -1,5 +1,5 @@
 """Per-chunk timeline of the full-grid (pixel-split) convolution tiles at batch 32: block 0's four
-waves (see conv_trace.py).  Needs the library built with -DSCF_CONV_TRACE."""
+waves (see conv_trace.py).  Needs the library built with -DSCF_CONV_LAB."""
 import sys, os, ctypes as C, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from scflow_amd import ops, _lib
