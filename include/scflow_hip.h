@@ -55,7 +55,7 @@ enum {
  * SCF_ABI_MAJOR before its first call; structs additionally carry no size field,
  * so a mismatch must be refused, not worked around. */
 #define SCF_ABI_MAJOR 3
-#define SCF_VERSION (SCF_ABI_MAJOR * 100 + 2)
+#define SCF_VERSION (SCF_ABI_MAJOR * 100 + 3)
 int scf_version(void);
 const char* scf_error_string(int code);
 /* number of HIP devices visible (>=0) or SCF_ENODEVICE */
@@ -170,6 +170,11 @@ typedef struct scf_conv_desc {
                                            row k = ci * KH*KW + t, Kp = Cin*KH*KW rounded up to a multiple of
                                            8, zero padded; selects the kernel that contracts over taps x channels
                                            as one dense K dimension                                  */
+  const float* wp_a4t;                  /* optional: the a4 packing with a4t_groups = 4 (32-channel chunks) for
+                                           3x3 layers, used on TINY grids (no more K-split blocks than CUs:
+                                           every block is alone on its CU, a launch is a chain of one memory
+                                           round trip per chunk, so half as many chunks is half the chain)    */
+  int32_t a4t_groups;
 } scf_conv_desc;
 
 int scf_conv2d(const scf_conv_desc* desc, scf_stream_t stream);
@@ -218,6 +223,7 @@ typedef struct scf_gru_pass {
   const void* wp_zr_f16; const void* wp_q_f16;
   const float* wp_zr_k32; const float* wp_q_k32;
   const float* wp_zr_a4s; const float* wp_q_a4s; int32_t a4s_groups;
+  const float* wp_zr_a4t; const float* wp_q_a4t; int32_t a4t_groups;   /* 3x3 passes: tiny-grid packings (scf_conv_desc.wp_a4t), optional */
 } scf_gru_pass;
 
 int scf_sepconv_gru(float* hx, int64_t hx_nstride, int N, int Ch, int Cx, int H, int W,

@@ -49,6 +49,8 @@ class ConvDesc(C.Structure):
         ('wp_thin', _fp),
         ('out_tile8x4', C.c_int32),
         ('wp_taps', _fp),
+        ('wp_a4t', _fp),
+        ('a4t_groups', C.c_int32),
     ]
 
 
@@ -61,6 +63,7 @@ class GruPass(C.Structure):
         ('wp_zr_f16', _fp), ('wp_q_f16', _fp),
         ('wp_zr_k32', _fp), ('wp_q_k32', _fp),
         ('wp_zr_a4s', _fp), ('wp_q_a4s', _fp), ('a4s_groups', C.c_int32),
+        ('wp_zr_a4t', _fp), ('wp_q_a4t', _fp), ('a4t_groups', C.c_int32),
     ]
 
 

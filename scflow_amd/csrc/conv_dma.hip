@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel
   CTRACE(3);
 }
 
-#define SCF_DMA_LDS_DEEP (144 * 1024)  // deep rings on small grids: one block per CU
+#define SCF_DMA_LDS_DEEP (144 * 1024)  // tiny grids (one block per CU): 32-channel chunks of 3x3 layers
 
 template <int WM, int WN, int NST = 2, bool KSP = false, bool PX4 = false>
 static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
@@ -511,7 +511,7 @@ static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st
     if (!(raised.load(std::memory_order_relaxed) & bit)) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WM, WN, NST, KSP, PX4>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                              NST == 2 ? SCF_DMA_LDS_MAX : SCF_DMA_LDS_DEEP) != hipSuccess)
+                              (NST == 2 && !KSP) ? SCF_DMA_LDS_MAX : SCF_DMA_LDS_DEEP) != hipSuccess)
         return SCF_ELAUNCH;
       raised.fetch_or(bit, std::memory_order_relaxed);
     }
@@ -609,8 +609,18 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   // batch 8 8.95 -> 8.14; the 4- and 6-deep rings of round 2 lost at every batch size).
   bool use_ksp = !large;
   const ConvK k_in = k;
+  const long long ksp_blk = (long long)N * ((k.Ho + FR - 1) / FR) * ((k.Wo + FC - 1) / FC) * frags_m;
+  // TINY grids (no more blocks than CUs: every block alone on its CU): a launch is a chain of one
+  // memory round trip per staged chunk (~1.8 us each, whatever the arithmetic: 17 us for a 128 -> 128
+  // 3x3 onto a 4 x 4 map), so 3x3 layers take 32-channel chunks there when the caller provides that
+  // packing -- half the chunks, half the chain (batch 1: 256 -> 192 29.8 -> 21.5 us, pose-head convs
+  // 17 -> 13.7 us).  With more blocks than CUs the 100 KB stages would cost the co-residency that
+  // small grids live on (128 -> 512 at batch 1: 19.4 -> 23.5 us): those keep 16-channel chunks.
+  const bool tiny = ksp_blk <= scf_cu_count() && k.wp4t && k.G4t == 4 && !(k.in1 && (k.C0 % 32) != 0);
   if (use_ksp) {
-    if (k.wp4s && (k.G4s == 1 || k.G4s == 2 || k.G4s == 4) && !(k.in1 && (k.C0 % (8 * k.G4s)) != 0)) {
+    if (tiny) {
+      k.wp4 = k.wp4t; k.G4 = k.G4t;
+    } else if (k.wp4s && (k.G4s == 1 || k.G4s == 2 || k.G4s == 4) && !(k.in1 && (k.C0 % (8 * k.G4s)) != 0)) {
       k.wp4 = k.wp4s; k.G4 = k.G4s;                    // the small-grid packing: bigger chunks
     } else if (!pix_ok) {
       use_ksp = false;
@@ -627,11 +637,11 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
     ldsb = stage_b * 2;
     if (ldsb < 16 * 1024) ldsb = 16 * 1024;            // cross-wave reduction area
     if (PE > (px4 ? 1024 * SCF_DMA_PU_X4 : 256 * SCF_DMA_PU_KSP) || WF4 > 256 * SCF_DMA_WU_KSP ||
-        ldsb > SCF_DMA_LDS_MAX) {
+        ldsb > (tiny ? SCF_DMA_LDS_DEEP : SCF_DMA_LDS_MAX)) {
       use_ksp = false;
     } else {
       ksp = true;
-      nblk = (long long)N * ((k.Ho + FR - 1) / FR) * ((k.Wo + FC - 1) / FC) * frags_m;
+      nblk = ksp_blk;
       k.PH = PH;
       k.tiles_y = (k.Ho + FR - 1) / FR;
     }

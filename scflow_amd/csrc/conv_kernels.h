@@ -12,6 +12,7 @@ struct ConvK {
   const float* wthin;               // [Cin][T][CO] packing (conv_thin.hip) or nullptr
   const float* wp4; int G4, Mld4;   // LDS-DMA packing (conv_dma.hip) or nullptr
   const float* wp4s; int G4s;       // its small-grid variant (more channels per chunk) or nullptr
+  const float* wp4t; int G4t;       // tiny-grid variant for 3x3 layers (32-channel chunks) or nullptr
   int Mld, Cout, Krows;
   int KH, KW, T, stride, pad_h, pad_w, KC, nchunk;
   int fc_log2, tiles_x, tiles_y, mblocks, PH, PW, PWin;

@@ -425,6 +425,7 @@ static int conv_plan(const scf_conv_desc* d, ConvPlan* plan) {
   k.wthin = d->wp_thin;
   k.wp4 = d->wp_a4; k.G4 = d->a4_groups; k.Mld4 = d->a4_mld;
   k.wp4s = d->wp_a4s; k.G4s = d->a4s_groups;
+  k.wp4t = d->wp_a4t; k.G4t = d->a4t_groups;
   k.out_tile = d->out_tile8x4;
   k.KH = d->KH; k.KW = d->KW; k.T = d->KH * d->KW; k.stride = d->stride;
   k.pad_h = d->pad_h; k.pad_w = d->pad_w; k.KC = d->KC;
@@ -625,6 +626,7 @@ static int sepconv_gru_impl(float* hx, int64_t hx_nstride, int N, int Ch, int Cs
     d.Mld = (2 * Ch + 31) / 32 * 32; d.Cout = 2 * Ch; d.bias = g.bias_zr;
     d.wp_a4 = g.wp_zr_a4; d.a4_groups = g.a4_groups; d.a4_mld = d.Mld; d.wp_f16 = g.wp_zr_f16;
     d.wp_a4s = g.wp_zr_a4s; d.a4s_groups = g.a4s_groups;
+    d.wp_a4t = g.wp_zr_a4t; d.a4t_groups = g.a4t_groups;
     d.out = z; d.out_nstride = Ch * hw;
     d.mode = SCF_CONV_GRU_ZR; d.gru_h = hx; d.gru_h_nstride = hx_nstride;
     d.gru_aux = rh; d.gru_aux_nstride = Ch * hw;
@@ -638,6 +640,7 @@ static int sepconv_gru_impl(float* hx, int64_t hx_nstride, int N, int Ch, int Cs
     d.Mld = (Ch + 31) / 32 * 32; d.Cout = Ch; d.bias = g.bias_q;
     d.wp_a4 = g.wp_q_a4; d.a4_mld = d.Mld; d.wp_f16 = g.wp_q_f16;
     d.wp_a4s = g.wp_q_a4s;
+    d.wp_a4t = g.wp_q_a4t;
     d.out = hx; d.out_nstride = hx_nstride;
     d.mode = SCF_CONV_GRU_Q; d.gru_h = hx; d.gru_h_nstride = hx_nstride;
     d.gru_aux = nullptr; d.gru_aux_nstride = 0;

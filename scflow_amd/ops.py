@@ -218,6 +218,13 @@ def choose_a4s_groups(cin: int, kh: int, kw: int, stride: int) -> int:
     return 4 if t <= 5 else 2
 
 
+def choose_a4t_groups(cin: int, kh: int, kw: int, stride: int) -> int:
+    """TINY-grid a4 packing (no more K-split blocks than CUs): 32-channel chunks for the 3x3 layers,
+    whose small-grid packing has 16 (0: the layer has none)."""
+    t = kh * kw
+    return 4 if (stride in (1, 2) and cin >= 32 and 5 < t < 25) else 0
+
+
 def pack_conv_weight_a4(weight: Tensor, groups: int) -> Tuple[Tensor, int]:
     """(Cout, Cin, KH, KW) -> [chunk][tap][g][h][Mld][4] (conv_dma.hip): channel
     chunk*8G + 8g + 2s + h at float s of cell (g, h); zero-padded channels and couts."""
@@ -302,6 +309,8 @@ class PackedConv:
     g4s: int = 0
     wtaps: Optional[Tensor] = None    # [Cin*T][Mld] packing (Cin <= 4: contraction over taps)
     desc: Optional[ConvDesc] = None   # scf_conv_desc with this layer's own fields filled (built lazily)
+    wp4t: Optional[Tensor] = None     # tiny-grid LDS-DMA packing of 3x3 layers (32-channel chunks)
+    g4t: int = 0
 
     @staticmethod
     def from_weight(weight: Tensor, bias: Optional[Tensor], stride: int = 1,
@@ -329,7 +338,13 @@ class PackedConv:
         return PackedConv(wp, None if bias is None else bias.float().contiguous(), scale, shift,
                           cin, cout, kh, kw, stride, ph, pw, kc, mld, wp_alt, {}, wp16, wp4, g4,
                           pack_conv_weight_thin(weight) if (cout <= 4 and stride == 1 and cin >= 32) else None,
-                          wp4s, g4s, pack_conv_weight_taps(weight) if (cin <= 4 and dma_packing) else None)
+                          wp4s, g4s, pack_conv_weight_taps(weight) if (cin <= 4 and dma_packing) else None,
+                          None, *PackedConv._tiny(weight, kh, kw, stride, dma_packing))
+
+    @staticmethod
+    def _tiny(weight, kh, kw, stride, dma_packing):
+        g = choose_a4t_groups(weight.shape[1], kh, kw, stride) if dma_packing else 0
+        return (pack_conv_weight_a4(weight, g)[0] if g else None), g
 
     def out_hw(self, h: int, w: int) -> Tuple[int, int]:
         return ((h + 2 * self.pad_h - self.kh) // self.stride + 1,
@@ -352,6 +367,8 @@ def _desc_template(pc: 'PackedConv') -> ConvDesc:
         d.wp_a4, d.a4_groups, d.a4_mld = pc.wp4.data_ptr(), pc.g4, pc.mld
     if pc.wp4s is not None:
         d.wp_a4s, d.a4s_groups, d.a4_mld = pc.wp4s.data_ptr(), pc.g4s, pc.mld
+    if pc.wp4t is not None:
+        d.wp_a4t, d.a4t_groups, d.a4_mld = pc.wp4t.data_ptr(), pc.g4t, pc.mld
     return d
 
 
@@ -468,6 +485,8 @@ def _gru_passes(packs):
             g.wp_zr_k32, g.wp_q_k32 = pzr.wp_alt.data_ptr(), pq.wp_alt.data_ptr()
         if pzr.wp4s is not None and pq.wp4s is not None and pzr.g4s == pq.g4s:
             g.wp_zr_a4s, g.wp_q_a4s, g.a4s_groups = pzr.wp4s.data_ptr(), pq.wp4s.data_ptr(), pzr.g4s
+        if pzr.wp4t is not None and pq.wp4t is not None and pzr.g4t == pq.g4t:
+            g.wp_zr_a4t, g.wp_q_a4t, g.a4t_groups = pzr.wp4t.data_ptr(), pq.wp4t.data_ptr(), pzr.g4t
     return arr
 
 

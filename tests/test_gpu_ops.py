@@ -633,6 +633,14 @@ def test_sepconv_gru_c_entry(n, h, w, kind):
             assert lib.scf_pack_conv_weight_a4(wt.data_ptr(), co, ci, kh, kw, grps, a4s.data_ptr()) == 0
             bufs.append(a4s.to(DEV))
         g.wp_zr_a4s, g.wp_q_a4s, g.a4s_groups = bufs[8].data_ptr(), bufs[9].data_ptr(), grps
+        grpt = ops.choose_a4t_groups(ch + cx, k[0], k[1], 1)      # tiny-grid packings of 3x3 passes (32-channel chunks)
+        if grpt:
+            for wt in (wzr, wq.contiguous()):
+                co, ci, kh, kw = wt.shape
+                a4t = torch.empty(lib.scf_pack_conv_weight_a4_size(co, ci, kh, kw, grpt))
+                assert lib.scf_pack_conv_weight_a4(wt.data_ptr(), co, ci, kh, kw, grpt, a4t.data_ptr()) == 0
+                bufs.append(a4t.to(DEV))
+            g.wp_zr_a4t, g.wp_q_a4t, g.a4t_groups = bufs[10].data_ptr(), bufs[11].data_ptr(), grpt
         keep += bufs
         g.KH, g.KW, g.pad_h, g.pad_w = k[0], k[1], pad[0], pad[1]
         g.wp_zr, g.wp_zr_a4, g.wp_q, g.wp_q_a4 = (t.data_ptr() for t in bufs[:4])
