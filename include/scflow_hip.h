@@ -55,7 +55,7 @@ enum {
  * SCF_ABI_MAJOR before its first call; structs additionally carry no size field,
  * so a mismatch must be refused, not worked around. */
 #define SCF_ABI_MAJOR 3
-#define SCF_VERSION (SCF_ABI_MAJOR * 100 + 3)
+#define SCF_VERSION (SCF_ABI_MAJOR * 100 + 4)
 int scf_version(void);
 const char* scf_error_string(int code);
 /* number of HIP devices visible (>=0) or SCF_ENODEVICE */
@@ -175,6 +175,11 @@ typedef struct scf_conv_desc {
                                            every block is alone on its CU, a launch is a chain of one memory
                                            round trip per chunk, so half as many chunks is half the chain)    */
   int32_t a4t_groups;
+  const float* wp_wino;                 /* optional: G g G^T of a 3x3 / stride-1 / pad-1 layer
+                                           (scf_pack_conv_weight_wino); selects the Winograd F(2x2, 3x3)
+                                           fp32 kernel for plain / affine epilogues (bias, BN, residual,
+                                           ReLU).  Same fp32 arithmetic, re-associated sums: results differ
+                                           from the direct kernels by a few ulp of the accumulated magnitude */
 } scf_conv_desc;
 
 int scf_conv2d(const scf_conv_desc* desc, scf_stream_t stream);
@@ -194,6 +199,11 @@ int scf_pack_conv_weight_a4(const float* w, int Cout, int Cin, int KH, int KW, i
  *   rounded up to 32, rows rounded up to a multiple of 8, zeros elsewhere */
 int64_t scf_pack_conv_weight_taps_size(int Cout, int Cin, int KH, int KW);
 int scf_pack_conv_weight_taps(const float* w, int Cout, int Cin, int KH, int KW, float* out);
+/*   Winograd packing (scf_conv_desc.wp_wino, 3x3 only): U[xi = 4i + j] = (G g G^T)[i][j] per (co, ci), computed
+ *   in double and rounded once;  out[((chunk*16 + xi)*F + co/32)*128 + (cl & 1)*64 + (co % 32)*2 + (cl >> 1)]
+ *   with ci = 4*chunk + cl, F = Cout rounded up to 32, / 32; zeros elsewhere */
+int64_t scf_pack_conv_weight_wino_size(int32_t Cout, int32_t Cin);
+int scf_pack_conv_weight_wino(const float* w, int32_t Cout, int32_t Cin, float* out);
 
 /* ---------------------------------------------------------------------------------
  * Convolutional GRU update, whole cell.     replaces ConvGRU.forward

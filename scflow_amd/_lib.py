@@ -51,6 +51,7 @@ class ConvDesc(C.Structure):
         ('wp_taps', _fp),
         ('wp_a4t', _fp),
         ('a4t_groups', C.c_int32),
+        ('wp_wino', _fp),
     ]
 
 
@@ -133,6 +134,8 @@ SIGNATURES = {
     'scf_pack_conv_weight_a4': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'scf_pack_conv_weight_taps_size': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'scf_pack_conv_weight_taps': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'scf_pack_conv_weight_wino_size': (C.c_int64, [C.c_int32, C.c_int32]),
+    'scf_pack_conv_weight_wino': (C.c_int, [_fp, C.c_int32, C.c_int32, _fp]),
     'scf_sepconv_gru': (C.c_int, [_fp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.POINTER(GruPass), C.c_int, _fp, _fp, _fp]),
     'scf_sepconv_gru_ctx': (C.c_int, [_fp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

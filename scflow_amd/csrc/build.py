@@ -5,7 +5,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['capi.hip', 'corr_lookup.hip', 'corr_gemm.hip', 'conv_mfma.hip', 'conv_f16x3.hip', 'conv_dma.hip', 'conv_thin.hip', 'conv_taps.hip', 'resample.hip', 'pose.hip', 'scflow_iter.hip',
+SOURCES = ['capi.hip', 'corr_lookup.hip', 'corr_gemm.hip', 'conv_mfma.hip', 'conv_f16x3.hip', 'conv_dma.hip', 'conv_thin.hip', 'conv_taps.hip', 'conv_wino.hip', 'resample.hip', 'pose.hip', 'scflow_iter.hip',
            'norm.hip']
 OUT = os.path.join(HERE, 'libscflow_hip.so')
 
@@ -15,7 +15,7 @@ def needs_build() -> bool:
         return True
     t = os.path.getmtime(OUT)
     deps = [os.path.join(HERE, s) for s in SOURCES] + [
-        os.path.join(HERE, 'scf_common.h'), os.path.join(HERE, 'conv_kernels.h'),
+        os.path.join(HERE, 'scf_common.h'), os.path.join(HERE, 'conv_kernels.h'), os.path.join(HERE, 'scf_dma.h'),
         os.path.join(HERE, '..', '..', 'include', 'scflow_hip.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -552,6 +552,10 @@ extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
     const int rp = scf_conv_taps_dispatch(pl.k, d->wp_taps, d->N, false, nullptr, scf_stream(stream));
     if (rp != SCF_EUNSUPPORTED) return rp;
   }
+  if (d->wp_wino) {
+    const int rw = scf_conv_wino_dispatch(pl.k, d->wp_wino, d->N, false, nullptr, scf_stream(stream));
+    if (rw != SCF_EUNSUPPORTED) return rw;
+  }
   if (want_f16x3(d)) {
     const int r16 = scf_conv_f16x3_dispatch(pl.k, d->N, false, nullptr, scf_stream(stream));
     if (r16 != SCF_EUNSUPPORTED) return r16;
@@ -691,6 +695,10 @@ extern "C" int scf_conv2d_query(const scf_conv_desc* d, int32_t* info) {
   }
   if (d->wp_taps && scf_conv_taps_dispatch(pl.k, d->wp_taps, d->N, true, info, nullptr) == SCF_OK) {
     info[3] = -info[3];      // negative: the thin-input kernel will run, KC of d is irrelevant
+    return SCF_OK;
+  }
+  if (d->wp_wino && scf_conv_wino_dispatch(pl.k, d->wp_wino, d->N, true, info, nullptr) == SCF_OK) {
+    info[3] = -info[3];      // negative: the Winograd kernel will run (info = CW, TW, blocks, -LDS bytes)
     return SCF_OK;
   }
   if (want_f16x3(d) && scf_conv_f16x3_dispatch(pl.k, d->N, true, info, nullptr) == SCF_OK) {

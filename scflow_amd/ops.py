@@ -25,7 +25,7 @@ from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_GRU_Q, CONV_G
 
 Tensor = torch.Tensor
 
-__all__ = ['PackedConv', 'conv_desc', 'gru_passes', 'scflow_iteration', 'side_stream_handle', 'pyramid_layout', 'untile_level', 'level_storage_shape', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision',
+__all__ = ['PackedConv', 'conv_desc', 'gru_passes', 'scflow_iteration', 'side_stream_handle', 'pyramid_layout', 'untile_level', 'level_storage_shape', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision', 'set_conv_winograd', 'get_conv_winograd', 'pack_conv_weight_wino',
            'get_conv_precision', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
            'instance_norm', 'group_norm_relu', 'linear', 'pose_update', 'reproject_flow',
            'unproject_depth', 'linear_pair', 'resize_bilinear', 'convex_upsample', 'avgpool2x2', 'copy_channels',
@@ -263,7 +263,39 @@ def pack_conv_weight_taps(weight: Tensor) -> Tensor:
     return out.contiguous()
 
 
+def pack_conv_weight_wino(weight: Tensor) -> Tensor:
+    """(Cout, Cin, 3, 3) -> U = G g G^T in conv_wino.hip's layout (scf_pack_conv_weight_wino):
+    [chunk][xi = 4i + j][Cout / 32][channel & 1][Cout % 32][channel >> 1 & 1], 4 channels per chunk,
+    computed in double and rounded once; zero padded."""
+    cout, cin, kh, kw = weight.shape
+    if (kh, kw) != (3, 3):
+        raise ValueError('Winograd packing: 3x3 kernels')
+    g = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]],
+                     dtype=torch.float64, device=weight.device)
+    u = torch.einsum('ia,ocab,jb->ijoc', g, weight.double(), g).reshape(16, cout, cin)
+    f, nchunk = (cout + 31) // 32, (cin + 3) // 4
+    full = torch.zeros((16, f * 32, nchunk * 4), dtype=torch.float64, device=weight.device)
+    full[:, :cout, :cin] = u
+    # [xi][frag][m][chunk][s][kh] -> [chunk][xi][frag][kh][m][s]
+    full = full.reshape(16, f, 32, nchunk, 2, 2).permute(3, 0, 1, 5, 2, 4)
+    return full.contiguous().float().reshape(-1)
+
+
 _CONV_PRECISION = 'f32'
+_CONV_WINOGRAD = False
+
+
+def set_conv_winograd(on: bool) -> bool:
+    """3x3 / stride-1 / pad-1 layers with plain or affine epilogues through the Winograd F(2x2, 3x3)
+    kernel (conv_wino.hip, fp32, 2.25x fewer matrix-core flops; sums re-associated) instead of the
+    direct kernels.  Only under conv precision 'f32'.  Returns the previous setting."""
+    global _CONV_WINOGRAD
+    prev, _CONV_WINOGRAD = _CONV_WINOGRAD, bool(on)
+    return prev
+
+
+def get_conv_winograd() -> bool:
+    return _CONV_WINOGRAD
 
 
 def set_conv_precision(mode: str) -> str:
@@ -311,6 +343,7 @@ class PackedConv:
     desc: Optional[ConvDesc] = None   # scf_conv_desc with this layer's own fields filled (built lazily)
     wp4t: Optional[Tensor] = None     # tiny-grid LDS-DMA packing of 3x3 layers (32-channel chunks)
     g4t: int = 0
+    wwino: Optional[Tensor] = None    # G g G^T packing (3x3, stride 1, pad 1, Cin >= 8)
 
     @staticmethod
     def from_weight(weight: Tensor, bias: Optional[Tensor], stride: int = 1,
@@ -339,7 +372,9 @@ class PackedConv:
                           cin, cout, kh, kw, stride, ph, pw, kc, mld, wp_alt, {}, wp16, wp4, g4,
                           pack_conv_weight_thin(weight) if (cout <= 4 and stride == 1 and cin >= 32) else None,
                           wp4s, g4s, pack_conv_weight_taps(weight) if (cin <= 4 and dma_packing) else None,
-                          None, *PackedConv._tiny(weight, kh, kw, stride, dma_packing))
+                          None, *PackedConv._tiny(weight, kh, kw, stride, dma_packing),
+                          pack_conv_weight_wino(weight) if (dma_packing and (kh, kw, stride, ph, pw) == (3, 3, 1, 1, 1)
+                                                            and cin >= 8) else None)
 
     @staticmethod
     def _tiny(weight, kh, kw, stride, dma_packing):
@@ -432,6 +467,8 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
     # hide.  Stage 32 channels per chunk instead when that packing fits (decided once per shape).
     if _CONV_PRECISION == 'f16x3' and pc.wp16 is not None:
         d.wp_f16 = pc.wp16.data_ptr()
+    elif _CONV_WINOGRAD and pc.wwino is not None and mode == CONV_PLAIN:
+        d.wp_wino = pc.wwino.data_ptr()
     if x1 is not None:
         d.wp_taps = None                # the thin-input kernel takes one input segment
     if pc.wp_alt is not None and (c1 == 0 or c0 % 32 == 0):

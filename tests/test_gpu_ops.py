@@ -289,6 +289,70 @@ def test_conv2d_dma_kernel(case):
     close(got, ref.cpu(), atol=3e-5, what='dma vs register-staged ' + str(case))
 
 
+WINO_CASES = [
+    # n, cin, cout, H, W, (c0 split or 0), BN, residual, relu
+    (2, 64, 64, 32, 32, 0, False, False, True),        # (2,2) blocks, one strip per row group
+    (2, 128, 512, 32, 32, 0, False, False, True),      # XHead hidden layer shape
+    (3, 256, 126, 32, 32, 192, False, False, True),    # motion encoder out conv: two segments, 126 channels
+    (2, 96, 96, 64, 64, 0, True, True, True),          # 3 fragments: (1,4) blocks; BN + residual
+    (1, 64, 64, 128, 128, 0, False, False, False),     # encoder layer, no activation (InstanceNorm follows)
+    (2, 30, 40, 20, 28, 0, False, True, False),        # ragged: Cin % 4 != 0, Cout % 32 != 0, Wo % 32 != 0
+    (1, 128, 64, 60, 80, 0, False, False, True),       # 60 x 80 map (480 x 640 crops): narrower tile groups
+    (2, 16, 32, 7, 10, 0, False, False, True),         # odd height, tiny width
+    (1, 8, 64, 16, 16, 0, False, False, True),
+]
+
+
+@pytest.mark.parametrize('case', WINO_CASES)
+def test_conv2d_winograd(case):
+    """F(2x2, 3x3) kernel vs torch fp64 and vs the direct kernel: same fp32 arithmetic with re-associated
+    sums, so the error budget is a small multiple of the direct kernel's."""
+    import ctypes as C
+    n, cin, cout, H, W, c0, bn, with_res, relu = case
+    x = rnd((n, cin, H, W), 40)
+    wt = rnd((cout, cin, 3, 3), 41, (1.0 / (cin * 9)) ** 0.5)
+    b = rnd((cout,), 42, 0.1)
+    want = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    bnp = None
+    if bn:
+        gamma, beta = rnd((cout,), 43) * 0.2 + 1, rnd((cout,), 44) * 0.1
+        mean, var = rnd((cout,), 45) * 0.1, rnd((cout,), 46).abs() * 0.5 + 0.5
+        want = F.batch_norm(want, mean.double(), var.double(), gamma.double(), beta.double(), False, 0., 1e-5)
+        bnp = [t.to(DEV) for t in (gamma, beta, mean, var)]
+    res = rnd(tuple(want.shape), 47) if with_res else None
+    if with_res:
+        want = want + res.double()
+    if relu:
+        want = torch.relu(want)
+    want = want.float()
+    pc = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), padding=1, bn=bnp)
+    assert pc.wwino is not None
+    # the C packer and the torch packer agree bit for bit
+    lib = ops._lib.load()
+    size = lib.scf_pack_conv_weight_wino_size(cout, cin)
+    assert size == pc.wwino.numel()
+    host = torch.empty(size)
+    wc = wt.contiguous()
+    assert lib.scf_pack_conv_weight_wino(wc.data_ptr(), cout, cin, host.data_ptr()) == 0
+    assert torch.equal(host, pc.wwino.cpu())
+    xd = x.to(DEV)
+    kw = dict(res=None if res is None else res.to(DEV), act=ops.ACT_RELU if relu else ops.ACT_NONE)
+    x0, x1 = (xd[:, :c0], xd[:, c0:]) if c0 else (xd, None)
+    direct = ops.conv2d(pc, x0, x1, **kw)
+    prev = ops.set_conv_winograd(True)
+    try:
+        d, _ = ops.conv_desc(pc, x0, x1, **kw)
+        info = (C.c_int32 * 4)()
+        assert lib.scf_conv2d_query(C.byref(d), info) == 0 and info[3] < 0 and info[0] * info[1] == 4, list(info)
+        got = ops.conv2d(pc, x0, x1, **kw)
+    finally:
+        ops.set_conv_winograd(prev)
+    e_dir = float((direct.cpu() - want).abs().max())
+    e_win = float((got.cpu() - want).abs().max())
+    print(f'winograd {case}: max err {e_win:.2e} (direct kernel {e_dir:.2e})')
+    close(got, want, atol=2e-5, what='winograd ' + str(case))
+
+
 def test_conv2d_dma_two_segments_gru_q():
     """the GRU candidate conv on the DMA kernel: two input segments, tanh gate epilogue."""
     n, h, w = 32, 32, 32

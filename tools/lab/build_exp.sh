@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../../scflow_amd/csrc"
 O=/tmp/scf_exp_obj; mkdir -p $O
-for f in capi corr_lookup corr_gemm conv_mfma conv_f16x3 conv_dma conv_thin conv_taps resample pose norm scflow_iter; do
+for f in capi corr_lookup corr_gemm conv_mfma conv_f16x3 conv_dma conv_thin conv_taps conv_wino resample pose norm scflow_iter; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $1 -c $f.hip -o $O/$f.o &
 done
 wait
