@@ -199,8 +199,9 @@ int scf_pack_conv_weight_a4(const float* w, int Cout, int Cin, int KH, int KW, i
  *   rounded up to 32, rows rounded up to a multiple of 8, zeros elsewhere */
 int64_t scf_pack_conv_weight_taps_size(int Cout, int Cin, int KH, int KW);
 int scf_pack_conv_weight_taps(const float* w, int Cout, int Cin, int KH, int KW, float* out);
-/*   Winograd packing (scf_conv_desc.wp_wino, 3x3 only): U[xi = 4i + j] = (G g G^T)[i][j] per (co, ci), computed
- *   in double and rounded once;  out[((chunk*16 + xi)*F + co/32)*128 + (cl & 1)*64 + (co % 32)*2 + (cl >> 1)]
+/*   Winograd packing (scf_conv_desc.wp_wino, 3x3 only): U[i][j] = (G g G^T)[i][j] per (co, ci), computed
+ *   in double and rounded once;  out[((chunk*F + co/32)*16 + 4*pi(i) + j)*128 + (cl & 1)*64 + (co % 32)*2 + (cl >> 1)],
+ *   pi = (0, 1, 3, 2): the rows of the transform domain are stored in the order 0, 1, 3, 2,
  *   with ci = 4*chunk + cl, F = Cout rounded up to 32, / 32; zeros elsewhere */
 int64_t scf_pack_conv_weight_wino_size(int32_t Cout, int32_t Cin);
 int scf_pack_conv_weight_wino(const float* w, int32_t Cout, int32_t Cin, float* out);

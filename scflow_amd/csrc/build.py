@@ -8,6 +8,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ['capi.hip', 'corr_lookup.hip', 'corr_gemm.hip', 'conv_mfma.hip', 'conv_f16x3.hip', 'conv_dma.hip', 'conv_thin.hip', 'conv_taps.hip', 'conv_wino.hip', 'resample.hip', 'pose.hip', 'scflow_iter.hip',
            'norm.hip']
 OUT = os.path.join(HERE, 'libscflow_hip.so')
+# conv_wino.hip: the SLP vectoriser turns the input transform's 32 adds into packed adds PLUS as many register
+# moves to pair their operands up; vector-ALU instructions cost matrix-pipe time there (see the file), so the
+# scalar form (no moves) is the faster one
+FILE_FLAGS = {'conv_wino.hip': ['-fno-slp-vectorize']}
 
 
 def needs_build() -> bool:
@@ -35,7 +39,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(src: str) -> str:
         obj = os.path.join(objdir, src.replace('.hip', '.o'))
-        subprocess.run([hipcc, *flags, '-c', os.path.join(HERE, src), '-o', obj], check=True)
+        subprocess.run([hipcc, *flags, *FILE_FLAGS.get(src, []), '-c', os.path.join(HERE, src), '-o', obj], check=True)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:

@@ -7,19 +7,25 @@
 //
 //   GEMM view   for each of the 16 transform positions xi:  M[xi][cout][tile] = sum_cin U[xi][cout][cin] V[xi][cin][tile]
 //               v_mfma_f32_32x32x2_f32, M = 32 output channels, N = 32 tiles (2 x 2 outputs each), k = 2 channels.
-//   wave        ONE 32 x 32 fragment for ALL 16 xi = 256 accumulator registers (one wave per SIMD, the
-//               accumulators live in AGPRs), so the output transform A^T M A is lane-local: no exchange.
-//   block       CW x TW waves: CW channel fragments x TW tile groups (stacked vertically in the image).
+//   wave pair   one 32 x 32 fragment: each of the two waves accumulates 8 of the 16 xi (two rows of the 4 x 4
+//               transform domain) = 128 accumulator registers, so TWO waves fit a SIMD and two blocks a CU:
+//               one block's staging, barriers and epilogue run under the other's MFMAs (a first version with
+//               all 16 xi in one wave = one wave per SIMD measured MFMA time + everything else, no overlap).
+//               The output transform A^T M A is linear in the rows: each wave transforms its two rows, the
+//               pair exchanges half of the 4-value partial results through LDS and each finishes 8 of the
+//               fragment's 16 channel rows.
+//   block       4 waves = 2 fragments (CW x TW = 2: two channel fragments of one tile group, or one
+//               channel fragment of two vertically stacked tile groups).
 //   U           = G g G^T, transformed and packed on the host (scf_pack_conv_weight_wino) in the exact
-//               LDS image [chunk][xi][fragment][k-half][cout][2]: one ds_read_b64 per xi feeds both
+//               LDS image [chunk][fragment][xi][k-half][cout][2]: one ds_read_b64 per xi feeds both
 //               k-steps of a 4-channel chunk; staged by LDS-DMA into a 3-deep ring.
 //   V           = B^T d B, computed IN the kernel: the raw input patch of the next chunk is staged by
 //               LDS-DMA (descriptor range check = zero padding), each thread transforms one
-//               (tile, channel) 4 x 4 window (32 adds) and writes its 16 values to the V double buffer,
-//               interleaved with the MFMAs of the current chunk.
+//               (tile, channel) 4 x 4 window (32 adds) in pieces placed between groups of MFMAs and
+//               writes its 16 values to the V double buffer.
 //   pipeline    per chunk: issue DMA of chunk c+2 (U) / c+3 (patch); transform patch c+1 -> V; MFMAs of
 //               chunk c; one barrier.
-//   epilogue    lane-local output transform, then the affine epilogue (bias, BN scale/shift, residual,
+//   epilogue    output transform, pair exchange, then the affine epilogue (bias, BN scale/shift, residual,
 //               ReLU) and float2 stores: 16 lanes cover one full 128-byte line of an output row.
 //
 // Arithmetic: fp32 adds / fmas only; the transforms re-associate the sum, so results differ from the
@@ -31,14 +37,16 @@
 #include "scf_dma.h"
 
 typedef float wn_f32x16 __attribute__((ext_vector_type(16)));
+typedef float wn_f32x4 __attribute__((ext_vector_type(4)));
 typedef float wn_f32x2 __attribute__((ext_vector_type(2)));
 
-#define WN_NPI(TW) ((TW) == 2 ? 6 : 11)   // patch DMA instructions per wave per chunk (256 floats each per block): fixed per
-                                         // block shape, lanes past the patch write zeros into the slot's padding
+// patch DMA instructions per wave per chunk, fixed per block shape (lanes past the patch write zeros into the
+// slot's padding): 16-byte cells (256 cells per block-instruction) when the rows are 16-byte aligned, else dwords
+#define WN_NPI(TW, PX4) ((PX4) ? ((TW) == 2 ? 3 : 2) : ((TW) == 2 ? 8 : 5))
 #define WN_KC 4             // channels per chunk
 
 struct WinoK {
-  const float* wu;          // [nchunk][16][F][2][32][2]
+  const float* wu;          // [nchunk][F][16][2][32][2]
   int F;                    // channel fragments in the packing
   int txl;                  // log2(tiles per row of a wave's 32-tile group)
   int PH, PW, PWp, PPL;     // patch rows, columns, row pitch, plane stride (floats)
@@ -50,9 +58,25 @@ struct WinoK {
 #endif
 };
 #ifdef SCF_WINO_LAB
+#ifdef SCF_WINO_LAB_MASK            // compile-time ablation (no run-time branches in the loop)
+#define WN_LAB(bit) ((SCF_WINO_LAB_MASK >> (bit)) & 1)
+#else
 #define WN_LAB(bit) (q.lab & (1 << (bit)))
+#endif
+#include "../../tools/lab/wino_lab_hooks.h"
+#ifdef SCF_WINO_LAB_MASK
+#undef WN_T
+#define WN_T(slot) do { } while (0)
+#undef WN_T_RT
+#define WN_T_RT(slot) do { } while (0)
+#endif
 #else
 #define WN_LAB(bit) 0
+#define WN_TRACE_BYTES 0
+#define WN_T(slot) do { } while (0)
+#define WN_T_RT(slot) do { } while (0)
+#define WN_T_CHUNK(c, k) do { } while (0)
+#define WN_T_DUMP() do { } while (0)
 #endif
 
 // floor(e / d) for 0 <= e < 2^20, 0 < d < 2^12 without the integer-division expansion
@@ -64,20 +88,21 @@ __device__ __forceinline__ int wn_div(int e, int d, float rd) {
   return q;
 }
 
-template <int CW, int TW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+template <int CW, int TW, bool PX4>
+__global__ __launch_bounds__(256, 2)
 void conv_wino_kernel(ConvK p, WinoK q) {
-  static_assert(CW * TW == 4, "four waves per block");
+  static_assert(CW * TW == 2, "two fragments (four waves) per block");
   extern __shared__ __attribute__((aligned(16))) float wn_lds[];
-  constexpr int USLOT = CW * 2048, VSLOT = TW * 2048;           // floats per ring slot
-  constexpr int NUI = (CW == 1) ? 8 : CW * 2;                   // U DMA instructions per wave per chunk
-  constexpr int NPI = WN_NPI(TW);                               // patch DMA instructions per wave per chunk
-  constexpr int PSLOT = NPI * 256;
+  constexpr int USLOT = CW * 2048;                              // floats per ring slot
+  constexpr int NUI = 2 * CW;                                   // U DMA instructions (16 B per lane) per wave per chunk
+  constexpr int NPI = WN_NPI(TW, PX4);                          // patch DMA instructions per wave per chunk
+  constexpr int PSLOT = NPI * (PX4 ? 1024 : 256);
   constexpr int GRP = NUI + NPI;                                // DMA instructions per wave per group
-  constexpr int TQ = (TW * 128 + 255) / 256;                    // windows per thread per chunk
+  static_assert(3 * USLOT + 3 * PSLOT >= 4 * 2048, "the pair exchange reuses the rings");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cw = wave / TW, tw = wave % TW;
+  const int fs = wave >> 1, xh = wave & 1;                      // fragment of the block, half of the transform domain
+  const int cw = CW == 2 ? fs : 0, tw = TW == 2 ? fs : 0;
   const int half = lane >> 5, l32 = lane & 31;
 
   int lb = scf_xcd_remap(blockIdx.x, gridDim.x);
@@ -93,40 +118,40 @@ void conv_wino_kernel(ConvK p, WinoK q) {
   const int HW = p.H * p.W;
 
   float* Us = wn_lds;
-  float* Vs = Us + 3 * USLOT;
-  float* Ps = Vs + 2 * VSLOT;
+  float* Ps = Us + 3 * USLOT;
+#ifdef SCF_WINO_LAB
+  unsigned* wn_trace = reinterpret_cast<unsigned*>(Ps + 3 * PSLOT);
+#endif
+  WN_T(0);
+  WN_T_RT(118);
   const unsigned u_lds = scf_lds_addr(Us), p_lds = scf_lds_addr(Ps);
 
   // ---- chunk-invariant DMA offsets --------------------------------------------------------------
   unsigned pvo[NPI];                            // patch: byte offset inside the chunk's 4 channel planes
   {
-    const float rPPL = 1.0f / (float)q.PPL, rPW = 1.0f / (float)q.PWp;
+    // PX4: cells of 4 floats, rows start 4 columns left of the block (16-byte aligned: W % 4 == 0), the
+    // windows then start at column 3; else single floats, rows start 1 column left
+    const int NC = PX4 ? q.PWp >> 2 : q.PWp, PPC = q.PH * NC;        // cells per row / per plane
+    const float rPPC = 1.0f / (float)PPC, rNC = 1.0f / (float)NC;
 #pragma unroll
     for (int i = 0; i < NPI; ++i) {
       const int e = i * 256 + tid;
-      const int c = wn_div(e, q.PPL, rPPL), r = e - c * q.PPL;
-      const int py = wn_div(r, q.PWp, rPW), px = r - py * q.PWp;
-      const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-      const bool ok = c < WN_KC && py < q.PH && px < q.PW && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const int c = wn_div(e, PPC, rPPC), r = e - c * PPC;
+      const int py = wn_div(r, NC, rNC), px = r - py * NC;
+      const int iy = y0 - 1 + py, ix = PX4 ? x0 - 4 + 4 * px : x0 - 1 + px;
+      const bool ok = c < WN_KC && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && (PX4 || px < q.PW);
       pvo[i] = ok ? (unsigned)((c * HW + iy * p.W + ix) * 4) : SCF_BUF_OOB;
     }
   }
   unsigned uvo[NUI], uld[NUI];                  // U: byte offset inside the chunk's slab / inside the ring slot
 #pragma unroll
-  for (int i = 0; i < NUI; ++i) {
+  for (int i = 0; i < NUI; ++i) {               // a fragment's 16 xi are 8 KB contiguous: 8 instructions of 1 KB
     const int j = wave + 4 * i;
-    if (CW == 1) {
-      const int xi = j >> 1, part = j & 1;
-      uvo[i] = (unsigned)((xi * q.F + f0) * 512 + part * 256 + lane * 4);
-      uld[i] = (unsigned)(xi * 512 + part * 256);
-    } else {
-      constexpr int IPX = CW / 2 > 0 ? CW / 2 : 1;
-      const int xi = j / IPX, part = j % IPX;
-      uvo[i] = (unsigned)((xi * q.F + f0) * 512 + part * 1024 + lane * 16);
-      uld[i] = (unsigned)(xi * CW * 512 + part * 1024);
-    }
+    const int f = j >> 3, part = j & 7;
+    uvo[i] = (unsigned)((f0 + f) * 8192 + part * 1024 + lane * 16);
+    uld[i] = (unsigned)(f * 8192 + part * 1024);
   }
-  const unsigned u_chunk_bytes = (unsigned)(16 * q.F * 512);
+  const unsigned u_chunk_bytes = (unsigned)(q.F * 8192);
   const unsigned u_total = (unsigned)q.nchunk * u_chunk_bytes;
 
   auto issue_u = [&](int k, int slot) {          // U[k] -> ring slot (chunks past the end: zeros)
@@ -134,10 +159,7 @@ void conv_wino_kernel(ConvK p, WinoK q) {
     const scf_rsrc4 rs = scf_make_rsrc((const char*)q.wu + done, k < q.nchunk ? u_total - done : 0u);
     const unsigned dst = u_lds + (unsigned)(slot * USLOT * 4);
 #pragma unroll
-    for (int i = 0; i < NUI; ++i) {
-      if (CW == 1) scf_bdma_b32(rs, uvo[i], dst + uld[i]);
-      else scf_bdma_b128(rs, uvo[i], dst + uld[i]);
-    }
+    for (int i = 0; i < NUI; ++i) scf_bdma_b128(rs, uvo[i], dst + uld[i]);
   };
   auto issue_p = [&](int k, int slot) {          // patch[k] -> ring slot
     const int c0 = k * WN_KC;
@@ -148,157 +170,200 @@ void conv_wino_kernel(ConvK p, WinoK q) {
     if (left > WN_KC) left = WN_KC;
     if (left < 0) left = 0;
     const scf_rsrc4 rs = scf_make_rsrc(base, (unsigned)(left * HW * 4));
-    const unsigned dst = p_lds + (unsigned)((slot * PSLOT + wave * 64) * 4);
+    const unsigned dst = p_lds + (unsigned)((slot * PSLOT + wave * (PX4 ? 256 : 64)) * 4);
 #pragma unroll
-    for (int i = 0; i < NPI; ++i) scf_bdma_b32(rs, pvo[i], dst + (unsigned)(i * 1024));
-  };
-
-  // ---- input transform: window (tile, channel) of a patch slot -> 16 values of a V slot, in three
-  //      pieces that the main loop places between groups of MFMAs (a piece runs in their shadow) ------
-  int poff[TQ];
-#pragma unroll
-  for (int u = 0; u < TQ; ++u) {
-    const int qi = tid + 256 * u;
-    const int s = qi & 1, t32 = (qi >> 1) & 31, kh = (qi >> 6) & 1, twq = qi >> 7;
-    const int ty = twq * TYW + (t32 >> q.txl), tx = t32 & (TXW - 1);
-    poff[u] = (2 * s + kh) * q.PPL + 2 * ty * q.PWp + 2 * tx;
-  }
-  float d[TQ][4][4], w[TQ][4][4];
-  auto tr_load = [&](const float* ps) {
-#pragma unroll
-    for (int u = 0; u < TQ; ++u) {
-      const float* s0 = ps + poff[u];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const wn_f32x2 lo = *reinterpret_cast<const wn_f32x2*>(s0 + i * q.PWp);
-        const wn_f32x2 hi = *reinterpret_cast<const wn_f32x2*>(s0 + i * q.PWp + 2);
-        d[u][i][0] = lo[0]; d[u][i][1] = lo[1]; d[u][i][2] = hi[0]; d[u][i][3] = hi[1];
-      }
+    for (int i = 0; i < NPI; ++i) {
+      if (PX4) scf_bdma_b128(rs, pvo[i], dst + (unsigned)(i * 4096));
+      else scf_bdma_b32(rs, pvo[i], dst + (unsigned)(i * 1024));
     }
   };
-  auto tr_rows = [&](int u) {
+
+  // ---- input transform in registers: lane (tile l32, k-half) turns the 4 x 4 windows of channels
+  //      half and 2 + half into the B operands of its wave's two rows of the transform domain.
+  //      Rows (0, 1) of B^T d need input rows 0-2, rows (2, 3) need 1-3: three rows from row xh on ----
+  const int ty = tw * TYW + (l32 >> q.txl), tx = l32 & (TXW - 1);
+  // Vector-ALU instructions of a wave run on the same SIMD as the MFMAs of both co-resident waves and do
+  // NOT hide behind them: every one costs matrix-pipe time.  So the loop keeps them to the transform's own
+  // adds: (a) the six row addresses of the two windows are absolute LDS addresses computed once (one add of
+  // the slot offset per row and chunk); (b) both halves of the transform domain run the SAME code: rows
+  // (0, 1) take input rows (d0, d1, d2) as (e0, e1, e2) and compute e0 - e2, e1 + e2; rows (3, 2) take
+  // (d3, d2, d1) and compute e0 - e2 = -(row 3), e1 - e2 = row 2 -- one fma with sigma = +-1, the sign of row
+  // 3 is undone in the output transform and the packing stores U's rows in the order 0, 1, 3, 2; (c) the
+  // operand double buffer is a 2x unrolled loop, not 32 moves.
+  const float sigma = xh == 0 ? 1.0f : -1.0f;
+  unsigned prow[2][3];                              // absolute LDS byte address of row e_i, slot 0
+  {
+    const int poff = half * q.PPL + 2 * ty * q.PWp + 2 * tx + (PX4 ? 3 : 0);      // channel `half`, input row d0
+#pragma unroll
+    for (int sI = 0; sI < 2; ++sI)
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        prow[sI][i] = p_lds + (unsigned)((poff + 2 * sI * q.PPL + (xh == 0 ? i : 3 - i) * q.PWp) * 4);
+  }
+  float dws[2][3][4];
+  auto win_load = [&](unsigned slot_bytes, int sI) {                  // channel 2 sI + half
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const __attribute__((address_space(3))) float* r =
+          (const __attribute__((address_space(3))) float*)(uintptr_t)(prow[sI][i] + slot_bytes);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dws[sI][i][j] = r[j];
+    }
+  };
+  auto win_transform = [&](wn_f32x2 (&bo)[8], int sI) {                // -> bo[4 il + j][sI]
+    float w[2][4];
+    const float (&e)[3][4] = dws[sI];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      w[u][0][j] = d[u][0][j] - d[u][2][j];
-      w[u][1][j] = d[u][1][j] + d[u][2][j];
-      w[u][2][j] = d[u][2][j] - d[u][1][j];
-      w[u][3][j] = d[u][1][j] - d[u][3][j];
+      w[0][j] = e[0][j] - e[2][j];
+      w[1][j] = __builtin_fmaf(sigma, e[2][j], e[1][j]);
     }
-  };
-  auto tr_cols = [&](float* vs, int u, int i0) {     // rows i0, i0 + 1 of the result
-    if (TW * 128 >= 256 || tid + 256 * u < TW * 128) {
-      float* o = vs + tid + 256 * u;
 #pragma unroll
-      for (int i = i0; i < i0 + 2; ++i) {
-        o[(4 * i + 0) * (TW * 128)] = w[u][i][0] - w[u][i][2];
-        o[(4 * i + 1) * (TW * 128)] = w[u][i][1] + w[u][i][2];
-        o[(4 * i + 2) * (TW * 128)] = w[u][i][2] - w[u][i][1];
-        o[(4 * i + 3) * (TW * 128)] = w[u][i][1] - w[u][i][3];
-      }
+    for (int il = 0; il < 2; ++il) {
+      bo[4 * il + 0][sI] = w[il][0] - w[il][2];
+      bo[4 * il + 1][sI] = w[il][1] + w[il][2];
+      bo[4 * il + 2][sI] = w[il][2] - w[il][1];
+      bo[4 * il + 3][sI] = w[il][1] - w[il][3];
     }
   };
 
-  wn_f32x16 acc[16];
+  wn_f32x16 acc[8];
 #pragma unroll
-  for (int x = 0; x < 16; ++x)
+  for (int x = 0; x < 8; ++x)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
-  // ---- prologue: patch[0]; (U[0], patch[1]); (U[1], patch[2]) -----------------------------------------
-  issue_p(0, 0);
-  issue_u(0, 0); issue_p(1, 1);
-  issue_u(1, 1); issue_p(2, 2);
+  // ---- prologue: patch[0], U[0]; (U[1], patch[1]); (U[2], patch[2]) ---------------------------------
+  issue_p(0, 0); issue_u(0, 0);
+  issue_u(1, 1); issue_p(1, 1);
+  issue_u(2, 2); issue_p(2, 2);
   scf_wait_vmcnt_imm<GRP>();           // all but the last group have landed
   __syncthreads();
-  tr_load(Ps);
+  const float* ua = Us + cw * 2048 + xh * 1024 + lane * 2;          // + xi_local * 128
+  wn_f32x2 a0[8], b0[8], a1[8], b1[8];
 #pragma unroll
-  for (int u = 0; u < TQ; ++u) { tr_rows(u); tr_cols(Vs, u, 0); tr_cols(Vs, u, 2); }
-  __syncthreads();
+  for (int x = 0; x < 8; ++x) a0[x] = *reinterpret_cast<const wn_f32x2*>(ua + x * 128);
+  win_load(0u, 0); win_transform(b0, 0);
+  win_load(0u, 1); win_transform(b0, 1);
+  __syncthreads();                     // slot 0 of both rings is free again
+  WN_T(1);
 
-  const float* ua = Us + cw * 128 + lane * 2;
-  const float* vb = Vs + tw * 128 + lane * 2;
-  int us = 0, ps1 = 1, vs0 = 0;        // ring slots of U[c], patch[c + 1], V[c]
-  for (int c = 0; c < q.nchunk; ++c) {
-    {
-      const int un = us == 0 ? 2 : us - 1;          // (c + 2) % 3
-      const int pn = ps1 == 0 ? 2 : ps1 - 1;        // (c + 3) % 3
-      if (!WN_LAB(2)) { issue_u(c + 2, un); issue_p(c + 3, pn); }
+  // chunk c: the operands of chunk c are in registers (a, b); those of chunk c + 1 are read (U) / computed
+  // (patch) into (an, bn) under its MFMAs; the copies of chunk c + 3 are issued, those of chunk c + 2 must have
+  // landed at its end.  The MFMAs go first; everything else is placed between them in the order its results
+  // are needed.
+  int s1 = 1;                          // ring slot of U[c + 1], patch[c + 1]
+  auto chunk = [&](int c, const wn_f32x2 (&a)[8], const wn_f32x2 (&b)[8], wn_f32x2 (&an)[8], wn_f32x2 (&bn)[8]) {
+    const float* uc = ua + s1 * USLOT;               // past the last chunk: zeros, results unused
+    const unsigned pcb = (unsigned)(s1 * PSLOT * 4);
+#define WN_M(X, S)                                                                                    \
+    if (!WN_LAB(0)) acc[X] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[X][S], b[X][S], acc[X], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);
+    WN_M(0, 0)
+    if (!WN_LAB(1)) win_load(pcb, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    WN_M(1, 0)
+    if (!WN_LAB(1)) win_load(pcb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    WN_M(2, 0)
+    if (!WN_LAB(2)) {
+      const int s3 = s1 == 0 ? 2 : s1 - 1;          // (c + 3) % 3
+      issue_u(c + 3, s3); issue_p(c + 3, s3);
     }
-    wn_f32x2 a[16], b[16];
-    const float* uc = ua + us * USLOT;
-    const float* vc = vb + vs0 * VSLOT;
-    float* vnext = Vs + (vs0 ^ 1) * VSLOT;
+    __builtin_amdgcn_sched_barrier(0);
+    WN_M(3, 0)
 #pragma unroll
-    for (int x = 0; x < 16; ++x) {
-      a[x] = *reinterpret_cast<const wn_f32x2*>(uc + x * (CW * 128));
-      b[x] = *reinterpret_cast<const wn_f32x2*>(vc + x * (TW * 128));
-    }
-    if (!WN_LAB(1)) tr_load(Ps + ps1 * PSLOT);       // patch[c + 1]; past the last chunk: zeros, result unused
+    for (int x = 0; x < 8; ++x) an[x] = *reinterpret_cast<const wn_f32x2*>(uc + x * 128);
     __builtin_amdgcn_sched_barrier(0);
-#define WN_MFMA(X0, X1, S)                                                                            \
-    if (!WN_LAB(0)) _Pragma("unroll") for (int x = X0; x < X1; ++x)                                   \
-      acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x][S], b[x][S], acc[x], 0, 0, 0);               \
+    WN_M(4, 0) WN_M(5, 0)
+    if (!WN_LAB(1)) win_transform(bn, 0);
     __builtin_amdgcn_sched_barrier(0);
-    WN_MFMA(0, 4, 0)
-    if (!WN_LAB(1)) tr_rows(0);
+    WN_M(6, 0) WN_M(7, 0)
+    WN_M(0, 1) WN_M(1, 1)
+    if (!WN_LAB(1)) win_transform(bn, 1);
     __builtin_amdgcn_sched_barrier(0);
-    WN_MFMA(4, 8, 0)
-    if (!WN_LAB(1)) tr_cols(vnext, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    WN_MFMA(8, 12, 0)
-    if (!WN_LAB(1)) tr_cols(vnext, 0, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    WN_MFMA(12, 16, 0)
-    if (TQ > 1 && !WN_LAB(1)) { tr_rows(TQ - 1); __builtin_amdgcn_sched_barrier(0); }
-    WN_MFMA(0, 4, 1)
-    if (TQ > 1 && !WN_LAB(1)) { tr_cols(vnext, TQ - 1, 0); __builtin_amdgcn_sched_barrier(0); }
-    WN_MFMA(4, 8, 1)
-    if (TQ > 1 && !WN_LAB(1)) { tr_cols(vnext, TQ - 1, 2); __builtin_amdgcn_sched_barrier(0); }
-    WN_MFMA(8, 16, 1)
-#undef WN_MFMA
+    WN_M(2, 1) WN_M(3, 1) WN_M(4, 1) WN_M(5, 1) WN_M(6, 1) WN_M(7, 1)
+#undef WN_M
     scf_wait_vmcnt_imm<GRP>();
     if (!WN_LAB(4)) __syncthreads();
-    us = us == 2 ? 0 : us + 1;
-    ps1 = ps1 == 2 ? 0 : ps1 + 1;
-    vs0 ^= 1;
+    s1 = s1 == 2 ? 0 : s1 + 1;
+  };
+  int c = 0;
+  for (; c + 1 < q.nchunk; c += 2) {
+    chunk(c, a0, b0, a1, b1);
+    chunk(c + 1, a1, b1, a0, b0);
   }
+  if (c < q.nchunk) chunk(c, a0, b0, a1, b1);
   scf_wait_vmcnt_imm<0>();             // the zero-filled groups past the end
+  WN_T(122);
+  __syncthreads();                     // every wave's copies have landed: the rings are free for the exchange
 
-  // ---- output transform + affine epilogue ------------------------------------------------------------
+  // ---- output transform of this wave's two rows of the transform domain -----------------------------
+  // rows (0, 1): A^T contributes (M0 + M1, M1); rows (3, 2), row 3 negated (above): (M2, -M2 - M3) =
+  // (acc[4 + j], acc[j] - acc[4 + j]); then the column transform
+  float* xw = wn_lds + wave * 2048;             // this wave's outbox: [8 channel rows][64 lanes][4]
+  const float* xr = wn_lds + (wave ^ 1) * 2048; // the partner's
+  wn_f32x4 own[8];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float t0[4], t1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (xh == 0) { t0[j] = acc[j][r] + acc[4 + j][r]; t1[j] = acc[4 + j][r]; }
+      else { t0[j] = acc[4 + j][r]; t1[j] = acc[j][r] - acc[4 + j][r]; }
+    }
+    wn_f32x4 y;
+    y[0] = (t0[0] + t0[1]) + t0[2];
+    y[1] = (t0[1] - t0[2]) - t0[3];
+    y[2] = (t1[0] + t1[1]) + t1[2];
+    y[3] = (t1[1] - t1[2]) - t1[3];
+    // this wave finishes channel rows r in [8 xh, 8 xh + 8); the others go to the partner
+    if ((r >> 3) == xh) own[r & 7] = y;
+    else *reinterpret_cast<wn_f32x4*>(xw + ((r & 7) * 64 + lane) * 4) = y;
+  }
+  WN_T(123);
+  __syncthreads();
+  WN_T_DUMP();
+
   const ConvEpi e = scf_conv_epi(p, n);
-  const int ty = tw * TYW + (l32 >> q.txl), tx = l32 & (TXW - 1);
   const int oy = y0 + 2 * ty, ox = x0 + 2 * tx;
   if (ox >= p.Wo || oy >= p.Ho || WN_LAB(3)) return;
   const bool row1 = oy + 1 < p.Ho;
   const bool relu = p.act == SCF_ACT_RELU;
-  const int cb = (f0 + cw) * 32 + 4 * half;
+  const int cb = (f0 + cw) * 32 + 4 * half + 16 * xh;
+  // every load of the epilogue (partner's partial sums, bias / BN constants, residual) is issued before the
+  // first store: loads and stores share the in-order vmcnt counter, so a load behind a store waits for the
+  // store's acknowledgement -- one memory round trip per channel row otherwise
+  wn_f32x4 o[8];
+  float bv[8], sc[8], sh[8];
+  wn_f32x2 rr[8][2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
+  for (int r = 0; r < 8; ++r) {
+    const int co = cb + 8 * (r >> 2) + (r & 3);
+    const int cc = co < p.Cout ? co : 0;
+    o[r] = *reinterpret_cast<const wn_f32x4*>(xr + (r * 64 + lane) * 4);
+    bv[r] = p.bias ? p.bias[cc] : 0.f;
+    sc[r] = p.scale ? p.scale[cc] : 1.f;
+    sh[r] = p.scale ? p.shift[cc] : 0.f;
+    const int off = cc * e.HWo + oy * p.Wo + ox;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      rr[r][i] = (e.res && (i == 0 || row1)) ? *reinterpret_cast<const wn_f32x2*>(e.res + off + i * p.Wo) : wn_f32x2{0.f, 0.f};
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
     const int co = cb + 8 * (r >> 2) + (r & 3);
     if (co >= p.Cout) continue;
-    float t0[4], t1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      t0[j] = (acc[j][r] + acc[4 + j][r]) + acc[8 + j][r];
-      t1[j] = (acc[4 + j][r] - acc[8 + j][r]) - acc[12 + j][r];
-    }
-    float y[2][2];
-    y[0][0] = (t0[0] + t0[1]) + t0[2];
-    y[0][1] = (t0[1] - t0[2]) - t0[3];
-    y[1][0] = (t1[0] + t1[1]) + t1[2];
-    y[1][1] = (t1[1] - t1[2]) - t1[3];
-    const float bv = p.bias ? p.bias[co] : 0.f;
-    const float sc = p.scale ? p.scale[co] : 1.f, sh = p.scale ? p.shift[co] : 0.f;
+    // rows (0, 1) + rows (2, 3), the same order in both waves
+    const wn_f32x4 y = xh == 0 ? own[r] + o[r] : o[r] + own[r];
     const int off = co * e.HWo + oy * p.Wo + ox;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (i == 1 && !row1) break;
-      wn_f32x2 v = {y[i][0] + bv, y[i][1] + bv};
-      if (p.scale) { v[0] = v[0] * sc + sh; v[1] = v[1] * sc + sh; }
-      if (e.res) {
-        const wn_f32x2 rr = *reinterpret_cast<const wn_f32x2*>(e.res + off + i * p.Wo);
-        v[0] += rr[0]; v[1] += rr[1];
-      }
+      wn_f32x2 v = {y[2 * i] + bv[r], y[2 * i + 1] + bv[r]};
+      if (p.scale) { v[0] = v[0] * sc[r] + sh[r]; v[1] = v[1] * sc[r] + sh[r]; }
+      v[0] += rr[r][i][0]; v[1] += rr[r][i][1];
       if (relu) { v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f; }
       *reinterpret_cast<wn_f32x2*>(e.out + off + i * p.Wo) = v;
     }
@@ -330,7 +395,8 @@ extern "C" int scf_pack_conv_weight_wino(const float* w, int32_t cout, int32_t c
       for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) {
           const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
-          out[(((size_t)chunk * 16 + (4 * i + j)) * F + frag) * 128 + kh * 64 + m * 2 + s] = (float)u;
+          const int pos = 4 * (i < 2 ? i : 5 - i) + j;        // rows of the transform domain stored in the order 0, 1, 3, 2
+          out[(((size_t)chunk * F + frag) * 16 + pos) * 128 + kh * 64 + m * 2 + s] = (float)u;
         }
     }
   return SCF_OK;
@@ -350,8 +416,12 @@ int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* i
   if (k.in1 && (k.C0 % WN_KC) != 0) return SCF_EUNSUPPORTED;
   if (((uintptr_t)wu & 15) || (long long)WN_KC * k.H * k.W * 4 >= 0x7fffffffLL) return SCF_EUNSUPPORTED;
   const int F = (k.Cout + 31) / 32;
-  int CW, TW;
-  if (F % 2 == 0) { CW = 2; TW = 2; } else { CW = 1; TW = 4; }
+  // two channel fragments of one tile group per block when the fragments pair up and the grid stays
+  // large; else one fragment of two stacked tile groups (all 256 threads transform a window)
+  int CW = 1, TW = 2;
+#ifdef SCF_WINO_LAB
+  if (getenv("SCF_WINO_CW2") && F % 2 == 0) { CW = 2; TW = 1; }
+#endif
   // tiles per row of a wave's group: 16 unless a narrower group wastes clearly fewer columns
   const int tcols = (k.Wo + 1) / 2;
   int txl = 4;
@@ -366,35 +436,45 @@ int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* i
   const int TXW = 1 << txl, TYW = 32 >> txl;
   WinoK q;
   q.wu = wu; q.F = F; q.txl = txl;
-  q.PH = 2 * TW * TYW + 2; q.PW = 2 * TXW + 2; q.PWp = q.PW;
+  // 16-byte patch cells when every row of every plane is 16-byte aligned
+  const bool px4 = (k.W % 4) == 0 && (((uintptr_t)k.in0 | (uintptr_t)k.in1) & 15) == 0 && (k.in0_ns % 4) == 0 && (k.in1_ns % 4) == 0;
+  const int npi = WN_NPI(TW, px4);
+  q.PH = 2 * TW * TYW + 2; q.PW = px4 ? 2 * TXW + 8 : 2 * TXW + 2;
+  // row pitch = TXW mod 32 floats: the TYW tile rows a half-wave reads together then start 2 TXW banks apart
+  // (fewer bank conflicts in the window reads), when the wider patch still fits the slot
+  q.PWp = q.PW + ((TXW - q.PW) & 31);
+  if (WN_KC * q.PH * q.PWp > npi * (px4 ? 1024 : 256)) q.PWp = q.PW;
   q.PPL = q.PH * q.PWp;
-  q.PPL += ((16 - (q.PPL & 31)) + 32) & 31;            // plane stride = 16 mod 32 floats: the two channel planes a half-wave reads hit disjoint banks
-  const int npi = WN_NPI(TW);
-  if (WN_KC * q.PPL > npi * 256) return SCF_EUNSUPPORTED;
+  if (WN_KC * q.PPL > npi * (px4 ? 1024 : 256)) return SCF_EUNSUPPORTED;
   q.nchunk = (k.Cin + WN_KC - 1) / WN_KC;
   q.sx = (k.Wo + 2 * TXW - 1) / (2 * TXW);
   q.sy = (k.Ho + 2 * TW * TYW - 1) / (2 * TW * TYW);
   q.mblocks = F / CW;
   const long long nblk = (long long)N * q.sx * q.sy * q.mblocks;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
-  const size_t ldsb = (size_t)(3 * CW * 2048 + 2 * TW * 2048 + 3 * npi * 256) * sizeof(float);
-  if (ldsb > 160 * 1024) return SCF_EUNSUPPORTED;
+  const size_t ldsb = (size_t)(3 * CW * 2048 + 3 * npi * (px4 ? 1024 : 256)) * sizeof(float) + WN_TRACE_BYTES;
+  if (ldsb > 80 * 1024) return SCF_EUNSUPPORTED;
 #ifdef SCF_WINO_LAB
   q.lab = getenv("SCF_WINO_LAB") ? atoi(getenv("SCF_WINO_LAB")) : 0;
 #endif
   if (info) { info[0] = CW; info[1] = TW; info[2] = (int)nblk; info[3] = (int)ldsb; }
   if (dry_run) return SCF_OK;
-  static bool raised[64][2] = {};
+  static bool raised[64][4] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SCF_ELAUNCH;
-  const int cfg = CW == 2 ? 0 : 1;
-  if (!raised[dev][cfg]) {
-    const int rc = cfg == 0 ? wino_lds_attr((const void*)conv_wino_kernel<2, 2>, 160 * 1024)
-                            : wino_lds_attr((const void*)conv_wino_kernel<1, 4>, 160 * 1024);
+  const int cfg = (CW == 2 ? 0 : 2) + (px4 ? 1 : 0);
+  const void* fn = cfg == 0 ? (const void*)conv_wino_kernel<2, 1, false> : cfg == 1 ? (const void*)conv_wino_kernel<2, 1, true>
+                 : cfg == 2 ? (const void*)conv_wino_kernel<1, 2, false> : (const void*)conv_wino_kernel<1, 2, true>;
+  if (!raised[dev][cfg]) {          // more than 64 KB of dynamic LDS needs the attribute, once per device
+    const int rc = wino_lds_attr(fn, 80 * 1024);
     if (rc != SCF_OK) return rc;
     raised[dev][cfg] = true;
   }
-  if (cfg == 0) scf_launch((conv_wino_kernel<2, 2>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
-  else scf_launch((conv_wino_kernel<1, 4>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
+  switch (cfg) {
+    case 0: scf_launch((conv_wino_kernel<2, 1, false>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q); break;
+    case 1: scf_launch((conv_wino_kernel<2, 1, true>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q); break;
+    case 2: scf_launch((conv_wino_kernel<1, 2, false>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q); break;
+    default: scf_launch((conv_wino_kernel<1, 2, true>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q); break;
+  }
   return scf_launch_status();
 }

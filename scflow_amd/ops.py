@@ -265,19 +265,20 @@ def pack_conv_weight_taps(weight: Tensor) -> Tensor:
 
 def pack_conv_weight_wino(weight: Tensor) -> Tensor:
     """(Cout, Cin, 3, 3) -> U = G g G^T in conv_wino.hip's layout (scf_pack_conv_weight_wino):
-    [chunk][xi = 4i + j][Cout / 32][channel & 1][Cout % 32][channel >> 1 & 1], 4 channels per chunk,
+    [chunk][Cout / 32][4 i' + j][channel & 1][Cout % 32][channel >> 1 & 1] with the rows i of the transform
+    domain stored in the order i' -> 0, 1, 3, 2 (conv_wino.hip gives each of the two rows-halves one wave), 4 channels per chunk,
     computed in double and rounded once; zero padded."""
     cout, cin, kh, kw = weight.shape
     if (kh, kw) != (3, 3):
         raise ValueError('Winograd packing: 3x3 kernels')
     g = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]],
                      dtype=torch.float64, device=weight.device)
-    u = torch.einsum('ia,ocab,jb->ijoc', g, weight.double(), g).reshape(16, cout, cin)
+    u = torch.einsum('ia,ocab,jb->ijoc', g, weight.double(), g)[[0, 1, 3, 2]].reshape(16, cout, cin)   # rows stored 0, 1, 3, 2
     f, nchunk = (cout + 31) // 32, (cin + 3) // 4
     full = torch.zeros((16, f * 32, nchunk * 4), dtype=torch.float64, device=weight.device)
     full[:, :cout, :cin] = u
-    # [xi][frag][m][chunk][s][kh] -> [chunk][xi][frag][kh][m][s]
-    full = full.reshape(16, f, 32, nchunk, 2, 2).permute(3, 0, 1, 5, 2, 4)
+    # [xi][frag][m][chunk][s][kh] -> [chunk][frag][xi][kh][m][s]
+    full = full.reshape(16, f, 32, nchunk, 2, 2).permute(3, 1, 0, 5, 2, 4)
     return full.contiguous().float().reshape(-1)
 
 

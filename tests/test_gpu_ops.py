@@ -343,7 +343,7 @@ def test_conv2d_winograd(case):
     try:
         d, _ = ops.conv_desc(pc, x0, x1, **kw)
         info = (C.c_int32 * 4)()
-        assert lib.scf_conv2d_query(C.byref(d), info) == 0 and info[3] < 0 and info[0] * info[1] == 4, list(info)
+        assert lib.scf_conv2d_query(C.byref(d), info) == 0 and info[3] < 0 and info[0] * info[1] == 2, list(info)
         got = ops.conv2d(pc, x0, x1, **kw)
     finally:
         ops.set_conv_winograd(prev)

@@ -4,11 +4,14 @@ time with the MFMAs / the input transform / the in-loop DMA / the stores / the p
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from scflow_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'bin', 'libscflow_hip_exp.so')
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'bin', f'libscflow_hip_exp{os.environ.get("SCF_EXP_SUFFIX", "")}.so')
 from scflow_amd import ops
 DEV = 'cuda:0'
 cases = [('128->512 @32 N32', 32, 128, 512, 32, 32), ('64->64 @128 N64', 64, 64, 64, 128, 128), ('96->96 @64 N64', 64, 96, 96, 64, 64)]
-masks = [(0, 'full'), (1, 'no MFMA'), (2, 'no transform'), (4, 'no loop DMA'), (8, 'no stores'), (16, 'no barrier'),
+if os.environ.get('SCF_EXP_SUFFIX'):
+    masks = [(0, 'compile-time mask ' + os.environ['SCF_EXP_SUFFIX'])]
+else:
+  masks = [(0, 'full'), (1, 'no MFMA'), (2, 'no transform'), (4, 'no loop DMA'), (8, 'no stores'), (16, 'no barrier'),
          (3, 'no MFMA, no transform'), (6, 'no transform, no DMA'), (7, 'no MFMA/transform/DMA'), (1 + 2 + 4 + 8, 'loop skeleton only')]
 ops.set_conv_winograd(True)
 for name, n, cin, cout, H, W in cases:
