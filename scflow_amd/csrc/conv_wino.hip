@@ -69,6 +69,10 @@ struct WinoK {
 #define WN_T(slot) do { } while (0)
 #undef WN_T_RT
 #define WN_T_RT(slot) do { } while (0)
+#undef WN_T_DUMP
+#define WN_T_DUMP() do { } while (0)
+#undef WN_TRACE_BYTES
+#define WN_TRACE_BYTES 0
 #endif
 #else
 #define WN_LAB(bit) 0
@@ -119,7 +123,7 @@ void conv_wino_kernel(ConvK p, WinoK q) {
 
   float* Us = wn_lds;
   float* Ps = Us + 3 * USLOT;
-#ifdef SCF_WINO_LAB
+#if defined(SCF_WINO_LAB) && !defined(SCF_WINO_LAB_MASK)
   unsigned* wn_trace = reinterpret_cast<unsigned*>(Ps + 3 * PSLOT);
 #endif
   WN_T(0);
@@ -200,30 +204,39 @@ void conv_wino_kernel(ConvK p, WinoK q) {
       for (int i = 0; i < 3; ++i)
         prow[sI][i] = p_lds + (unsigned)((poff + 2 * sI * q.PPL + (xh == 0 ? i : 3 - i) * q.PWp) * 4);
   }
-  float dws[2][3][4];
+  // Packed fp32 adds on the register pairs the LDS reads return (columns 0-1, 2-3 of a window row): 16
+  // instructions per chunk instead of 32.  Written as asm because the op_sel / neg forms of the column
+  // stage are not something hipcc derives (it pairs operands up with moves instead).
+  wn_f32x2 dws[2][3][2];
   auto win_load = [&](unsigned slot_bytes, int sI) {                  // channel 2 sI + half
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const __attribute__((address_space(3))) float* r =
           (const __attribute__((address_space(3))) float*)(uintptr_t)(prow[sI][i] + slot_bytes);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dws[sI][i][j] = r[j];
+      dws[sI][i][0] = wn_f32x2{r[0], r[1]};
+      dws[sI][i][1] = wn_f32x2{r[2], r[3]};
     }
   };
+  const wn_f32x2 sigma2 = {sigma, sigma};
   auto win_transform = [&](wn_f32x2 (&bo)[8], int sI) {                // -> bo[4 il + j][sI]
-    float w[2][4];
-    const float (&e)[3][4] = dws[sI];
+    const wn_f32x2 (&e)[3][2] = dws[sI];
+    wn_f32x2 w[2][2];                  // [il][column pair]
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      w[0][j] = e[0][j] - e[2][j];
-      w[1][j] = __builtin_fmaf(sigma, e[2][j], e[1][j]);
+    for (int h = 0; h < 2; ++h) {
+      asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(w[0][h]) : "v"(e[0][h]), "v"(e[2][h]));   // e0 - e2
+      asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(w[1][h]) : "v"(sigma2), "v"(e[2][h]), "v"(e[1][h]));             // e1 + sigma e2
     }
 #pragma unroll
     for (int il = 0; il < 2; ++il) {
-      bo[4 * il + 0][sI] = w[il][0] - w[il][2];
-      bo[4 * il + 1][sI] = w[il][1] + w[il][2];
-      bo[4 * il + 2][sI] = w[il][2] - w[il][1];
-      bo[4 * il + 3][sI] = w[il][1] - w[il][3];
+      wn_f32x2 v01, v23;
+      // (w0 - w2, w1 + w2): both halves take the low half of (w2, w3), negated for the low result
+      asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(v01) : "v"(w[il][0]), "v"(w[il][1]));
+      // (w2 - w1, w1 - w3): low = w2 - w1, high = -w3 + w1
+      asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v23) : "v"(w[il][1]), "v"(w[il][0]));
+      bo[4 * il + 0][sI] = v01[0];
+      bo[4 * il + 1][sI] = v01[1];
+      bo[4 * il + 2][sI] = v23[0];
+      bo[4 * il + 3][sI] = v23[1];
     }
   };
 

@@ -23,7 +23,7 @@ for name, n, cin, cout, H, W in cases:
     print(name)
     for m, what in masks:
         os.environ['SCF_WINO_LAB'] = str(m)
-        for _ in range(2):
+        for _ in range(300):              # ~60 ms: the shader clock takes a while to ramp up
             ops.conv2d(pc, x, out=out, act=ops.ACT_RELU)
         ts = sorted(ops.time_first_kernel(lambda: ops.conv2d(pc, x, out=out, act=ops.ACT_RELU)) for _ in range(5))
         print(f'   {what:28s} {ts[2]:8.1f} us', flush=True)
