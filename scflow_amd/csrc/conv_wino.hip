@@ -158,28 +158,47 @@ void conv_wino_kernel(ConvK p, WinoK q) {
   const unsigned u_chunk_bytes = (unsigned)(q.F * 8192);
   const unsigned u_total = (unsigned)q.nchunk * u_chunk_bytes;
 
-  auto issue_u = [&](int k, int slot) {          // U[k] -> ring slot (chunks past the end: zeros)
-    const unsigned done = (unsigned)k * u_chunk_bytes;
-    const scf_rsrc4 rs = scf_make_rsrc((const char*)q.wu + done, k < q.nchunk ? u_total - done : 0u);
+  // Both copy streams walk their chunks in order, so the buffer descriptors are kept in SGPRs and advanced
+  // by a constant per chunk (a handful of scalar adds; rebuilding them from the chunk index is ~50 scalar
+  // instructions and two branches per chunk, in front of the wave's next MFMA).  Chunks past the end get
+  // num_records = 0: every lane is out of range and its cell is zeroed.
+  scf_rsrc4 urs = scf_make_rsrc(q.wu, u_total);
+  int u_left = (int)u_total;
+  auto issue_u = [&](int slot) {                   // the next U chunk -> ring slot
     const unsigned dst = u_lds + (unsigned)(slot * USLOT * 4);
 #pragma unroll
-    for (int i = 0; i < NUI; ++i) scf_bdma_b128(rs, uvo[i], dst + uld[i]);
+    for (int i = 0; i < NUI; ++i) scf_bdma_b128(urs, uvo[i], dst + uld[i]);
+    const unsigned lo = (unsigned)urs[0] + u_chunk_bytes;
+    urs[1] += lo < u_chunk_bytes ? 1 : 0;          // carry into base[47:32] (stride bits stay 0: the carry never gets there)
+    urs[0] = (int)lo;
+    u_left -= (int)u_chunk_bytes;
+    urs[2] = u_left > 0 ? u_left : 0;
   };
-  auto issue_p = [&](int k, int slot) {          // patch[k] -> ring slot
-    const int c0 = k * WN_KC;
-    const float* base;
-    int left;
-    if (c0 < p.C0) { base = p.in0 + (long long)n * p.in0_ns + (long long)c0 * HW; left = p.C0 - c0; }
-    else { base = (p.in1 ? p.in1 + (long long)n * p.in1_ns : p.in0) + (long long)(c0 - p.C0) * HW; left = p.in1 ? p.Cin - c0 : 0; }
-    if (left > WN_KC) left = WN_KC;
-    if (left < 0) left = 0;
-    const scf_rsrc4 rs = scf_make_rsrc(base, (unsigned)(left * HW * 4));
+  const unsigned p_chunk_bytes = (unsigned)(WN_KC * HW * 4);
+  const float* p_seg = p.in0 + (long long)n * p.in0_ns;      // current input segment (in0, then in1)
+  int p_left = p.C0;                                 // its channels still to copy
+  bool p_second = p.in1 == nullptr;                  // no (further) segment behind this one
+  scf_rsrc4 prs = scf_make_rsrc(p_seg, (unsigned)((p_left < WN_KC ? p_left : WN_KC) * HW * 4));
+  auto issue_p = [&](int slot) {                   // the next patch chunk -> ring slot
     const unsigned dst = p_lds + (unsigned)((slot * PSLOT + wave * (PX4 ? 256 : 64)) * 4);
 #pragma unroll
     for (int i = 0; i < NPI; ++i) {
-      if (PX4) scf_bdma_b128(rs, pvo[i], dst + (unsigned)(i * 4096));
-      else scf_bdma_b32(rs, pvo[i], dst + (unsigned)(i * 1024));
+      if (PX4) scf_bdma_b128(prs, pvo[i], dst + (unsigned)(i * 4096));
+      else scf_bdma_b32(prs, pvo[i], dst + (unsigned)(i * 1024));
     }
+    p_left -= WN_KC;
+    if (p_left <= 0 && !p_second) {                  // rare: on to the second segment (C0 % 4 == 0 there)
+      p_second = true;
+      p_seg = p.in1 + (long long)n * p.in1_ns;
+      p_left = p.Cin - p.C0;
+      prs = scf_make_rsrc(p_seg, 0u);
+    } else {
+      const unsigned lo = (unsigned)prs[0] + p_chunk_bytes;
+      prs[1] += lo < p_chunk_bytes ? 1 : 0;
+      prs[0] = (int)lo;
+    }
+    const int cl = p_left < WN_KC ? p_left : WN_KC;
+    prs[2] = cl > 0 ? cl * HW * 4 : 0;
   };
 
   // ---- input transform in registers: lane (tile l32, k-half) turns the 4 x 4 windows of channels
@@ -247,9 +266,9 @@ void conv_wino_kernel(ConvK p, WinoK q) {
     for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
   // ---- prologue: patch[0], U[0]; (U[1], patch[1]); (U[2], patch[2]) ---------------------------------
-  issue_p(0, 0); issue_u(0, 0);
-  issue_u(1, 1); issue_p(1, 1);
-  issue_u(2, 2); issue_p(2, 2);
+  issue_p(0); issue_u(0);
+  issue_u(1); issue_p(1);
+  issue_u(2); issue_p(2);
   scf_wait_vmcnt_imm<GRP>();           // all but the last group have landed
   __syncthreads();
   const float* ua = Us + cw * 2048 + xh * 1024 + lane * 2;          // + xi_local * 128
@@ -279,16 +298,17 @@ void conv_wino_kernel(ConvK p, WinoK q) {
     if (!WN_LAB(1)) win_load(pcb, 1);
     __builtin_amdgcn_sched_barrier(0);
     WN_M(2, 0)
-    if (!WN_LAB(2)) {
-      const int s3 = s1 == 0 ? 2 : s1 - 1;          // (c + 3) % 3
-      issue_u(c + 3, s3); issue_p(c + 3, s3);
-    }
+    const int s3 = s1 == 0 ? 2 : s1 - 1;            // (c + 3) % 3
+    if (!WN_LAB(2)) issue_u(s3);
     __builtin_amdgcn_sched_barrier(0);
     WN_M(3, 0)
+    if (!WN_LAB(2)) issue_p(s3);
+    __builtin_amdgcn_sched_barrier(0);
+    WN_M(4, 0)
 #pragma unroll
     for (int x = 0; x < 8; ++x) an[x] = *reinterpret_cast<const wn_f32x2*>(uc + x * 128);
     __builtin_amdgcn_sched_barrier(0);
-    WN_M(4, 0) WN_M(5, 0)
+    WN_M(5, 0)
     if (!WN_LAB(1)) win_transform(bn, 0);
     __builtin_amdgcn_sched_barrier(0);
     WN_M(6, 0) WN_M(7, 0)
@@ -465,6 +485,11 @@ int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* i
   q.mblocks = F / CW;
   const long long nblk = (long long)N * q.sx * q.sy * q.mblocks;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
+  // Small grids stay on the direct kernels: a block here is a serial chain of Cin / 4 chunks (27 us at 128
+  // input channels, 48 us at 256, whatever the grid) and the direct path has a K-split tile for them.  Measured
+  // on all layer shapes of the refiner (tools/lab/wino_sweep.py): 0.4-0.87x at <= 96 blocks, 1.25-1.35x at 128,
+  // 1.5-2x from 192 blocks on.
+  if (nblk < scf_cu_count() / 2) return SCF_EUNSUPPORTED;
   const size_t ldsb = (size_t)(3 * CW * 2048 + 3 * npi * (px4 ? 1024 : 256)) * sizeof(float) + WN_TRACE_BYTES;
   if (ldsb > 80 * 1024) return SCF_EUNSUPPORTED;
 #ifdef SCF_WINO_LAB
