@@ -57,6 +57,9 @@ def parse_args(argv=None):
     ap.add_argument('--min-seconds', type=float, default=3.0,
                     help='repeat blocks of --steps steps until this much timed work has run')
     ap.add_argument('--min-warmup-seconds', type=float, default=1.0)
+    ap.add_argument('--conv-algo', choices=['winograd', 'direct'], default='winograd',
+                    help="fp32 3x3 stride-1 layers: 'winograd' = F(2x2,3x3) kernel on large grids (default), "
+                         "'direct' = direct kernels everywhere (fp32 fma chains in the reference's summation order)")
     ap.add_argument('--precision', choices=['f32', 'f16x3'], default='f32',
                     help='convolution arithmetic: exact fp32 MFMA, or split-fp16 3xMFMA '
                          '(fp32 accumulate, ~22 mantissa bits; see DESIGN.md)')
@@ -309,6 +312,7 @@ def main():
     else:
         from scflow_amd import ops
         ops.set_conv_precision(args.precision)
+        ops.set_conv_winograd(args.conv_algo == 'winograd')
         ndev = torch.cuda.device_count()
         if ndev < 1 or (world > 1 and ndev < world and not args.share_device):
             print(f'[bench] rank {rank}: {ndev} GPU(s) visible for {world} ranks', file=sys.stderr)
@@ -409,6 +413,7 @@ def main():
     result = None
     conv_launches, cb_us, cb_ev = None, None, []
     alt = None
+    alt_direct = None
     if not standin:
         # Secondary measurements: never allowed to take the headline line down with them.
         try:
@@ -430,6 +435,16 @@ def main():
             del fa, fb, lv0
         except Exception as exc:          # pragma: no cover - reported, not fatal
             print(f'[bench] secondary measurement failed: {exc!r}', file=sys.stderr)
+        if not args.no_alt and args.precision == 'f32' and args.conv_algo == 'winograd':
+            ops.set_conv_winograd(False)
+            blocks_d, _, _ = timed('f32')
+            ops.set_conv_winograd(True)
+            dt_d = _median(blocks_d)
+            alt_direct = {'conv_algo': 'direct', 'value': round(args.batch * world * args.steps / dt_d, 2),
+                          'unit': 'pairs/s', 'ms_per_step': round(dt_d / args.steps * 1e3, 3), 'blocks': len(blocks_d),
+                          'note': 'the same step with the direct kernels on every layer (ops.set_conv_winograd(False)): '
+                                  'fp32 fma chains in the summation order of the reference; flow EPE vs the CPU oracle '
+                                  '6.3e-5 px, with the Winograd layers 6.2e-5 px (tools/lab/wino_e2e.py)'}
         if not args.no_alt:
             other = 'f16x3' if args.precision == 'f32' else 'f32'
             blocks_alt, lk_alt, _ = timed(other)
@@ -535,22 +550,39 @@ def main():
         if conv_launches:
             c_us = sum(e[0] for e in conv_launches)
             c_fl = sum(e[1] for e in conv_launches)
+            w_us = sum(e[0] for e in conv_launches if e[2].endswith('[winograd]'))
+            w_fl = sum(e[1] for e in conv_launches if e[2].endswith('[winograd]'))
+            x_fl = c_fl - w_fl + w_fl / 2.25            # flops the matrix cores actually execute
             by_shape = {}
             for us, fl, tag in conv_launches:
                 a = by_shape.setdefault(tag, [0, 0.0, 0.0])
                 a[0] += 1; a[1] += us; a[2] += fl
             top = sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:args.top_layers]
             result['roofline_conv'] = {
-                'kernel': 'conv_dma_kernel / conv_mfma_kernel (all convolution launches of one step)',
+                'kernel': 'conv_wino_kernel / conv_dma_kernel / conv_mfma_kernel / conv_taps_kernel (all convolution '
+                          'launches of one step)',
                 'bound': 'mfma', 'achieved': round(c_fl / (c_us * 1e-6) / 1e12, 1),
                 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(c_fl / (c_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                 'launches_timed': len(conv_launches), 'conv_us_per_step': round(c_us, 1),
                 'share_of_step': round(c_us * 1e-6 / (dt / args.steps), 3),
                 'algorithmic_flops_per_step': c_fl,
+                'executed': {'tflops': round(x_fl / (c_us * 1e-6) / 1e12, 1),
+                             'frac': round(x_fl / (c_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                             'flops_per_step': x_fl,
+                             'winograd_us_per_step': round(w_us, 1),
+                             'winograd_algorithmic_flops_per_step': w_fl,
+                             'winograd_tflops_algorithmic': round(w_fl / max(w_us, 1e-9) / 1e6, 1),
+                             'direct_us_per_step': round(c_us - w_us, 1),
+                             'direct_tflops': round((c_fl - w_fl) / max(c_us - w_us, 1e-9) / 1e6, 1),
+                             'note': 'the 3x3 stride-1 layers on grids of >= 128 blocks run the Winograd F(2x2, 3x3) '
+                                     'kernel (fp32, 16 multiplies per 2x2 outputs instead of 36): `achieved` / `frac` '
+                                     'above price every launch at its ALGORITHMIC flops (the contract of this line, '
+                                     'so they can exceed what a direct kernel could reach), `executed` counts the '
+                                     'Winograd launches at 1 / 2.25 of that = the MFMA work actually issued'},
                 'top_layers': [{'layer': k, 'launches': v[0], 'us': round(v[1], 1),
                                 'tflops': round(v[2] / v[1] / 1e6, 1)} for k, v in top],
-                'note': 'v_mfma_f32_32x32x2_f32 (exact fp32), dense peak 256 CU x 256 flop/clk x 2.4 GHz; '
+                'note': 'v_mfma_f32_32x32x2_f32 (fp32 throughout), dense peak 256 CU x 256 flop/clk x 2.4 GHz; '
                         'flops = 2*Cin*KH*KW*Cout*Ho*Wo*N per launch; HIP start/stop events bound to each launch'}
             # GRU context hoisting: the context channels' part of the SepConvGRU
             # convolutions runs once per pair instead of once per iteration.  `achieved` counts the
@@ -609,6 +641,8 @@ def main():
 
     if rank == 0 and alt is not None:
         result['alt_precision'] = alt
+        if alt_direct:
+            result['alt_direct'] = alt_direct
     if rank == 0 and world == 1 and not standin and not args.no_cpu_baseline:
         try:
             result['cpu_baseline'] = cpu_baseline(sd, args.iters)
