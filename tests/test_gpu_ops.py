@@ -300,7 +300,9 @@ WINO_CASES = [
     (24, 30, 40, 20, 28, 0, False, True, False),       # ragged: Cin % 4 != 0, Cout % 32 != 0, Wo % 32 != 0
     (4, 128, 64, 60, 80, 0, False, False, True),       # 60 x 80 map (480 x 640 crops): narrower tile groups
     (128, 16, 32, 7, 10, 0, False, False, True),       # odd height, tiny width, rows not 16-byte aligned (dword patch copies)
-    (64, 8, 64, 16, 16, 0, False, False, True),
+    (64, 16, 64, 16, 16, 0, False, False, True),       # 4 chunks: the shortest K the kernel takes
+    (5, 64, 96, 64, 64, 0, False, True, True),          # 240 tiles on 512 block slots / odd fragment count
+    (40, 32, 64, 48, 32, 0, False, False, True),        # 960 tiles: persistent blocks walk 2 tiles each (one of them partially)
 ]
 
 

@@ -368,6 +368,32 @@ def test_hipgraph_replay_matches_eager(golden_dir, model):
     model.decoder.iters = 8
 
 
+def test_refiner_winograd_vs_direct(golden_dir, model):
+    """The default path runs the 3x3 stride-1 layers on large grids through the Winograd kernel
+    (conv_wino.hip); at batch 8 that is every encoder layer and the 128 -> 512 head layers.  Same fp32
+    arithmetic, re-associated: against the direct kernels the flow differs by < 1e-4 px over 8 iterations
+    (measured ~3e-5), far inside the 1e-3 px tolerance both hold against the oracle."""
+    from scflow_amd import ops
+    inp = scflow_amd.make_inputs(8, 256, 256, seed=21)
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    model.decoder.iters = 8
+    outs = {}
+    for wino in (True, False):
+        prev = ops.set_conv_winograd(wino)
+        try:
+            outs[wino] = model.get_pose(d['render_images'], d['real_images'], d['ref_rotation'],
+                                        d['ref_translation'], d['depth'], d['internel_k'], d['label'])
+        finally:
+            ops.set_conv_winograd(prev)
+    assert ops.get_conv_winograd()            # the default
+    worst = 0.0
+    for it in range(8):
+        worst = max(worst, oracle.end_point_error(outs[True][1][it].cpu(), outs[False][1][it].cpu()))
+    print(f'[measured] Winograd vs direct kernels, batch 8: worst flow EPE over 8 iterations {worst:.2e} px')
+    assert 0.0 < worst <= 1e-4, f'EPE {worst:.2e}'     # > 0: the two paths really are different kernels
+    close(outs[True][2][-1], outs[False][2][-1].cpu(), atol=2e-6, what='final rotation, Winograd vs direct')
+
+
 def test_full_refiner_f16x3_epe(golden_dir, model):
     """split-fp16 convolutions: the stated tolerance (flow EPE <= 1e-3 px vs the fp32 CPU path)
     must hold with margin over 8 iterations."""
