@@ -23,6 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #include "conv_kernels.h"
+#include "scf_dma.h"
 
 #define SCF_DMA_PU 20   // patch gathers per thread per chunk (256 * 20 floats)
 #define SCF_DMA_WU 7    // weight float4 per thread per chunk
@@ -32,38 +33,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SCF_DMA_PU_X4 8     // PX4: float4 patch cells per thread per chunk (256 * 8 * 4 floats)
 #define SCF_DMA_LDS_MAX (80 * 1024)   // two blocks per CU (160 KB)
 
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
-}
-
-// LDS-DMA through a raw buffer descriptor: `buffer_load_dword[x4] voff, rsrc, 0 offen lds` moves
-// 4 / 16 bytes per lane from rsrc.base + voff to LDS byte M0 + lane * size.  The descriptor's
-// range check does the masking: a lane whose offset is >= num_records writes ZEROS to its LDS
-// cell (checked on gfx950: tools/lab/buf_lds_test.hip), so zero padding, out-of-image positions
-// and the channels past the end of a short last chunk need no EXEC mask, no pre-zeroed LDS and
-// no special path -- and no EXEC write after a vector-memory instruction (~35 cycles of issue
-// stall each: tools/lab/dma_rate.hip).  The compiler does not count these loads: the caller
-// waits (vmcnt) itself.
-typedef int scf_rsrc_t __attribute__((ext_vector_type(4)));
-#define SCF_DMA_OOB 0x80000000u        // an offset past every descriptor range: the lane's cell is zeroed
-
-__device__ __forceinline__ scf_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-  const unsigned long long a = (unsigned long long)base;
-  scf_rsrc_t r;
-  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-  r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu));   // stride 0: raw buffer
-  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);                             // num_records (bytes)
-  r[3] = 0x00020000;
-  return r;
-}
-__device__ __forceinline__ void bdma_b128(scf_rsrc_t rsrc, unsigned voff, unsigned lds_base) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %0, 0 offen lds"
-               : : "s"(rsrc), "v"(voff), "s"(lds_base) : "memory");
-}
-__device__ __forceinline__ void bdma_b32(scf_rsrc_t rsrc, unsigned voff, unsigned lds_base) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %0, 0 offen lds"
-               : : "s"(rsrc), "v"(voff), "s"(lds_base) : "memory");
-}
+// LDS-DMA through raw buffer descriptors: scf_dma.h (scf_make_rsrc, scf_bdma_b128 / _b32; a lane whose offset
+// is >= num_records writes ZEROS to its LDS cell, so zero padding, out-of-image positions and the channels
+// past the end of a short last chunk need no EXEC mask, no pre-zeroed LDS and no special path)
+typedef scf_rsrc4 scf_rsrc_t;
+#define SCF_DMA_OOB SCF_BUF_OOB
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return scf_lds_addr(p); }
+__device__ __forceinline__ scf_rsrc_t make_rsrc(const void* base, unsigned bytes) { return scf_make_rsrc(base, bytes); }
+__device__ __forceinline__ void bdma_b128(scf_rsrc_t rsrc, unsigned voff, unsigned lds_base) { scf_bdma_b128(rsrc, voff, lds_base); }
+__device__ __forceinline__ void bdma_b32(scf_rsrc_t rsrc, unsigned voff, unsigned lds_base) { scf_bdma_b32(rsrc, voff, lds_base); }
 // the first n (0 < n < 64) lanes only: the last, partial slot of an LDS area
 __device__ __forceinline__ void bdma_b128_n(scf_rsrc_t rsrc, unsigned voff, unsigned lds_base, int n) {
   asm volatile("s_bfm_b64 exec, %3, 0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
@@ -116,29 +94,18 @@ __device__ __forceinline__ int fast_div(int e, int d, float rd) {
   return q;
 }
 
-// tools/lab/conv_trace*.py build this file with a per-chunk timeline (tools/lab/conv_lab_hooks.h);
-// the product build sees an empty hook.
+// tools/lab/conv_trace*.py build this file with a per-chunk timeline, tools/lab/conv_phases.py with compile-time
+// phase ablations (tools/lab/conv_lab_hooks.h, -DSCF_CONV_LAB [-DSCF_CONV_LAB_MASK=m]); the product build sees
+// empty hooks
 #ifdef SCF_CONV_LAB
 #include "../../tools/lab/conv_lab_hooks.h"
 #else
 #define CTRACE(slot) do { } while (0)
+#define CLAB(bit) 0
 #endif
 
-// s_waitcnt vmcnt(n) for a wave-uniform RUN-TIME n (the instruction takes an immediate)
-template <int V>
-__device__ __forceinline__ void wait_vmcnt_imm() {
-  __builtin_amdgcn_s_waitcnt(0x0F70 | (V & 15) | ((V >> 4) << 14));
-}
-__device__ __forceinline__ void wait_vmcnt_le(int n) {
-#define SCF_W4(b) case b: wait_vmcnt_imm<b>(); break; case b + 1: wait_vmcnt_imm<b + 1>(); break; \
-                  case b + 2: wait_vmcnt_imm<b + 2>(); break; case b + 3: wait_vmcnt_imm<b + 3>(); break;
-  switch (n) {
-    SCF_W4(0) SCF_W4(4) SCF_W4(8) SCF_W4(12) SCF_W4(16) SCF_W4(20) SCF_W4(24) SCF_W4(28)
-    SCF_W4(32) SCF_W4(36) SCF_W4(40) SCF_W4(44) SCF_W4(48) SCF_W4(52) SCF_W4(56) SCF_W4(60)
-    default: wait_vmcnt_imm<0>(); break;
-  }
-#undef SCF_W4
-}
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n: scf_wait_vmcnt_le (scf_dma.h)
+__device__ __forceinline__ void wait_vmcnt_le(int n) { scf_wait_vmcnt_le(n); }
 
 // NST   : chunk buffers in the LDS ring.  2 = chunk c+1 streams in while chunk c is on the matrix
 //         cores (large grids: co-resident blocks hide each other's latency).  Small grids (batch 1:
@@ -353,7 +320,7 @@ __global__ __launch_bounds__(256, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel
     CTRACE(4 + chunk * 4);
     __syncthreads();                                   // everyone's has; previous MFMA phase done
     CTRACE(5 + chunk * 4);
-    if (chunk + NST - 1 < p.nchunk) stage(chunk + NST - 1, buf == 0 ? NST - 1 : buf - 1);
+    if (!CLAB(0) && chunk + NST - 1 < p.nchunk) stage(chunk + NST - 1, buf == 0 ? NST - 1 : buf - 1);
     CTRACE(6 + chunk * 4);
     __builtin_amdgcn_s_setprio(0);                     // the MFMA stream yields to the other waves
 
@@ -425,6 +392,7 @@ __global__ __launch_bounds__(256, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel
       }
     };
     auto mma = [&](const f32x4 (&aa)[WM], const f32x4 (&bb)[WN]) {
+      if (CLAB(1)) { asm volatile("" : : "v"(aa[0]), "v"(bb[0])); return; }
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -495,7 +463,7 @@ __global__ __launch_bounds__(256, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel
                                : oy * p.Wo + ox;
     pix[j] = pok ? lin : -1;
   }
-  scf_conv_epilogue_tile<WM, WN>(p, epi, acc, m0, half, pix, use_div);
+  if (!CLAB(2)) scf_conv_epilogue_tile<WM, WN>(p, epi, acc, m0, half, pix, use_div);
   CTRACE(3);
 }
 

@@ -20,33 +20,9 @@
 // Blocks overlap each other's staging; nothing is chunk-pipelined because nothing needs to be.
 #include "scf_common.h"
 #include "conv_kernels.h"
+#include "scf_dma.h"     // LDS-DMA through raw buffer descriptors: out-of-range lanes write zeros
 
 typedef float ct_f32x16 __attribute__((ext_vector_type(16)));
-
-// LDS-DMA through a raw buffer descriptor (as in conv_dma.hip): a lane whose offset is past
-// num_records gets ZEROS written to its LDS cell -- zero padding and the areas' tail cells for free.
-typedef int ct_rsrc_t __attribute__((ext_vector_type(4)));
-#define CT_OOB 0x80000000u
-__device__ __forceinline__ unsigned ct_lds_addr(const void* p) {
-  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
-}
-__device__ __forceinline__ ct_rsrc_t ct_make_rsrc(const void* base, unsigned bytes) {
-  const unsigned long long a = (unsigned long long)base;
-  ct_rsrc_t r;
-  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-  r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu));
-  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
-  r[3] = 0x00020000;
-  return r;
-}
-__device__ __forceinline__ void ct_dma_b128(ct_rsrc_t rsrc, unsigned voff, unsigned lds_base) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %0, 0 offen lds"
-               : : "s"(rsrc), "v"(voff), "s"(lds_base) : "memory");
-}
-__device__ __forceinline__ void ct_dma_b32(ct_rsrc_t rsrc, unsigned voff, unsigned lds_base) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %0, 0 offen lds"
-               : : "s"(rsrc), "v"(voff), "s"(lds_base) : "memory");
-}
 
 template <int WM>
 __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvK p, const float* __restrict__ wt, int Kp, int PWp) {
@@ -82,17 +58,17 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvK p, const float*
 
   // ---- everything is requested up front (asynchronous memory -> LDS copies), then ONE wait ----
   {
-    const ct_rsrc_t wrs = ct_make_rsrc(wt + m0, (unsigned)(((long long)(Kp - 1) * p.Mld + BM) * 4));
-    const unsigned wl = ct_lds_addr(Ws);
+    const scf_rsrc4 wrs = scf_make_rsrc(wt + m0, (unsigned)(((long long)(Kp - 1) * p.Mld + BM) * 4));
+    const unsigned wl = scf_lds_addr(Ws);
     for (int c0 = wave * 64; c0 < w_cells; c0 += 256) {   // wave-uniform trip count
       const int e = c0 + lane;
       const int row = e / q4, c4 = e - row * q4;
-      const unsigned voff = e < n4 ? (unsigned)((row * p.Mld + 4 * c4) * 4) : CT_OOB;
-      ct_dma_b128(wrs, voff, wl + (unsigned)c0 * 16u);
+      const unsigned voff = e < n4 ? (unsigned)((row * p.Mld + 4 * c4) * 4) : SCF_BUF_OOB;
+      scf_bdma_b128(wrs, voff, wl + (unsigned)c0 * 16u);
     }
     const int HW = p.H * p.W;
-    const ct_rsrc_t xrs = ct_make_rsrc(p.in0 + (long long)n * p.in0_ns, (unsigned)((long long)p.Cin * HW * 4));
-    const unsigned xl = ct_lds_addr(Xs);
+    const scf_rsrc4 xrs = scf_make_rsrc(p.in0 + (long long)n * p.in0_ns, (unsigned)((long long)p.Cin * HW * 4));
+    const unsigned xl = scf_lds_addr(Xs);
     const float rPHW = 1.0f / (float)PHW, rPW = 1.0f / (float)PWp;
     for (int c0 = wave * 64; c0 < x_cells; c0 += 256) {
       const int e = c0 + lane;
@@ -104,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvK p, const float*
       if (px < 0) { --py; px += PWp; } else if (px >= PWp) { ++py; px -= PWp; }
       const int iy = iy0 + py, ix = ix0 + px;
       const bool ok = e < PE && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      ct_dma_b32(xrs, ok ? (unsigned)((c * HW + iy * p.W + ix) * 4) : CT_OOB, xl + (unsigned)c0 * 4u);
+      scf_bdma_b32(xrs, ok ? (unsigned)((c * HW + iy * p.W + ix) * 4) : SCF_BUF_OOB, xl + (unsigned)c0 * 4u);
     }
   }
   // ---- tap table: k = c * T + t -> patch offset; padding rows (k >= Cin * T: zero weights) read cell 0 ----

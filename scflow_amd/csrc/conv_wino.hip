@@ -45,6 +45,15 @@ typedef float wn_f32x2 __attribute__((ext_vector_type(2)));
 #define WN_NPI(TW, PX4) ((PX4) ? ((TW) == 2 ? 3 : 2) : ((TW) == 2 ? 8 : 5))
 #define WN_KC 4             // channels per chunk
 
+// tools/lab/wino_phases.py builds this file with compile-time phase ablations (tools/lab/wino_lab_hooks.h,
+// -DSCF_WINO_LAB -DSCF_WINO_LAB_MASK=m); the product build sees constants
+#ifdef SCF_WINO_LAB
+#include "../../tools/lab/wino_lab_hooks.h"
+#else
+#define WN_LAB(bit) 0
+#define WN_LAB_FIELDS
+#endif
+
 struct WinoK {
   const float* wu;          // [nchunk][F][16][2][32][2]
   int F;                    // channel fragments in the packing
@@ -53,35 +62,8 @@ struct WinoK {
   int nchunk;
   int sx, sy;               // strips per image
   int mblocks;
-#ifdef SCF_WINO_LAB
-  int lab;                  // tools/lab/wino_phases.py: bit 0 no MFMAs, 1 no transform, 2 no DMA in the loop, 3 no stores, 4 no barrier
-#endif
+  WN_LAB_FIELDS
 };
-#ifdef SCF_WINO_LAB
-#ifdef SCF_WINO_LAB_MASK            // compile-time ablation (no run-time branches in the loop)
-#define WN_LAB(bit) ((SCF_WINO_LAB_MASK >> (bit)) & 1)
-#else
-#define WN_LAB(bit) (q.lab & (1 << (bit)))
-#endif
-#include "../../tools/lab/wino_lab_hooks.h"
-#ifdef SCF_WINO_LAB_MASK
-#undef WN_T
-#define WN_T(slot) do { } while (0)
-#undef WN_T_RT
-#define WN_T_RT(slot) do { } while (0)
-#undef WN_T_DUMP
-#define WN_T_DUMP() do { } while (0)
-#undef WN_TRACE_BYTES
-#define WN_TRACE_BYTES 0
-#endif
-#else
-#define WN_LAB(bit) 0
-#define WN_TRACE_BYTES 0
-#define WN_T(slot) do { } while (0)
-#define WN_T_RT(slot) do { } while (0)
-#define WN_T_CHUNK(c, k) do { } while (0)
-#define WN_T_DUMP() do { } while (0)
-#endif
 
 // floor(e / d) for 0 <= e < 2^20, 0 < d < 2^12 without the integer-division expansion
 __device__ __forceinline__ int wn_div(int e, int d, float rd) {
@@ -123,11 +105,6 @@ void conv_wino_kernel(ConvK p, WinoK q) {
 
   float* Us = wn_lds;
   float* Ps = Us + 3 * USLOT;
-#if defined(SCF_WINO_LAB) && !defined(SCF_WINO_LAB_MASK)
-  unsigned* wn_trace = reinterpret_cast<unsigned*>(Ps + 3 * PSLOT);
-#endif
-  WN_T(0);
-  WN_T_RT(118);
   const unsigned u_lds = scf_lds_addr(Us), p_lds = scf_lds_addr(Ps);
 
   // ---- chunk-invariant DMA offsets --------------------------------------------------------------
@@ -278,7 +255,6 @@ void conv_wino_kernel(ConvK p, WinoK q) {
   win_load(0u, 0); win_transform(b0, 0);
   win_load(0u, 1); win_transform(b0, 1);
   __syncthreads();                     // slot 0 of both rings is free again
-  WN_T(1);
 
   // chunk c: the operands of chunk c are in registers (a, b); those of chunk c + 1 are read (U) / computed
   // (patch) into (an, bn) under its MFMAs; the copies of chunk c + 3 are issued, those of chunk c + 2 must have
@@ -328,7 +304,6 @@ void conv_wino_kernel(ConvK p, WinoK q) {
   }
   if (c < q.nchunk) chunk(c, a0, b0, a1, b1);
   scf_wait_vmcnt_imm<0>();             // the zero-filled groups past the end
-  WN_T(122);
   __syncthreads();                     // every wave's copies have landed: the rings are free for the exchange
 
   // ---- output transform of this wave's two rows of the transform domain -----------------------------
@@ -354,9 +329,7 @@ void conv_wino_kernel(ConvK p, WinoK q) {
     if ((r >> 3) == xh) own[r & 7] = y;
     else *reinterpret_cast<wn_f32x4*>(xw + ((r & 7) * 64 + lane) * 4) = y;
   }
-  WN_T(123);
   __syncthreads();
-  WN_T_DUMP();
 
   const ConvEpi e = scf_conv_epi(p, n);
   const int oy = y0 + 2 * ty, ox = x0 + 2 * tx;
@@ -449,12 +422,9 @@ int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* i
   if (k.in1 && (k.C0 % WN_KC) != 0) return SCF_EUNSUPPORTED;
   if (((uintptr_t)wu & 15) || (long long)WN_KC * k.H * k.W * 4 >= 0x7fffffffLL) return SCF_EUNSUPPORTED;
   const int F = (k.Cout + 31) / 32;
-  // two channel fragments of one tile group per block when the fragments pair up and the grid stays
-  // large; else one fragment of two stacked tile groups (all 256 threads transform a window)
-  int CW = 1, TW = 2;
-#ifdef SCF_WINO_LAB
-  if (getenv("SCF_WINO_CW2") && F % 2 == 0) { CW = 2; TW = 1; }
-#endif
+  // a block = one channel fragment of two vertically stacked tile groups (8 x 32 outputs on a wide map): the
+  // two wave pairs share the U chunk
+  const int CW = 1, TW = 2;
   // tiles per row of a wave's group: 16 unless a narrower group wastes clearly fewer columns
   const int tcols = (k.Wo + 1) / 2;
   int txl = 4;
@@ -490,29 +460,20 @@ int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* i
   // on all layer shapes of the refiner (tools/lab/wino_sweep.py): 0.4-0.87x at <= 96 blocks, 1.25-1.35x at 128,
   // 1.5-2x from 192 blocks on.
   if (nblk < scf_cu_count() / 2) return SCF_EUNSUPPORTED;
-  const size_t ldsb = (size_t)(3 * CW * 2048 + 3 * npi * (px4 ? 1024 : 256)) * sizeof(float) + WN_TRACE_BYTES;
+  const size_t ldsb = (size_t)(3 * CW * 2048 + 3 * npi * (px4 ? 1024 : 256)) * sizeof(float);
   if (ldsb > 80 * 1024) return SCF_EUNSUPPORTED;
-#ifdef SCF_WINO_LAB
-  q.lab = getenv("SCF_WINO_LAB") ? atoi(getenv("SCF_WINO_LAB")) : 0;
-#endif
   if (info) { info[0] = CW; info[1] = TW; info[2] = (int)nblk; info[3] = (int)ldsb; }
   if (dry_run) return SCF_OK;
-  static bool raised[64][4] = {};
+  static bool raised[64][2] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SCF_ELAUNCH;
-  const int cfg = (CW == 2 ? 0 : 2) + (px4 ? 1 : 0);
-  const void* fn = cfg == 0 ? (const void*)conv_wino_kernel<2, 1, false> : cfg == 1 ? (const void*)conv_wino_kernel<2, 1, true>
-                 : cfg == 2 ? (const void*)conv_wino_kernel<1, 2, false> : (const void*)conv_wino_kernel<1, 2, true>;
+  const int cfg = px4 ? 1 : 0;
   if (!raised[dev][cfg]) {          // more than 64 KB of dynamic LDS needs the attribute, once per device
-    const int rc = wino_lds_attr(fn, 80 * 1024);
+    const int rc = wino_lds_attr(cfg ? (const void*)conv_wino_kernel<1, 2, true> : (const void*)conv_wino_kernel<1, 2, false>, 80 * 1024);
     if (rc != SCF_OK) return rc;
     raised[dev][cfg] = true;
   }
-  switch (cfg) {
-    case 0: scf_launch((conv_wino_kernel<2, 1, false>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q); break;
-    case 1: scf_launch((conv_wino_kernel<2, 1, true>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q); break;
-    case 2: scf_launch((conv_wino_kernel<1, 2, false>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q); break;
-    default: scf_launch((conv_wino_kernel<1, 2, true>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q); break;
-  }
+  if (cfg) scf_launch((conv_wino_kernel<1, 2, true>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
+  else scf_launch((conv_wino_kernel<1, 2, false>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
   return scf_launch_status();
 }

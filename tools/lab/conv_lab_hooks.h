@@ -3,6 +3,13 @@
 // scflow_amd/csrc/conv_dma.hip includes this file only when compiled with -DSCF_CONV_LAB
 // (tools/lab/build_exp.sh "-DSCF_CONV_LAB").
 #pragma once
+// -DSCF_CONV_LAB_MASK=m: compile-time phase ablation instead of the timeline (tools/lab/build_conv_masks.sh,
+// conv_phases.py): bit 0 no copies in the chunk loop, bit 1 no MFMAs, bit 2 no epilogue (results are wrong)
+#ifdef SCF_CONV_LAB_MASK
+#define CLAB(bit) ((SCF_CONV_LAB_MASK >> (bit)) & 1)
+#define CTRACE(slot) do { } while (0)
+#else
+#define CLAB(bit) 0
 __device__ unsigned long long* scf_conv_trace_ptr = nullptr;
 __device__ int scf_conv_trace_nblk = 0;
 extern "C" int scf_conv_trace_set(unsigned long long* p, int nblk) {
@@ -21,3 +28,4 @@ extern "C" int scf_conv_trace_set(unsigned long long* p, int nblk) {
                                   ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32); \
     }                                                                                             \
   } while (0)
+#endif
