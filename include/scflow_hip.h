@@ -55,7 +55,7 @@ enum {
  * SCF_ABI_MAJOR before its first call; structs additionally carry no size field,
  * so a mismatch must be refused, not worked around. */
 #define SCF_ABI_MAJOR 3
-#define SCF_VERSION (SCF_ABI_MAJOR * 100 + 4)
+#define SCF_VERSION (SCF_ABI_MAJOR * 100 + 5)
 int scf_version(void);
 const char* scf_error_string(int code);
 /* number of HIP devices visible (>=0) or SCF_ENODEVICE */
@@ -175,6 +175,9 @@ typedef struct scf_conv_desc {
                                            every block is alone on its CU, a launch is a chain of one memory
                                            round trip per chunk, so half as many chunks is half the chain)    */
   int32_t a4t_groups;
+  const float* wp_wino1d;               /* optional: G g of a 1x5 / 5x1 stride-1 'same' layer (scf_pack_conv_weight_wino1d);
+                                           selects the one-dimensional Winograd F(2, 5) fp32 kernel (every epilogue
+                                           kind incl. the GRU gates) on grids of >= 128 blocks; same contract as wp_wino */
   const float* wp_wino;                 /* optional: G g G^T of a 3x3 / stride-1 / pad-1 layer
                                            (scf_pack_conv_weight_wino); selects the Winograd F(2x2, 3x3)
                                            fp32 kernel for plain / affine epilogues (bias, BN, residual,
@@ -203,6 +206,10 @@ int scf_pack_conv_weight_taps(const float* w, int Cout, int Cin, int KH, int KW,
  *   in double and rounded once;  out[((chunk*F + co/32)*16 + 4*pi(i) + j)*128 + (cl & 1)*64 + (co % 32)*2 + (cl >> 1)],
  *   pi = (0, 1, 3, 2): the rows of the transform domain are stored in the order 0, 1, 3, 2,
  *   with ci = 4*chunk + cl, F = Cout rounded up to 32, / 32; zeros elsewhere */
+int64_t scf_pack_conv_weight_wino1d_size(int32_t Cout, int32_t Cin);
+int scf_pack_conv_weight_wino1d(const float* w, int32_t Cout, int32_t Cin, float* out);   /* w: (Cout, Cin, 5) taps;
+     out[((chunk*F + co/32)*6 + i)*256 + (cl & 1)*128 + (co % 32)*4 + (cl >> 1)] = (G g)[i], ci = 8*chunk + cl,
+     G = the 6 x 5 matrix of the points 0, 1, -1, 2, -2, infinity */
 int64_t scf_pack_conv_weight_wino_size(int32_t Cout, int32_t Cin);
 int scf_pack_conv_weight_wino(const float* w, int32_t Cout, int32_t Cin, float* out);
 
@@ -235,6 +242,7 @@ typedef struct scf_gru_pass {
   const float* wp_zr_k32; const float* wp_q_k32;
   const float* wp_zr_a4s; const float* wp_q_a4s; int32_t a4s_groups;
   const float* wp_zr_a4t; const float* wp_q_a4t; int32_t a4t_groups;   /* 3x3 passes: tiny-grid packings (scf_conv_desc.wp_a4t), optional */
+  const float* wp_zr_wino1d; const float* wp_q_wino1d;   /* 1x5 / 5x1 passes: F(2, 5) packings (scf_conv_desc.wp_wino1d), optional */
 } scf_gru_pass;
 
 int scf_sepconv_gru(float* hx, int64_t hx_nstride, int N, int Ch, int Cx, int H, int W,

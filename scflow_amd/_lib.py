@@ -51,6 +51,7 @@ class ConvDesc(C.Structure):
         ('wp_taps', _fp),
         ('wp_a4t', _fp),
         ('a4t_groups', C.c_int32),
+        ('wp_wino1d', _fp),
         ('wp_wino', _fp),
     ]
 
@@ -65,6 +66,7 @@ class GruPass(C.Structure):
         ('wp_zr_k32', _fp), ('wp_q_k32', _fp),
         ('wp_zr_a4s', _fp), ('wp_q_a4s', _fp), ('a4s_groups', C.c_int32),
         ('wp_zr_a4t', _fp), ('wp_q_a4t', _fp), ('a4t_groups', C.c_int32),
+        ('wp_zr_wino1d', _fp), ('wp_q_wino1d', _fp),
     ]
 
 
@@ -134,6 +136,8 @@ SIGNATURES = {
     'scf_pack_conv_weight_a4': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'scf_pack_conv_weight_taps_size': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'scf_pack_conv_weight_taps': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    'scf_pack_conv_weight_wino1d_size': (C.c_int64, [C.c_int32, C.c_int32]),
+    'scf_pack_conv_weight_wino1d': (C.c_int, [_fp, C.c_int32, C.c_int32, _fp]),
     'scf_pack_conv_weight_wino_size': (C.c_int64, [C.c_int32, C.c_int32]),
     'scf_pack_conv_weight_wino': (C.c_int, [_fp, C.c_int32, C.c_int32, _fp]),
     'scf_sepconv_gru': (C.c_int, [_fp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

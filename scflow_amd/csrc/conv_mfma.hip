@@ -556,6 +556,10 @@ extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
     const int rw = scf_conv_wino_dispatch(pl.k, d->wp_wino, d->N, false, nullptr, scf_stream(stream));
     if (rw != SCF_EUNSUPPORTED) return rw;
   }
+  if (d->wp_wino1d) {
+    const int rw = scf_conv_wino1d_dispatch(pl.k, d->wp_wino1d, d->N, false, nullptr, scf_stream(stream));
+    if (rw != SCF_EUNSUPPORTED) return rw;
+  }
   if (want_f16x3(d)) {
     const int r16 = scf_conv_f16x3_dispatch(pl.k, d->N, false, nullptr, scf_stream(stream));
     if (r16 != SCF_EUNSUPPORTED) return r16;
@@ -631,6 +635,7 @@ static int sepconv_gru_impl(float* hx, int64_t hx_nstride, int N, int Ch, int Cs
     d.wp_a4 = g.wp_zr_a4; d.a4_groups = g.a4_groups; d.a4_mld = d.Mld; d.wp_f16 = g.wp_zr_f16;
     d.wp_a4s = g.wp_zr_a4s; d.a4s_groups = g.a4s_groups;
     d.wp_a4t = g.wp_zr_a4t; d.a4t_groups = g.a4t_groups;
+    d.wp_wino1d = g.wp_zr_wino1d;
     d.out = z; d.out_nstride = Ch * hw;
     d.mode = SCF_CONV_GRU_ZR; d.gru_h = hx; d.gru_h_nstride = hx_nstride;
     d.gru_aux = rh; d.gru_aux_nstride = Ch * hw;
@@ -645,6 +650,7 @@ static int sepconv_gru_impl(float* hx, int64_t hx_nstride, int N, int Ch, int Cs
     d.wp_a4 = g.wp_q_a4; d.a4_mld = d.Mld; d.wp_f16 = g.wp_q_f16;
     d.wp_a4s = g.wp_q_a4s;
     d.wp_a4t = g.wp_q_a4t;
+    d.wp_wino1d = g.wp_q_wino1d;
     d.out = hx; d.out_nstride = hx_nstride;
     d.mode = SCF_CONV_GRU_Q; d.gru_h = hx; d.gru_h_nstride = hx_nstride;
     d.gru_aux = nullptr; d.gru_aux_nstride = 0;
@@ -699,6 +705,10 @@ extern "C" int scf_conv2d_query(const scf_conv_desc* d, int32_t* info) {
   }
   if (d->wp_wino && scf_conv_wino_dispatch(pl.k, d->wp_wino, d->N, true, info, nullptr) == SCF_OK) {
     info[3] = -info[3];      // negative: the Winograd kernel will run (info = CW, TW, blocks, -LDS bytes)
+    return SCF_OK;
+  }
+  if (d->wp_wino1d && scf_conv_wino1d_dispatch(pl.k, d->wp_wino1d, d->N, true, info, nullptr) == SCF_OK) {
+    info[3] = -info[3];      // negative: the F(2, 5) kernel will run (info = 2, 2, blocks, -LDS bytes)
     return SCF_OK;
   }
   if (want_f16x3(d) && scf_conv_f16x3_dispatch(pl.k, d->N, true, info, nullptr) == SCF_OK) {

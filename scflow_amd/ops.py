@@ -25,7 +25,7 @@ from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_GRU_Q, CONV_G
 
 Tensor = torch.Tensor
 
-__all__ = ['PackedConv', 'conv_desc', 'gru_passes', 'scflow_iteration', 'side_stream_handle', 'pyramid_layout', 'untile_level', 'level_storage_shape', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision', 'set_conv_winograd', 'get_conv_winograd', 'pack_conv_weight_wino',
+__all__ = ['PackedConv', 'conv_desc', 'gru_passes', 'scflow_iteration', 'side_stream_handle', 'pyramid_layout', 'untile_level', 'level_storage_shape', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision', 'set_conv_winograd', 'get_conv_winograd', 'pack_conv_weight_wino', 'pack_conv_weight_wino1d',
            'get_conv_precision', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
            'instance_norm', 'group_norm_relu', 'linear', 'pose_update', 'reproject_flow',
            'unproject_depth', 'linear_pair', 'resize_bilinear', 'convex_upsample', 'avgpool2x2', 'copy_channels',
@@ -282,6 +282,35 @@ def pack_conv_weight_wino(weight: Tensor) -> Tensor:
     return full.contiguous().float().reshape(-1)
 
 
+def pack_conv_weight_wino1d(weight: Tensor) -> Tensor:
+    """(Cout, Cin, 1, 5) or (Cout, Cin, 5, 1) -> U = G g in conv_wino1d.hip's layout (scf_pack_conv_weight_wino1d):
+    [chunk][Cout / 32][position i][channel & 1][Cout % 32][channel >> 1 & 3], 8 channels per chunk; G = the 6 x 5
+    matrix of the points 0, 1, -1, 2, -2, infinity; computed in double and rounded once; zero padded."""
+    cout, cin, kh, kw = weight.shape
+    if (kh, kw) not in ((1, 5), (5, 1)):
+        raise ValueError('F(2, 5) packing: 1x5 / 5x1 kernels')
+    pts = [0.0, 1.0, -1.0, 2.0, -2.0]
+    g = torch.zeros((6, 5), dtype=torch.float64)
+    for i, a in enumerate(pts):
+        nrm = 1.0
+        for k, b in enumerate(pts):
+            if k != i:
+                nrm *= a - b
+        g[i] = torch.tensor([a ** k / nrm for k in range(5)], dtype=torch.float64)
+    g[5, 4] = 1.0
+    wd = weight.reshape(cout, cin, 5).double()
+    g = g.to(weight.device)
+    u = torch.zeros((6, cout, cin), dtype=torch.float64, device=weight.device)
+    for k in range(5):                   # the C packer's order of adds: bit-identical packings
+        u = u + g[:, k, None, None] * wd[None, :, :, k]
+    f, nchunk = (cout + 31) // 32, (cin + 7) // 8
+    full = torch.zeros((6, f * 32, nchunk * 8), dtype=torch.float64, device=weight.device)
+    full[:, :cout, :cin] = u
+    # [i][frag][m][chunk][s][kh] -> [chunk][frag][i][kh][m][s]
+    full = full.reshape(6, f, 32, nchunk, 4, 2).permute(3, 1, 0, 5, 2, 4)
+    return full.contiguous().float().reshape(-1)
+
+
 _CONV_PRECISION = 'f32'
 _CONV_WINOGRAD = True
 
@@ -348,6 +377,7 @@ class PackedConv:
     wp4t: Optional[Tensor] = None     # tiny-grid LDS-DMA packing of 3x3 layers (32-channel chunks)
     g4t: int = 0
     wwino: Optional[Tensor] = None    # G g G^T packing (3x3, stride 1, pad 1, Cin >= 8)
+    wwino1d: Optional[Tensor] = None  # G g packing (1x5 / 5x1, stride 1, 'same', Cin >= 16, Cout % 64 == 0)
 
     @staticmethod
     def from_weight(weight: Tensor, bias: Optional[Tensor], stride: int = 1,
@@ -378,7 +408,9 @@ class PackedConv:
                           wp4s, g4s, pack_conv_weight_taps(weight) if (cin <= 4 and dma_packing) else None,
                           None, *PackedConv._tiny(weight, kh, kw, stride, dma_packing),
                           pack_conv_weight_wino(weight) if (dma_packing and (kh, kw, stride, ph, pw) == (3, 3, 1, 1, 1)
-                                                            and cin >= 8) else None)
+                                                            and cin >= 8) else None,
+                          pack_conv_weight_wino1d(weight) if (dma_packing and stride == 1 and cin >= 16 and cout % 64 == 0
+                                                              and (kh, kw, ph, pw) in ((1, 5, 0, 2), (5, 1, 2, 0))) else None)
 
     @staticmethod
     def _tiny(weight, kh, kw, stride, dma_packing):
@@ -473,6 +505,8 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
         d.wp_f16 = pc.wp16.data_ptr()
     elif _CONV_WINOGRAD and pc.wwino is not None and mode == CONV_PLAIN:
         d.wp_wino = pc.wwino.data_ptr()
+    elif _CONV_WINOGRAD and pc.wwino1d is not None:
+        d.wp_wino1d = pc.wwino1d.data_ptr()
     if x1 is not None:
         d.wp_taps = None                # the thin-input kernel takes one input segment
     if pc.wp_alt is not None and (c1 == 0 or c0 % 32 == 0):
@@ -533,6 +567,8 @@ def _gru_passes(packs):
             g.wp_zr_a4s, g.wp_q_a4s, g.a4s_groups = pzr.wp4s.data_ptr(), pq.wp4s.data_ptr(), pzr.g4s
         if pzr.wp4t is not None and pq.wp4t is not None and pzr.g4t == pq.g4t:
             g.wp_zr_a4t, g.wp_q_a4t, g.a4t_groups = pzr.wp4t.data_ptr(), pq.wp4t.data_ptr(), pzr.g4t
+        if _CONV_WINOGRAD and not f16 and pzr.wwino1d is not None and pq.wwino1d is not None:
+            g.wp_zr_wino1d, g.wp_q_wino1d = pzr.wwino1d.data_ptr(), pq.wwino1d.data_ptr()
     return arr
 
 

@@ -362,6 +362,57 @@ def test_conv2d_winograd(case):
     assert lib.scf_conv2d_query(C.byref(d), info) == 0 and not (info[3] < 0 and info[0] * info[1] == 2), list(info)
 
 
+WINO1D_CASES = [
+    # n, cin, cout, k, H, W, c0 split -- every case is >= 128 blocks
+    (8, 256, 256, (1, 5), 32, 32, 128),     # GRU z|r, horizontal pass
+    (16, 256, 128, (5, 1), 32, 32, 128),    # GRU q, vertical pass
+    (32, 40, 64, (1, 5), 20, 30, 0),        # ragged: Cin % 8 != 0, Wo % 4 != 0 (dword patch copies), odd tile rows
+    (24, 48, 64, (5, 1), 21, 28, 0),        # vertical, odd height
+    (2, 64, 128, (1, 5), 60, 80, 0),        # 60 x 80 maps
+    (2, 64, 128, (5, 1), 60, 80, 0),
+]
+
+
+@pytest.mark.parametrize('case', WINO1D_CASES)
+def test_conv2d_winograd_1d(case):
+    """F(2, 5) kernel (conv_wino1d.hip) vs torch fp64 and vs the direct kernel, plain epilogue with residual
+    + ReLU; the GRU epilogues on it are covered by test_sepconv_gru_winograd."""
+    import ctypes as C
+    n, cin, cout, k, H, W, c0 = case
+    pad = (0, 2) if k == (1, 5) else (2, 0)
+    x = rnd((n, cin, H, W), 50)
+    wt = rnd((cout, cin, *k), 51, (1.0 / (cin * 5)) ** 0.5)
+    b = rnd((cout,), 52, 0.1)
+    want = F.conv2d(x.double(), wt.double(), b.double(), padding=pad)
+    res = rnd(tuple(want.shape), 53)
+    want = torch.relu(want + res.double()).float()
+    pc = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), padding=pad)
+    assert pc.wwino1d is not None
+    lib = ops._lib.load()
+    host = torch.empty(lib.scf_pack_conv_weight_wino1d_size(cout, cin))
+    wc = wt.reshape(cout, cin, 5).contiguous()
+    assert lib.scf_pack_conv_weight_wino1d(wc.data_ptr(), cout, cin, host.data_ptr()) == 0
+    assert torch.equal(host, pc.wwino1d.cpu())
+    xd = x.to(DEV)
+    x0, x1 = (xd[:, :c0], xd[:, c0:]) if c0 else (xd, None)
+    kw = dict(res=res.to(DEV), act=ops.ACT_RELU)
+    prev = ops.set_conv_winograd(False)
+    try:
+        direct = ops.conv2d(pc, x0, x1, **kw)
+        ops.set_conv_winograd(True)
+        d, _ = ops.conv_desc(pc, x0, x1, **kw)
+        info = (C.c_int32 * 4)()
+        assert lib.scf_conv2d_query(C.byref(d), info) == 0
+        assert info[3] < 0 and (info[0], info[1]) == (2, 2) and info[2] >= 128, list(info)
+        got = ops.conv2d(pc, x0, x1, **kw)
+    finally:
+        ops.set_conv_winograd(prev)
+    e_dir = float((direct.cpu() - want).abs().max())
+    e_win = float((got.cpu() - want).abs().max())
+    print(f'winograd F(2,5) {case}: max err {e_win:.2e} (direct kernel {e_dir:.2e})')
+    close(got, want, atol=2e-5, what='winograd 1d ' + str(case))
+
+
 def test_conv2d_dma_two_segments_gru_q():
     """the GRU candidate conv on the DMA kernel: two input segments, tanh gate epilogue."""
     n, h, w = 32, 32, 32
@@ -496,6 +547,36 @@ def test_convgru_context_hoisting(n, h, w, kind):
         close(b[:, :hc], href, atol=5e-5, what=f'hoisted vs torch, iteration {it}')
         close(b[:, :hc], a[:, :hc].cpu(), atol=2e-5, what=f'hoisted vs plain cell, iteration {it}')
         close(b[:, hc:], a[:, hc:].cpu(), atol=0, what='x untouched')
+
+
+@pytest.mark.parametrize('n,h,w', [(32, 32, 32), (8, 60, 80)])
+def test_sepconv_gru_winograd(n, h, w):
+    """SepConvGRU with its 1x5 / 5x1 gates on the F(2, 5) kernel (conv_wino1d.hip: both GRU epilogues, two input
+    segments, hoisted context term) vs the direct kernels, two iterations: the state differs by fp32 round-off."""
+    from scflow_amd.modules import ConvGRU
+    torch.manual_seed(12)
+    hc, cc, xc = 128, 128, 128
+    gru = ConvGRU(hc, cc + xc, 'SeqConv').to(DEV)
+    for prm in gru.parameters():
+        prm.data.mul_(1.5)
+    hx = rnd((n, hc + cc + xc, h, w), 95)
+    hx[:, :hc] = torch.tanh(hx[:, :hc])
+    outs = {}
+    for wino in (True, False):
+        prev = ops.set_conv_winograd(wino)
+        try:
+            gru.invalidate_packed() if hasattr(gru, 'invalidate_packed') else None
+            a = hx.to(DEV)
+            ctx = gru.context_terms(a[:, hc:hc + cc])
+            for it in range(2):
+                a[:, hc + cc:] = rnd((n, xc, h, w), 96 + it).to(DEV)
+                gru.forward_inplace(a, ctx, cc)
+            outs[wino] = a[:, :hc].clone()
+        finally:
+            ops.set_conv_winograd(prev)
+    err = float((outs[True] - outs[False]).abs().max())
+    print(f'[measured] SepConvGRU F(2,5) vs direct kernels, {n}x{h}x{w}: max |dh| after 2 iterations {err:.2e}')
+    assert 0.0 < err <= 2e-5, err
 
 
 # ----------------------------------------------------------- small kernels
@@ -714,6 +795,16 @@ def test_sepconv_gru_c_entry(n, h, w, kind):
                 assert lib.scf_pack_conv_weight_a4(wt.data_ptr(), co, ci, kh, kw, grpt, a4t.data_ptr()) == 0
                 bufs.append(a4t.to(DEV))
             g.wp_zr_a4t, g.wp_q_a4t, g.a4t_groups = bufs[10].data_ptr(), bufs[11].data_ptr(), grpt
+        if k in ((1, 5), (5, 1)):                     # F(2, 5) packings of the separable passes (large grids)
+            w1 = []
+            for wt in (wzr, wq.contiguous()):
+                co, ci = wt.shape[:2]
+                u = torch.empty(lib.scf_pack_conv_weight_wino1d_size(co, ci))
+                taps = wt.reshape(co, ci, 5).contiguous()
+                assert lib.scf_pack_conv_weight_wino1d(taps.data_ptr(), co, ci, u.data_ptr()) == 0
+                w1.append(u.to(DEV))
+            g.wp_zr_wino1d, g.wp_q_wino1d = w1[0].data_ptr(), w1[1].data_ptr()
+            bufs += w1
         keep += bufs
         g.KH, g.KW, g.pad_h, g.pad_w = k[0], k[1], pad[0], pad[1]
         g.wp_zr, g.wp_zr_a4, g.wp_q, g.wp_q_a4 = (t.data_ptr() for t in bufs[:4])
