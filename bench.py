@@ -552,14 +552,16 @@ def main():
             c_fl = sum(e[1] for e in conv_launches)
             w_us = sum(e[0] for e in conv_launches if e[2].endswith('[winograd]'))
             w_fl = sum(e[1] for e in conv_launches if e[2].endswith('[winograd]'))
-            x_fl = c_fl - w_fl + w_fl / 2.25            # flops the matrix cores actually execute
+            v_us = sum(e[0] for e in conv_launches if e[2].endswith('[winograd F(2,5)]'))
+            v_fl = sum(e[1] for e in conv_launches if e[2].endswith('[winograd F(2,5)]'))
+            x_fl = c_fl - w_fl - v_fl + w_fl / 2.25 + v_fl * 0.6       # flops the matrix cores actually execute
             by_shape = {}
             for us, fl, tag in conv_launches:
                 a = by_shape.setdefault(tag, [0, 0.0, 0.0])
                 a[0] += 1; a[1] += us; a[2] += fl
             top = sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:args.top_layers]
             result['roofline_conv'] = {
-                'kernel': 'conv_wino_kernel / conv_dma_kernel / conv_mfma_kernel / conv_taps_kernel (all convolution '
+                'kernel': 'conv_wino_kernel / conv_wino1d_kernel / conv_dma_kernel / conv_mfma_kernel / conv_taps_kernel (all convolution '
                           'launches of one step)',
                 'bound': 'mfma', 'achieved': round(c_fl / (c_us * 1e-6) / 1e12, 1),
                 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -573,13 +575,17 @@ def main():
                              'winograd_us_per_step': round(w_us, 1),
                              'winograd_algorithmic_flops_per_step': w_fl,
                              'winograd_tflops_algorithmic': round(w_fl / max(w_us, 1e-9) / 1e6, 1),
-                             'direct_us_per_step': round(c_us - w_us, 1),
-                             'direct_tflops': round((c_fl - w_fl) / max(c_us - w_us, 1e-9) / 1e6, 1),
+                             'winograd_f25_us_per_step': round(v_us, 1),
+                             'winograd_f25_algorithmic_flops_per_step': v_fl,
+                             'winograd_f25_tflops_algorithmic': round(v_fl / max(v_us, 1e-9) / 1e6, 1),
+                             'direct_us_per_step': round(c_us - w_us - v_us, 1),
+                             'direct_tflops': round((c_fl - w_fl - v_fl) / max(c_us - w_us - v_us, 1e-9) / 1e6, 1),
                              'note': 'the 3x3 stride-1 layers on grids of >= 128 blocks run the Winograd F(2x2, 3x3) '
-                                     'kernel (fp32, 16 multiplies per 2x2 outputs instead of 36): `achieved` / `frac` '
+                                     'kernel (fp32, 16 multiplies per 2x2 outputs instead of 36), the 1x5 / 5x1 GRU gates '
+                                     'the one-dimensional F(2, 5) kernel (6 instead of 10 per 2 outputs): `achieved` / `frac` '
                                      'above price every launch at its ALGORITHMIC flops (the contract of this line, '
                                      'so they can exceed what a direct kernel could reach), `executed` counts the '
-                                     'Winograd launches at 1 / 2.25 of that = the MFMA work actually issued'},
+                                     'Winograd launches at 1 / 2.25 (F(2, 5): 0.6) of that = the MFMA work actually issued'},
                 'top_layers': [{'layer': k, 'launches': v[0], 'us': round(v[1], 1),
                                 'tflops': round(v[2] / v[1] / 1e6, 1)} for k, v in top],
                 'note': 'v_mfma_f32_32x32x2_f32 (fp32 throughout), dense peak 256 CU x 256 flop/clk x 2.4 GHz; '

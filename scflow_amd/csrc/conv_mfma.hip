@@ -704,11 +704,11 @@ extern "C" int scf_conv2d_query(const scf_conv_desc* d, int32_t* info) {
     return SCF_OK;
   }
   if (d->wp_wino && scf_conv_wino_dispatch(pl.k, d->wp_wino, d->N, true, info, nullptr) == SCF_OK) {
-    info[3] = -info[3];      // negative: the Winograd kernel will run (info = CW, TW, blocks, -LDS bytes)
+    info[3] = -info[3];      // negative: the Winograd kernel will run (info = 16 positions, fragments per block, blocks, -LDS bytes)
     return SCF_OK;
   }
   if (d->wp_wino1d && scf_conv_wino1d_dispatch(pl.k, d->wp_wino1d, d->N, true, info, nullptr) == SCF_OK) {
-    info[3] = -info[3];      // negative: the F(2, 5) kernel will run (info = 2, 2, blocks, -LDS bytes)
+    info[3] = -info[3];      // negative: the F(2, 5) kernel will run (info = 6 positions, 4 fragments per block, blocks, -LDS bytes)
     return SCF_OK;
   }
   if (want_f16x3(d) && scf_conv_f16x3_dispatch(pl.k, d->N, true, info, nullptr) == SCF_OK) {

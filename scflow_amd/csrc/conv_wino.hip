@@ -413,7 +413,7 @@ static int wino_lds_attr(const void* fn, size_t bytes) {
 }
 
 // Tile selection + launch; SCF_EUNSUPPORTED -> the caller goes on to the direct kernels.
-// info (optional): {CW, TW, blocks, LDS bytes}.
+// info (optional): {16 transform positions, fragments per block, blocks, LDS bytes}.
 int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* info, hipStream_t st) {
   if (!wu || k.KH != 3 || k.KW != 3 || k.stride != 1 || k.pad_h != 1 || k.pad_w != 1) return SCF_EUNSUPPORTED;
   if (k.w_ns != 0 || k.out_tile || k.mode != SCF_CONV_PLAIN || k.out_div != 1.0f || k.act_split > 0) return SCF_EUNSUPPORTED;
@@ -462,7 +462,7 @@ int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* i
   if (nblk < scf_cu_count() / 2) return SCF_EUNSUPPORTED;
   const size_t ldsb = (size_t)(3 * CW * 2048 + 3 * npi * (px4 ? 1024 : 256)) * sizeof(float);
   if (ldsb > 80 * 1024) return SCF_EUNSUPPORTED;
-  if (info) { info[0] = CW; info[1] = TW; info[2] = (int)nblk; info[3] = (int)ldsb; }
+  if (info) { info[0] = 16; info[1] = CW * TW; info[2] = (int)nblk; info[3] = (int)ldsb; }     // positions, fragments per block
   if (dry_run) return SCF_OK;
   static bool raised[64][2] = {};
   int dev = 0;

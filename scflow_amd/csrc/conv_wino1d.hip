@@ -12,7 +12,9 @@
 //   * after the output transform a lane holds 16 channel rows of two pixels -- exactly two accumulator
 //     fragments of the direct kernels, so the shared fused epilogue (conv_kernels.h) finishes them: bias, BN,
 //     residual, activations, both GRU gates with the hoisted context term.
-// Error vs fp64 about 2x the direct kernel's (3e-6 -> 6e-6 on unit-scale outputs; tests/test_gpu_ops.py).
+// Error vs fp64 about 5e-6 on unit-scale outputs (the direct kernel: 1e-6; B^T scales the inputs by up to 5 and
+// G by down to 1/24 before they cancel again); the GRU state after two iterations differs from the direct
+// kernels' by 4.5e-6 (tests/test_gpu_ops.py).
 #include <stdlib.h>
 #include <string.h>
 #include "scf_common.h"
@@ -26,7 +28,8 @@ typedef float w1_f32x2 __attribute__((ext_vector_type(2)));
 #define W1_KC 8             // channels per chunk
 #define W1_UF 1536          // floats of one fragment's U chunk: [6 positions][2 k-halves][32 channels][4 k-steps]
 // patch copy instructions per wave per chunk (256 cells per block-instruction; lanes past the patch write zeros
-// into the slot's padding): horizontal with 16-byte cells 2, with dword cells 6; vertical (16-byte cells only) 3
+// into the slot's padding): horizontal with 16-byte cells 2 (a conflict-free row pitch of 96 floats was measured:
+// no difference), with dword cells 6; vertical (16-byte cells only) 3
 #define W1_NPI(VERT, PX4) ((VERT) ? 3 : ((PX4) ? 2 : 6))
 
 struct Wino1K {
@@ -181,6 +184,29 @@ void conv_wino1d_kernel(ConvK p, Wino1K q) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
+  // GRU launches: the pre-activation term (`res`: the hoisted context part, one value per output) is requested
+  // NOW, in front of the first copies (vector loads return in order, so the counted waits below still cover
+  // exactly the copies), and added after the output transform -- read in the epilogue it is one more memory
+  // round trip at the end of every block, when all blocks of a round are there at the same time.
+  const ConvEpi e = scf_conv_epi(p, n);
+  int pix[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int oy = VERT ? y0 + 2 * ty + j : y0 + ty, ox = VERT ? x0 + tx : x0 + 2 * tx + j;
+    pix[j] = (oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
+  }
+  const bool pre_res = e.res && (p.mode == SCF_CONV_GRU_ZR || p.mode == SCF_CONV_GRU_Q) && p.out_div == 1.0f;
+  float resv[2][16];
+  if (pre_res) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = (f0 + cw) * 32 + 8 * (r >> 2) + (r & 3) + 4 * half;
+        resv[j][r] = (pix[j] >= 0 && co < p.Cout) ? e.res[co * e.HWo + pix[j]] : 0.f;
+      }
+  }
+
   // ---- prologue: three chunks requested, two awaited ----------------------------------------------------
   issue_p(0); issue_u(0);
   issue_u(1); issue_p(1);
@@ -242,14 +268,15 @@ void conv_wino1d_kernel(ConvK p, Wino1K q) {
     o[0][0][r] = ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) + acc[4][r];
     o[0][1][r] = __builtin_fmaf(2.f, acc[3][r] - acc[4][r], acc[1][r] - acc[2][r]) + acc[5][r];
   }
-  const ConvEpi e = scf_conv_epi(p, n);
-  int pix[2];
+  ConvEpi e2 = e;
+  if (pre_res) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int oy = VERT ? y0 + 2 * ty + j : y0 + ty, ox = VERT ? x0 + tx : x0 + 2 * tx + j;
-    pix[j] = (oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[0][j][r] += resv[j][r];
+    e2.res = nullptr;                  // consumed
   }
-  scf_conv_epilogue_tile<1, 2>(p, e, o, (f0 + cw) * 32, half, pix, p.out_div != 1.0f);
+  scf_conv_epilogue_tile<1, 2>(p, e2, o, (f0 + cw) * 32, half, pix, p.out_div != 1.0f);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -291,7 +318,7 @@ extern "C" int scf_pack_conv_weight_wino1d(const float* w, int32_t cout, int32_t
   return SCF_OK;
 }
 
-// Tile selection + launch; SCF_EUNSUPPORTED -> the caller goes on to the direct kernels.  info: {2, 2, blocks, LDS bytes}.
+// Tile selection + launch; SCF_EUNSUPPORTED -> the caller goes on to the direct kernels.  info: {6 transform positions, 4 fragments per block, blocks, LDS bytes}.
 int scf_conv_wino1d_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* info, hipStream_t st) {
   const bool vert = k.KH == 5 && k.KW == 1 && k.pad_h == 2 && k.pad_w == 0;
   const bool horz = k.KH == 1 && k.KW == 5 && k.pad_h == 0 && k.pad_w == 2;
@@ -338,7 +365,7 @@ int scf_conv_wino1d_dispatch(ConvK k, const float* wu, int N, bool dry_run, int*
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
   if (nblk < scf_cu_count() / 2) return SCF_EUNSUPPORTED;             // small grids: the direct kernels' K-split tile
   const size_t ldsb = (size_t)(3 * 2 * W1_UF + 3 * npi * (px4 ? 1024 : 256)) * sizeof(float);
-  if (info) { info[0] = 2; info[1] = 2; info[2] = (int)nblk; info[3] = (int)ldsb; }
+  if (info) { info[0] = 6; info[1] = 4; info[2] = (int)nblk; info[3] = (int)ldsb; }      // positions, fragments per block
   if (dry_run) return SCF_OK;
   static bool raised[64][3] = {};
   int dev = 0;

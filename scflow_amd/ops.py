@@ -535,13 +535,13 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
             _lib.check(lib.scf_conv2d(C.byref(d), _stream()), 'scf_conv2d')
         finally:
             lib.scf_timer_arm(None)
-        wino = False
-        if d.wp_wino:                   # does the Winograd kernel take this launch (grid-size policy)?
+        tag = ''
+        if d.wp_wino or d.wp_wino1d:    # does a Winograd kernel take this launch (grid-size policy)?
             info = (C.c_int32 * 4)()
-            wino = lib.scf_conv2d_query(C.byref(d), info) == 0 and info[3] < 0 and info[0] * info[1] == 2
+            if lib.scf_conv2d_query(C.byref(d), info) == 0 and info[3] < 0 and info[0] in (16, 6):
+                tag = ' [winograd]' if info[0] == 16 else ' [winograd F(2,5)]'
         _CONV_EVENTS.append((tm, 2.0 * pc.cin * pc.kh * pc.kw * pc.cout * ho * wo * n,
-                             f'{pc.cin}->{pc.cout} {pc.kh}x{pc.kw}/s{pc.stride} @{ho}x{wo} N{n}'
-                             + (' [winograd]' if wino else '')))
+                             f'{pc.cin}->{pc.cout} {pc.kh}x{pc.kw}/s{pc.stride} @{ho}x{wo} N{n}' + tag))
         return out
     _lib.check(_lib.load().scf_conv2d(C.byref(d), _stream()), 'scf_conv2d')
     return out
@@ -648,7 +648,8 @@ def _read_timers(timers):
 def conv_timing(enable: bool):
     """like ``lookup_timing`` for the convolution launches: enable=False returns a list of
     (microseconds, algorithmic flops = 2*Cin*KH*KW*Cout*Ho*Wo*N, shape tag) per launch; the tag ends in
-    ' [winograd]' when the F(2x2, 3x3) kernel ran the launch (it executes 1 / 2.25 of those flops)."""
+    ' [winograd]' when the F(2x2, 3x3) kernel ran the launch (it executes 1 / 2.25 of those flops), in
+    ' [winograd F(2,5)]' for the 1x5 / 5x1 kernel (1 / 1.667)."""
     global _CONV_EVENTS
     if enable:
         _CONV_EVENTS = []
