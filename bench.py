@@ -444,7 +444,7 @@ def main():
                           'unit': 'pairs/s', 'ms_per_step': round(dt_d / args.steps * 1e3, 3), 'blocks': len(blocks_d),
                           'note': 'the same step with the direct kernels on every layer (ops.set_conv_winograd(False)): '
                                   'fp32 fma chains in the summation order of the reference; flow EPE vs the CPU oracle '
-                                  '6.3e-5 px, with the Winograd layers 6.2e-5 px (tools/lab/wino_e2e.py)'}
+                                  '6.3e-5 px, with the Winograd layers (3x3: F(2x2,3x3); GRU gates: F(2,5)) 5.2e-5 px (tools/lab/wino_e2e.py)'}
         if not args.no_alt:
             other = 'f16x3' if args.precision == 'f32' else 'f32'
             blocks_alt, lk_alt, _ = timed(other)
