@@ -1,0 +1,90 @@
+"""CPU: the Winograd weight packers of the C ABI (scf_pack_conv_weight_wino / _wino1d) against the algebra
+the kernels implement -- the packed U, read back through the layout documented in include/scflow_hip.h,
+combined with the kernels' input / output transforms in numpy, reproduces the convolution."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from scflow_amd import _lib, ops
+
+
+@pytest.fixture(scope='module')
+def lib():
+    return _lib.load()
+
+
+def _unpack(packed, npos, cout, cin, kc):
+    """[chunk][frag][pos][k-half][32][kc / 2] -> U[pos][cout][cin] (storage position, not transform index)"""
+    f, nchunk, ks = (cout + 31) // 32, (cin + kc - 1) // kc, kc // 2
+    a = packed.reshape(nchunk, f, npos, 2, 32, ks)
+    u = np.zeros((npos, f * 32, nchunk * kc))
+    for ch in range(nchunk):
+        for s in range(ks):
+            for kh in range(2):
+                u[:, :, ch * kc + 2 * s + kh] = a[ch, :, :, kh, :, s].transpose(1, 0, 2).reshape(npos, f * 32)
+    return u[:, :cout, :cin], u
+
+
+def test_wino2d_packing_reproduces_the_convolution(lib):
+    rng = np.random.default_rng(3)
+    cout, cin = 40, 10
+    w = torch.from_numpy(rng.standard_normal((cout, cin, 3, 3)).astype(np.float32))
+    n = lib.scf_pack_conv_weight_wino_size(cout, cin)
+    assert n == ((cin + 3) // 4) * 2 * 16 * 128
+    host = torch.empty(n)
+    assert lib.scf_pack_conv_weight_wino(w.data_ptr(), cout, cin, host.data_ptr()) == 0
+    assert torch.equal(host, ops.pack_conv_weight_wino(w))           # the torch packer: bit-identical
+    u, full = _unpack(host.numpy().astype(np.float64), 16, cout, cin, 4)
+    assert np.all(full[:, cout:, :] == 0) and np.all(full[:, :, cin:] == 0)      # zero padding
+    # storage rows of the transform domain: 0, 1, 3, 2
+    order = [0, 1, 3, 2]
+    U = np.zeros((4, 4, cout, cin))
+    for ip, i in enumerate(order):
+        for j in range(4):
+            U[i, j] = u[4 * ip + j]
+    BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=np.float64)
+    AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=np.float64)
+    d = rng.standard_normal((cin, 4, 4))
+    V = np.einsum('ia,cab,jb->ijc', BT, d, BT)
+    M = np.einsum('ijoc,ijc->ijo', U, V)
+    Y = np.einsum('ai,ijo,bj->oab', AT, M, AT)
+    want = np.zeros((cout, 2, 2))
+    wd = w.numpy().astype(np.float64)
+    for a in range(2):
+        for b in range(2):
+            want[:, a, b] = np.einsum('ocij,cij->o', wd, d[:, a:a + 3, b:b + 3])
+    assert np.abs(Y - want).max() < 1e-5         # U is rounded to fp32 once; everything else is exact here
+
+
+def test_wino1d_packing_reproduces_the_convolution(lib):
+    rng = np.random.default_rng(4)
+    cout, cin = 64, 20
+    w = torch.from_numpy(rng.standard_normal((cout, cin, 1, 5)).astype(np.float32))
+    n = lib.scf_pack_conv_weight_wino1d_size(cout, cin)
+    assert n == ((cin + 7) // 8) * 2 * 1536
+    host = torch.empty(n)
+    taps = w.reshape(cout, cin, 5).contiguous()
+    assert lib.scf_pack_conv_weight_wino1d(taps.data_ptr(), cout, cin, host.data_ptr()) == 0
+    assert torch.equal(host, ops.pack_conv_weight_wino1d(w))
+    assert torch.equal(host, ops.pack_conv_weight_wino1d(w.reshape(cout, cin, 5, 1)))     # 5x1: the same taps
+    u, full = _unpack(host.numpy().astype(np.float64), 6, cout, cin, 8)
+    assert np.all(full[:, :, cin:] == 0)
+    # the kernel's transforms (conv_wino1d.hip): points 0, 1, -1, 2, -2, infinity
+    BT = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0],
+                   [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=np.float64)
+    AT = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 1]], dtype=np.float64)
+    d = rng.standard_normal((cin, 6))
+    M = np.einsum('ioc,ic->io', u, np.einsum('ij,cj->ic', BT, d))
+    y = AT @ M                                     # (2, cout)
+    wd = taps.numpy().astype(np.float64)
+    want = np.stack([np.einsum('ock,ck->o', wd, d[:, o:o + 5]) for o in range(2)])
+    assert np.abs(y - want).max() < 1e-5
+
+
+def test_wino_packers_reject_bad_arguments(lib):
+    buf = torch.empty(16)
+    assert lib.scf_pack_conv_weight_wino(None, 4, 4, buf.data_ptr()) != 0
+    assert lib.scf_pack_conv_weight_wino1d(buf.data_ptr(), 0, 4, buf.data_ptr()) != 0
+    assert lib.scf_pack_conv_weight_wino_size(0, 4) == 0 and lib.scf_pack_conv_weight_wino1d_size(4, 0) == 0
