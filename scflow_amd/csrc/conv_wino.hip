@@ -14,19 +14,21 @@
 //               The output transform A^T M A is linear in the rows: each wave transforms its two rows, the
 //               pair exchanges half of the 4-value partial results through LDS and each finishes 8 of the
 //               fragment's 16 channel rows.
-//   block       4 waves = 2 fragments (CW x TW = 2: two channel fragments of one tile group, or one
-//               channel fragment of two vertically stacked tile groups).
+//   block       4 waves = 2 fragments: one channel fragment of two vertically stacked tile groups (an 8 x 32
+//               output region on a wide map); the two wave pairs share the U chunk.
 //   U           = G g G^T, transformed and packed on the host (scf_pack_conv_weight_wino) in the exact
-//               LDS image [chunk][fragment][xi][k-half][cout][2]: one ds_read_b64 per xi feeds both
-//               k-steps of a 4-channel chunk; staged by LDS-DMA into a 3-deep ring.
-//   V           = B^T d B, computed IN the kernel: the raw input patch of the next chunk is staged by
-//               LDS-DMA (descriptor range check = zero padding), each thread transforms one
-//               (tile, channel) 4 x 4 window (32 adds) in pieces placed between groups of MFMAs and
-//               writes its 16 values to the V double buffer.
-//   pipeline    per chunk: issue DMA of chunk c+2 (U) / c+3 (patch); transform patch c+1 -> V; MFMAs of
-//               chunk c; one barrier.
+//               LDS image [chunk][fragment][xi][k-half][cout][2] (rows of the transform domain in the order
+//               0, 1, 3, 2, see below): one ds_read_b64 per xi feeds both k-steps of a 4-channel chunk;
+//               staged by LDS-DMA into a 3-deep ring.
+//   V           = B^T d B, computed IN REGISTERS: the raw input patch of a later chunk is staged by LDS-DMA
+//               (descriptor range check = zero padding); lane (tile, k-half) reads the three input rows its
+//               wave's two transform rows need and computes its own B operands (16 packed adds per chunk),
+//               between the MFMAs of the current chunk.  No V buffer, one barrier per chunk.
+//   pipeline    chunk c: MFMAs on operands already in registers; the operands of chunk c+1 are read (U) /
+//               computed (patch) under them; the copies of chunk c+3 are issued, those of c+2 awaited.
 //   epilogue    output transform, pair exchange, then the affine epilogue (bias, BN scale/shift, residual,
 //               ReLU) and float2 stores: 16 lanes cover one full 128-byte line of an output row.
+//   grid        small grids (< CUs / 2 blocks) stay on the direct kernels (dispatch below).
 //
 // Arithmetic: fp32 adds / fmas only; the transforms re-associate the sum, so results differ from the
 // direct kernel by a few ulp of the accumulated magnitude (measured in tests/test_gpu_ops.py).
