@@ -4,8 +4,8 @@
 set -e
 cd "$(dirname "$0")/../../scflow_amd/csrc"
 O=/tmp/scf_exp_obj_cbase; mkdir -p $O
-for f in capi corr_lookup corr_gemm conv_mfma conv_f16x3 conv_wino conv_thin conv_taps resample pose norm scflow_iter; do
-  X=""; [ $f = conv_wino ] && X="-fno-slp-vectorize"
+for f in capi corr_lookup corr_gemm conv_mfma conv_f16x3 conv_wino conv_wino1d conv_thin conv_taps resample pose norm scflow_iter; do
+  X=""; [ $f = conv_wino -o $f = conv_wino1d ] && X="-fno-slp-vectorize"
   [ $O/$f.o -nt $f.hip ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $X -c $f.hip -o $O/$f.o &
 done
 wait
