@@ -276,7 +276,8 @@ void conv_wino_kernel(ConvK p, WinoK q) {
     if (!WN_LAB(1)) win_load(pcb, 1);
     __builtin_amdgcn_sched_barrier(0);
     WN_M(2, 0)
-    const int s3 = s1 == 0 ? 2 : s1 - 1;            // (c + 3) % 3
+    int s3 = s1 + 2;                                 // (c + 3) % 3
+    s3 = s3 >= 3 ? s3 - 3 : s3;
     if (!WN_LAB(2)) issue_u(s3);
     __builtin_amdgcn_sched_barrier(0);
     WN_M(3, 0)

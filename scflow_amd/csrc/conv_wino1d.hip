@@ -228,7 +228,8 @@ void conv_wino1d_kernel(ConvK p, Wino1K q) {
   auto chunk = [&](const w1_f32x4 (&a)[6], const w1_f32x4 (&b)[6], w1_f32x4 (&an)[6], w1_f32x4 (&bn)[6]) {
     const float* uc = ua + s1 * USLOT;
     const unsigned pcb = (unsigned)(s1 * PSLOT * 4);
-    const int s3 = s1 == 0 ? 2 : s1 - 1;
+    int s3 = s1 + 2;                   // ring slot of the chunk three ahead
+    s3 = s3 >= 3 ? s3 - 3 : s3;
 #define W1_M(X, S)                                                                              \
     acc[X] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[X][S], b[X][S], acc[X], 0, 0, 0);           \
     __builtin_amdgcn_sched_barrier(0);
