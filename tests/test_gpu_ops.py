@@ -413,6 +413,51 @@ def test_conv2d_winograd_1d(case):
     close(got, want, atol=2e-5, what='winograd 1d ' + str(case))
 
 
+@pytest.mark.parametrize('seed', range(12))
+def test_winograd_kernels_random_shapes(seed):
+    """Seeded random layer shapes (channels, map sizes, two segments, residual / BN / ReLU on and off) through
+    both Winograd kernels vs the direct kernels: edge tiles, short last chunks, odd sizes, unaligned rows."""
+    import ctypes as C
+    import random
+    rng = random.Random(1000 + seed)
+    lib = ops._lib.load()
+    for kind in ('2d', '1dh', '1dv'):
+        cin = rng.choice([16, 20, 36, 64, 72, 130])
+        cout = rng.choice([64, 128, 192]) if kind != '2d' else rng.choice([32, 40, 64, 96, 126, 160])
+        H, W = rng.choice([(16, 16), (20, 28), (23, 30), (32, 32), (33, 40), (48, 36), (12, 64)])
+        k, pad = {'2d': ((3, 3), 1), '1dh': ((1, 5), (0, 2)), '1dv': ((5, 1), (2, 0))}[kind]
+        n = 2
+        x = rnd((n, cin, H, W), 60 + seed)
+        wt = rnd((cout, cin, *k), 61 + seed, (1.0 / (cin * k[0] * k[1])) ** 0.5)
+        b = rnd((cout,), 62 + seed, 0.1)
+        pc = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), padding=pad)
+        # enough samples for the dispatch's grid threshold
+        ops.set_conv_winograd(True)
+        info = (C.c_int32 * 4)()
+        while True:
+            xd = rnd((n, cin, H, W), 63 + seed).to(DEV)
+            d, _ = ops.conv_desc(pc, xd)
+            assert lib.scf_conv2d_query(C.byref(d), info) == 0
+            if info[0] in (16, 6) or n >= 256:
+                break
+            n *= 2
+        if info[0] not in (16, 6):
+            continue                     # e.g. a vertical pass on rows that are not 16-byte aligned: direct kernels
+        c0 = rng.choice([0, 0, 8, 16]) if cin > 16 and (kind == '2d' or cin % 8 == 0) else 0
+        res = rnd((n, cout, H, W), 64 + seed).to(DEV) if rng.random() < 0.5 else None
+        act = ops.ACT_RELU if rng.random() < 0.5 else ops.ACT_NONE
+        x0, x1 = (xd[:, :c0], xd[:, c0:]) if c0 else (xd, None)
+        got = ops.conv2d(pc, x0, x1, res=res, act=act)
+        prev = ops.set_conv_winograd(False)
+        try:
+            want = ops.conv2d(pc, x0, x1, res=res, act=act)
+        finally:
+            ops.set_conv_winograd(True)
+        err = float((got - want).abs().max())
+        assert err <= 3e-5, (kind, n, cin, cout, H, W, c0, err)
+        assert err > 0.0, 'the two paths gave identical bits: the Winograd kernel did not run'
+
+
 def test_conv2d_dma_two_segments_gru_q():
     """the GRU candidate conv on the DMA kernel: two input segments, tanh gate epilogue."""
     n, h, w = 32, 32, 32
