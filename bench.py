@@ -134,6 +134,20 @@ def run_step(model, d):
                           d['ref_translation'], d['depth'], d['internel_k'], d['label'])
 
 
+def pin_rank_to_cores(slot: int, world: int):
+    """N > 1: bind this rank's host threads to its own slice of the CPUs the process may use, so that N
+    Python launch loops do not migrate over one another inside a small cgroup quota (the GPU box: 16 CPUs
+    for 8 ranks).  Returns the CPU list, or None where affinity cannot be set."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = max(1, min(len(cpus), host_cores()) // max(world, 1))
+        mine = cpus[(slot * per) % len(cpus):(slot * per) % len(cpus) + per] or cpus[:1]
+        os.sched_setaffinity(0, mine)
+        return mine
+    except (AttributeError, OSError):
+        return None
+
+
 def host_cores() -> int:
     """CPUs this process may actually use: min(cpu_count, affinity mask, cgroup cpu.max quota).
     (The GPU box exposes 256 logical CPUs but a 16-CPU cgroup quota; 256 torch threads on a
@@ -152,9 +166,10 @@ def host_cores() -> int:
     return n
 
 
-def cpu_baseline(sd, iters: int, pairs: int = 8, reps: int = 10, budget_s: float = 20.0):
-    """the oracle on the host cores: bounded sample (<= ``reps`` passes over ``pairs`` pairs
-    after one warm-up pair, stopped once ``budget_s`` seconds of CPU work are spent)."""
+def cpu_baseline(sd, iters: int, pairs: int = 32, reps: int = 10, budget_s: float = 20.0):
+    """the oracle on the host cores: bounded sample (<= ``reps`` passes over a batch of ``pairs`` pairs --
+    the batch size of the GPU line -- after one warm-up pair, stopped once ``budget_s`` seconds of CPU
+    work are spent; at least one pass)."""
     import torch
     import oracle
     import scflow_amd
@@ -167,15 +182,41 @@ def cpu_baseline(sd, iters: int, pairs: int = 8, reps: int = 10, budget_s: float
         oracle.get_pose(*[a[:1] if torch.is_tensor(a) else a for a in args], iters=iters)  # warm-up
         t0 = time.perf_counter()
         done = 0
-        while done < reps and time.perf_counter() - t0 < budget_s:
+        while done < reps and (done == 0 or time.perf_counter() - t0 < budget_s):
             oracle.get_pose(*args, iters=iters)
             done += 1
         dt = time.perf_counter() - t0
     return dict(value=round(pairs * done / dt, 3), unit='pairs/s', cores=cores, kind='port',
+                batch=pairs,
                 sample=f'{done} x oracle.get_pose on a batch of {pairs} synthetic 256x256 pairs '
-                       f'(the GPU line uses batches of 32: same per-pair work), '
+                       f'(the same call as one GPU step: same batch size, same inputs generator), '
                        f'{iters} iters, torch CPU fp32, {cores} threads (cgroup quota), after 1 '
                        f'warm-up pair ({dt:.1f} s timed)')
+
+
+def _latest_mfma_pmc():
+    """per-kernel SQ_VALU_MFMA_BUSY_CYCLES fractions from the newest committed counter pass
+    (profiles/r*_mfma_pmc.json, written by tools/summarize_mfma.py from a rocprofv3 --pmc run of this
+    command): copied into the line like roofline.traffic is, never measured live."""
+    import glob
+    import re
+    files = glob.glob(os.path.join(ROOT, 'profiles', 'r*_mfma_pmc.json'))
+    if not files:
+        return None
+    key = lambda f: [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', os.path.basename(f))]
+    path = sorted(files, key=key)[-1]
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    return {'source': f'profiles/{os.path.basename(path)}: ' + str(d.get('source', '')),
+            'all_matrix_kernels': d.get('all_matrix_kernels', {}).get('mfma_busy_vs_chip_peak'),
+            'kernels': [{'kernel': k['kernel'], 'launches': k['launches'], 'mean_duration_us': k['mean_duration_us'],
+                         'mfma_busy_vs_chip_peak': k['mfma_busy_vs_chip_peak'],
+                         'wait_inst_any_frac': (round(k['counters_per_launch']['SQ_WAIT_INST_ANY']
+                                                      / k['counters_per_launch']['SQ_WAVE_CYCLES'], 3)
+                                                if k.get('counters_per_launch', {}).get('SQ_WAVE_CYCLES') else None)}
+                        for k in d.get('kernels', [])[:10]]}
 
 
 def _median(xs):
@@ -223,7 +264,7 @@ class BlockTimer:
             blocks.append(el)
             total += el
             # every rank sees the same (all-reduced) totals, so they leave the loop together
-            if total >= self.min_seconds or len(blocks) >= 200:
+            if total >= self.min_seconds or len(blocks) >= 100000:
                 break
         return blocks, done
 
@@ -299,6 +340,7 @@ def main():
     if args.share_device:
         os.environ['LOCAL_RANK'] = '0'                          # every rank drives cuda:0
     rank, world, local = init_from_env()
+    pinned = pin_rank_to_cores(local if not args.share_device else rank, world) if world > 1 else None
     if world != args.gpus:
         if rank == 0:
             print(f'[bench] WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a line '
@@ -443,8 +485,8 @@ def main():
             alt_direct = {'conv_algo': 'direct', 'value': round(args.batch * world * args.steps / dt_d, 2),
                           'unit': 'pairs/s', 'ms_per_step': round(dt_d / args.steps * 1e3, 3), 'blocks': len(blocks_d),
                           'note': 'the same step with the direct kernels on every layer (ops.set_conv_winograd(False)): '
-                                  'fp32 fma chains in the summation order of the reference; flow EPE vs the CPU oracle '
-                                  '6.3e-5 px, with the Winograd layers (3x3: F(2x2,3x3); GRU gates: F(2,5)) 5.2e-5 px (tools/lab/wino_e2e.py)'}
+                                  'fp32 fma chains in the summation order of the reference; parity of both paths: '
+                                  'tests/test_gpu_refiner.py (not measured by this run)'}
         if not args.no_alt:
             other = 'f16x3' if args.precision == 'f32' else 'f32'
             blocks_alt, lk_alt, _ = timed(other)
@@ -454,9 +496,8 @@ def main():
                    'ms_per_step': round(dt_alt / args.steps * 1e3, 3), 'blocks': len(blocks_alt),
                    'lookup_avg_launch_us': round(sum(lk_alt) / max(len(lk_alt), 1), 2),
                    'note': 'f16x3 = spatial convs with >=16 input channels as 3 fp16 MFMAs over an exact '
-                           'hi/lo split of both operands, fp32 accumulate (~22 mantissa bits); flow EPE vs '
-                           'the fp32 CPU oracle 7.6e-5 px over 8 iterations (tests/test_gpu_refiner.py), '
-                           'north-star tolerance 1e-3 px.  f32 = v_mfma_f32_32x32x2_f32 everywhere.'}
+                           'hi/lo split of both operands, fp32 accumulate (~22 mantissa bits); parity: '
+                           'tests/test_gpu_refiner.py (not measured by this run).  f32 = v_mfma_f32_32x32x2_f32 everywhere.'}
             ops.set_conv_precision(args.precision)
 
     if rank == 0:
@@ -488,6 +529,10 @@ def main():
         if standin:
             result['standin'] = True
             result['metric'] = 'LAUNCHER SELF-TEST (CPU stand-in step, not a measurement)'
+        if world > 1:
+            result['host_affinity'] = {'cpus_of_rank0': pinned}
+        result['scaling_note'] = ('one line = one N: no scaling curve or efficiency is reported here -- the driver '
+                                  'computes it from the per-N lines of its SCALE run (configs[3] = 8 GPUs x 32 pairs)')
         if args.share_device:
             result['share_device'] = True
             result['scaling'] = 'none (ranks share one GPU)'
@@ -560,36 +605,50 @@ def main():
                 a = by_shape.setdefault(tag, [0, 0.0, 0.0])
                 a[0] += 1; a[1] += us; a[2] += fl
             top = sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:args.top_layers]
+            x_tf = x_fl / (c_us * 1e-6) / 1e12
+            w_x, v_x = w_fl / 2.25, v_fl * 0.6
+            d_us, d_fl = c_us - w_us - v_us, c_fl - w_fl - v_fl
             result['roofline_conv'] = {
                 'kernel': 'conv_wino_kernel / conv_wino1d_kernel / conv_dma_kernel / conv_mfma_kernel / conv_taps_kernel (all convolution '
                           'launches of one step)',
-                'bound': 'mfma', 'achieved': round(c_fl / (c_us * 1e-6) / 1e12, 1),
+                # the roofline fraction of THIS line: MFMA flops the kernels actually issue / time / dense fp32 peak
+                'bound': 'mfma', 'achieved': round(x_tf, 1),
                 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(c_fl / (c_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                'frac': round(x_tf / MFMA_F32_PEAK_TFLOPS, 4),
+                'flops_per_step': x_fl,
                 'launches_timed': len(conv_launches), 'conv_us_per_step': round(c_us, 1),
                 'share_of_step': round(c_us * 1e-6 / (dt / args.steps), 3),
-                'algorithmic_flops_per_step': c_fl,
-                'executed': {'tflops': round(x_fl / (c_us * 1e-6) / 1e12, 1),
-                             'frac': round(x_fl / (c_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                             'flops_per_step': x_fl,
-                             'winograd_us_per_step': round(w_us, 1),
-                             'winograd_algorithmic_flops_per_step': w_fl,
-                             'winograd_tflops_algorithmic': round(w_fl / max(w_us, 1e-9) / 1e6, 1),
-                             'winograd_f25_us_per_step': round(v_us, 1),
-                             'winograd_f25_algorithmic_flops_per_step': v_fl,
-                             'winograd_f25_tflops_algorithmic': round(v_fl / max(v_us, 1e-9) / 1e6, 1),
-                             'direct_us_per_step': round(c_us - w_us - v_us, 1),
-                             'direct_tflops': round((c_fl - w_fl - v_fl) / max(c_us - w_us - v_us, 1e-9) / 1e6, 1),
-                             'note': 'the 3x3 stride-1 layers on grids of >= 128 blocks run the Winograd F(2x2, 3x3) '
-                                     'kernel (fp32, 16 multiplies per 2x2 outputs instead of 36), the 1x5 / 5x1 GRU gates '
-                                     'the one-dimensional F(2, 5) kernel (6 instead of 10 per 2 outputs): `achieved` / `frac` '
-                                     'above price every launch at its ALGORITHMIC flops (the contract of this line, '
-                                     'so they can exceed what a direct kernel could reach), `executed` counts the '
-                                     'Winograd launches at 1 / 2.25 (F(2, 5): 0.6) of that = the MFMA work actually issued'},
+                'by_kernel': {
+                    'winograd_f2x2_3x3': {'us_per_step': round(w_us, 1),
+                                          'tflops': round(w_x / max(w_us, 1e-9) / 1e6, 1),
+                                          'frac': round(w_x / max(w_us, 1e-9) / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)},
+                    'winograd_f2_5': {'us_per_step': round(v_us, 1),
+                                      'tflops': round(v_x / max(v_us, 1e-9) / 1e6, 1),
+                                      'frac': round(v_x / max(v_us, 1e-9) / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)},
+                    'direct': {'us_per_step': round(d_us, 1),
+                               'tflops': round(d_fl / max(d_us, 1e-9) / 1e6, 1),
+                               'frac': round(d_fl / max(d_us, 1e-9) / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)}},
+                # side figure, NOT a roofline fraction: the same time priced at the flops a direct convolution
+                # of these layers would execute (Winograd issues 1 / 2.25 resp. 0.6 of them)
+                'algorithmic': {'flops_per_step': c_fl, 'tflops': round(c_fl / (c_us * 1e-6) / 1e12, 1),
+                                'winograd_f2x2_3x3_tflops': round(w_fl / max(w_us, 1e-9) / 1e6, 1),
+                                'winograd_f2_5_tflops': round(v_fl / max(v_us, 1e-9) / 1e6, 1),
+                                'note': 'direct-convolution flops 2*Cin*KH*KW*Cout*Ho*Wo*N of every launch / time: what '
+                                        'the layers cost in the formulation of the reference; can exceed the MFMA peak '
+                                        'because the Winograd kernels do not execute these flops'},
                 'top_layers': [{'layer': k, 'launches': v[0], 'us': round(v[1], 1),
-                                'tflops': round(v[2] / v[1] / 1e6, 1)} for k, v in top],
-                'note': 'v_mfma_f32_32x32x2_f32 (fp32 throughout), dense peak 256 CU x 256 flop/clk x 2.4 GHz; '
-                        'flops = 2*Cin*KH*KW*Cout*Ho*Wo*N per launch; HIP start/stop events bound to each launch'}
+                                'tflops_algorithmic': round(v[2] / v[1] / 1e6, 1),
+                                'tflops': round(v[2] / v[1] / 1e6 / (2.25 if k.endswith('[winograd]') else
+                                                                     (1 / 0.6) if k.endswith('[winograd F(2,5)]') else 1.0), 1)}
+                               for k, v in top],
+                'note': 'v_mfma_f32_32x32x2_f32 (fp32 throughout), dense peak 256 CU x 256 flop/clk x 2.4 GHz; achieved = '
+                        'EXECUTED MFMA flops of all convolution launches of one step (direct launches 2*Cin*KH*KW*Cout*Ho*Wo*N; '
+                        'F(2x2,3x3) launches 1 / 2.25 of that: 16 multiplies per 2x2 outputs instead of 36; F(2,5) launches '
+                        '0.6: 6 per 2 outputs instead of 10) / sum of the launch durations (HIP start/stop events bound to '
+                        'each launch)'}
+            mp = _latest_mfma_pmc()
+            if mp and args.batch == 32:       # SQ counter pass of this command (own rocprofv3 run), committed under profiles/
+                result['roofline_conv']['mfma_busy'] = mp
             # GRU context hoisting: the context channels' part of the SepConvGRU
             # convolutions runs once per pair instead of once per iteration.  `achieved` counts the
             # flops actually executed; the same step in the reference's formulation would execute
@@ -601,7 +660,7 @@ def main():
                 saved = 2.0 * cc_ * taps * 3 * hc_ * (32 * 32) * args.batch * (args.iters - 1)
                 result['roofline_conv']['gru_context_hoisting'] = {
                     'flops_saved_per_step': saved,
-                    'tflops_in_reference_formulation': round((c_fl + saved) / (c_us * 1e-6) / 1e12, 1),
+                    'tflops_algorithmic_in_reference_formulation': round((c_fl + saved) / (c_us * 1e-6) / 1e12, 1),
                     'note': 'conv([h|c|x]) = conv([h|x]) + conv_c(c), c = context features (constant over '
                             'the iterations): conv_c(c) once per pair; tflops_in_reference_formulation = '
                             '(executed + saved flops) / conv time, for comparison with a per-iteration GRU'}
@@ -651,7 +710,7 @@ def main():
             result['alt_direct'] = alt_direct
     if rank == 0 and world == 1 and not standin and not args.no_cpu_baseline:
         try:
-            result['cpu_baseline'] = cpu_baseline(sd, args.iters)
+            result['cpu_baseline'] = cpu_baseline(sd, args.iters, pairs=args.batch)
         except Exception as exc:      # pragma: no cover
             print(f'[bench] cpu baseline failed: {exc!r}', file=sys.stderr)
     if rank == 0:

@@ -55,7 +55,7 @@ enum {
  * SCF_ABI_MAJOR before its first call; structs additionally carry no size field,
  * so a mismatch must be refused, not worked around. */
 #define SCF_ABI_MAJOR 3
-#define SCF_VERSION (SCF_ABI_MAJOR * 100 + 5)
+#define SCF_VERSION (SCF_ABI_MAJOR * 100 + 6)
 int scf_version(void);
 const char* scf_error_string(int code);
 /* number of HIP devices visible (>=0) or SCF_ENODEVICE */
@@ -177,12 +177,16 @@ typedef struct scf_conv_desc {
   int32_t a4t_groups;
   const float* wp_wino1d;               /* optional: G g of a 1x5 / 5x1 stride-1 'same' layer (scf_pack_conv_weight_wino1d);
                                            selects the one-dimensional Winograd F(2, 5) fp32 kernel (every epilogue
-                                           kind incl. the GRU gates) on grids of >= 128 blocks; same contract as wp_wino */
+                                           kind incl. the GRU gates) on grids of >= CUs / 2 blocks (128 on the
+                                           MI355X); same contract as wp_wino */
   const float* wp_wino;                 /* optional: G g G^T of a 3x3 / stride-1 / pad-1 layer
                                            (scf_pack_conv_weight_wino); selects the Winograd F(2x2, 3x3)
                                            fp32 kernel for plain / affine epilogues (bias, BN, residual,
-                                           ReLU).  Same fp32 arithmetic, re-associated sums: results differ
-                                           from the direct kernels by a few ulp of the accumulated magnitude */
+                                           ReLU) on grids of >= CUs / 2 blocks (smaller grids: the direct kernels).
+                                           Same fp32 arithmetic, re-associated sums: results differ from the direct
+                                           kernels by a few ulp of sum |w||x|.  Kernel selection therefore depends on
+                                           N and on the device: leave both Winograd packings NULL for results that
+                                           do not */
 } scf_conv_desc;
 
 int scf_conv2d(const scf_conv_desc* desc, scf_stream_t stream);
@@ -391,6 +395,26 @@ int scf_pose_error(const double* verts, int nv, const double* gt_r, const double
  * reference does (its default align_corners=0 therefore samples at (x+fx)*W/(W-1) - 0.5). */
 int scf_filter_flow_by_mask(float* flow, const float* mask, int N, int H, int W,
                             float invalid_num, int align_corners, scf_stream_t stream);
+
+/* cal_epe (models/utils/flow.py:64-88), all three reductions from one pass over flow_tgt / flow_pred
+ * (N,2,H,W) and the optional mask (N,H,W; NULL = none):
+ *   valid = sqrt(tgt_x^2 + tgt_y^2) < max_flow [&& mask >= 0.5],  err = |flow_tgt - flow_pred|_2
+ *   err_map      (N,H,W) or NULL      reduction='none':  err * valid
+ *   mean, ratios (N), (nthr,N) / NULL reduction='mean':  sum(err * valid) / (count(valid) + 1e-10) per sample;
+ *                                     ratios[t][n] = count(err < threshs[t] among the INVALID pixels) / that
+ *                                     total -- the reference overwrites the valid pixels with 1e8 before the
+ *                                     comparison (flow.py:79), reproduced as-is; fix_threshold_quirk != 0
+ *                                     counts the valid pixels instead
+ *   total_mean, total_ratios (1), (nthr) / NULL   reduction='total_mean': the same over the whole batch,
+ *                                     ratios over the valid pixels (flow.py:84-87)
+ * threshs is a HOST array of nthr <= 8 thresholds.  Squares, adds and square roots are separately rounded
+ * fp32 operations as in torch; error sums are accumulated in fp64 in a fixed order and rounded once.
+ * workspace: scf_cal_epe_workspace_bytes(N, H, W) bytes of device memory (block partials). */
+int64_t scf_cal_epe_workspace_bytes(int N, int H, int W);
+int scf_cal_epe(const float* flow_tgt, const float* flow_pred, const float* mask, int N, int H, int W,
+                float max_flow, const float* threshs, int nthr, int fix_threshold_quirk, float* err_map,
+                float* mean, float* ratios, float* total_mean, float* total_ratios, void* workspace,
+                scf_stream_t stream);
 
 /* object-frame points of every pixel (dense cal_3d_2d_corr): pts (N,3,H,W), 0 where
  * depth <= 0.  Test/diagnostic entry; scf_reproject_flow recomputes them on the fly. */

@@ -30,6 +30,31 @@ int scf_timer_arm(scf_timer_t timer);
  * packing's KC does not fit this shape.  No launch: works without a GPU. */
 int scf_conv2d_query(const scf_conv_desc* desc, int32_t* info);
 
+/* Dispatch log: which kernel family ran each convolution launch.  scf_conv_log_enable(capacity > 0) starts
+ * (and clears) a process-wide log of up to `capacity` records; every successful scf_conv2d launch -- also
+ * those issued inside scf_sepconv_gru[_ctx] and scf_scflow_iteration -- appends one; scf_conv_log_enable(0)
+ * stops and frees it.  scf_conv_log_read copies up to max_entries records (out may be NULL) and returns the
+ * number recorded.  The tests use it to assert that a parity case really exercised the kernel it names
+ * (kernel selection depends on the grid size and the device: a threshold change must not silently move a
+ * golden test onto other arithmetic). */
+enum {
+  SCF_KERNEL_THIN = 1,        /* conv_thin_kernel: Cout <= 4, vector ALU                           */
+  SCF_KERNEL_TAPS = 2,        /* conv_taps_kernel: Cin <= 4, contraction over taps                 */
+  SCF_KERNEL_WINO = 3,        /* conv_wino_kernel: Winograd F(2x2, 3x3)                            */
+  SCF_KERNEL_WINO1D = 4,      /* conv_wino1d_kernel: Winograd F(2, 5)                              */
+  SCF_KERNEL_F16X3 = 5,       /* conv_f16x3_kernel: split-fp16 3xMFMA                              */
+  SCF_KERNEL_DMA = 6,         /* conv_dma_kernel: direct, LDS-DMA staged (pixel-split or K-split)  */
+  SCF_KERNEL_MFMA = 7,        /* conv_mfma_kernel: direct, register staged                         */
+  SCF_KERNEL_MFMA_KSPLIT = 8  /* conv_mfma_ksplit_kernel                                           */
+};
+typedef struct scf_conv_log_entry {
+  int32_t kernel;             /* SCF_KERNEL_*                                                      */
+  int32_t Cin, Cout, KH, KW, stride, Ho, Wo, N;
+  int32_t mode;               /* SCF_CONV_*                                                        */
+} scf_conv_log_entry;
+int scf_conv_log_enable(int capacity);
+int scf_conv_log_read(scf_conv_log_entry* out, int max_entries);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,15 @@ class GruPass(C.Structure):
     ]
 
 
+class ConvLogEntry(C.Structure):
+    """mirror of ``scf_conv_log_entry`` (include/scflow_hip_prof.h)."""
+    _fields_ = [(n, C.c_int32) for n in ('kernel', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'Ho', 'Wo', 'N', 'mode')]
+
+
+KERNEL_NAMES = {1: 'thin', 2: 'taps', 3: 'winograd', 4: 'winograd F(2,5)', 5: 'f16x3', 6: 'direct-dma',
+                7: 'direct-mfma', 8: 'direct-mfma-ksplit'}
+
+
 class IterGN(C.Structure):
     """mirror of ``scf_iter_gn``."""
     _fields_ = [('gamma', _fp), ('beta', _fp), ('out', _fp),
@@ -124,12 +133,17 @@ SIGNATURES = {
     'scf_corr_preferred_layout': (C.c_uint, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'scf_pose_error': (C.c_int, [_fp, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     'scf_filter_flow_by_mask': (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _fp]),
+    'scf_cal_epe_workspace_bytes': (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    'scf_cal_epe': (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float), C.c_int, C.c_int,
+                              _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     'scf_timer_create': (C.c_int, [C.POINTER(_fp)]),
     'scf_timer_destroy': (C.c_int, [_fp]),
     'scf_timer_arm': (C.c_int, [_fp]),
     'scf_timer_elapsed_us': (C.c_int, [_fp, C.POINTER(C.c_float)]),
     'scf_conv2d': (C.c_int, [C.POINTER(ConvDesc), _fp]),
     'scf_conv2d_query': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int32)]),
+    'scf_conv_log_enable': (C.c_int, [C.c_int]),
+    'scf_conv_log_read': (C.c_int, [C.POINTER(ConvLogEntry), C.c_int]),
     'scf_pack_conv_weight_size': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'scf_pack_conv_weight': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'scf_pack_conv_weight_a4_size': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -98,7 +98,7 @@ __device__ __forceinline__ int fast_div(int e, int d, float rd) {
 // phase ablations (tools/lab/conv_lab_hooks.h, -DSCF_CONV_LAB [-DSCF_CONV_LAB_MASK=m]); the product build sees
 // empty hooks
 #ifdef SCF_CONV_LAB
-#include "../../tools/lab/conv_lab_hooks.h"
+#include "conv_lab_hooks.h"      // lab builds only: -I tools/lab
 #else
 #define CTRACE(slot) do { } while (0)
 #define CLAB(bit) 0

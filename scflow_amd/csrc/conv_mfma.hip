@@ -21,6 +21,9 @@
 //     patch    [KC][PH][PW]    (input window incl. halo, zero padded)
 // in LDS, then issues T*KC/2 k-steps of WM*WN MFMAs.  2-3 blocks are resident per CU, so
 // one block's staging overlaps another's MFMA phase.
+#include <atomic>
+#include <mutex>
+#include <vector>
 #include "scf_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -540,31 +543,38 @@ static bool want_dma(const scf_conv_desc* d) {      // a layer opts in by carryi
          d->w_nstride == 0 && d->a4_mld >= d->Cout;
 }
 
-extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
+// which kernel family took the launch (SCF_KERNEL_* of scflow_hip_prof.h)
+static int conv2d_launch(const scf_conv_desc* d, scf_stream_t stream, int* which) {
   ConvPlan pl;
   const int rc = conv_plan(d, &pl);
   if (rc != SCF_OK) return rc;
   {
+    *which = SCF_KERNEL_THIN;
     const int rt = scf_conv_thin_dispatch(pl.k, d->N, false, scf_stream(stream));
     if (rt != SCF_EUNSUPPORTED) return rt;
   }
   if (d->wp_taps) {
+    *which = SCF_KERNEL_TAPS;
     const int rp = scf_conv_taps_dispatch(pl.k, d->wp_taps, d->N, false, nullptr, scf_stream(stream));
     if (rp != SCF_EUNSUPPORTED) return rp;
   }
   if (d->wp_wino) {
+    *which = SCF_KERNEL_WINO;
     const int rw = scf_conv_wino_dispatch(pl.k, d->wp_wino, d->N, false, nullptr, scf_stream(stream));
     if (rw != SCF_EUNSUPPORTED) return rw;
   }
   if (d->wp_wino1d) {
+    *which = SCF_KERNEL_WINO1D;
     const int rw = scf_conv_wino1d_dispatch(pl.k, d->wp_wino1d, d->N, false, nullptr, scf_stream(stream));
     if (rw != SCF_EUNSUPPORTED) return rw;
   }
   if (want_f16x3(d)) {
+    *which = SCF_KERNEL_F16X3;
     const int r16 = scf_conv_f16x3_dispatch(pl.k, d->N, false, nullptr, scf_stream(stream));
     if (r16 != SCF_EUNSUPPORTED) return r16;
   }
   if (want_dma(d)) {
+    *which = SCF_KERNEL_DMA;
     const int rd = scf_conv_dma_dispatch(pl.k, d->N, false, nullptr, scf_stream(stream));
     if (rd != SCF_EUNSUPPORTED) return rd;
   }
@@ -574,15 +584,59 @@ extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
   const size_t lds_bytes = pl.lds_bytes;
   hipStream_t st = scf_stream(stream);
   if (k.ksplit) {
+    *which = SCF_KERNEL_MFMA_KSPLIT;
     if (k.KC == 32) return launch_ksplit<32>(k, (int)nblk, lds_bytes, st);
     if (k.KC == 8) return launch_ksplit<8>(k, (int)nblk, lds_bytes, st);
     return launch_ksplit<2>(k, (int)nblk, lds_bytes, st);
   }
+  *which = SCF_KERNEL_MFMA;
 #define SCF_CASE(M, Nn) if (WM == M && WN == Nn) return launch_conv<M, Nn>(k, (int)nblk, lds_bytes, st);
   SCF_CASE(1, 1) SCF_CASE(1, 2) SCF_CASE(2, 1) SCF_CASE(2, 2)
   SCF_CASE(3, 1) SCF_CASE(4, 1)
 #undef SCF_CASE
   return SCF_EUNSUPPORTED;
+}
+
+// ---- dispatch log (scflow_hip_prof.h): which kernel family ran each convolution launch of this process,
+//      including the launches issued inside scf_sepconv_gru* / scf_scflow_iteration ----
+namespace {
+std::mutex g_log_mu;
+std::vector<scf_conv_log_entry> g_log;
+std::atomic<int> g_log_cap{0};
+}
+
+extern "C" int scf_conv_log_enable(int capacity) {
+  std::lock_guard<std::mutex> lk(g_log_mu);
+  g_log.clear();
+  if (capacity > 0) g_log.reserve((size_t)capacity);
+  else g_log.shrink_to_fit();
+  g_log_cap.store(capacity > 0 ? capacity : 0);
+  return SCF_OK;
+}
+
+extern "C" int scf_conv_log_read(scf_conv_log_entry* out, int max_entries) {
+  std::lock_guard<std::mutex> lk(g_log_mu);
+  const int n = (int)g_log.size();
+  if (out)
+    for (int i = 0; i < n && i < max_entries; ++i) out[i] = g_log[(size_t)i];
+  return n;
+}
+
+extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
+  int which = 0;
+  const int rc = conv2d_launch(d, stream, &which);
+  if (rc == SCF_OK && g_log_cap.load(std::memory_order_relaxed) > 0) {
+    std::lock_guard<std::mutex> lk(g_log_mu);
+    if ((int)g_log.size() < g_log_cap.load()) {
+      scf_conv_log_entry e;
+      e.kernel = which; e.Cin = d->C0 + d->C1; e.Cout = d->Cout; e.KH = d->KH; e.KW = d->KW; e.stride = d->stride;
+      e.Ho = (d->H + 2 * d->pad_h - d->KH) / d->stride + 1;
+      e.Wo = (d->W + 2 * d->pad_w - d->KW) / d->stride + 1;
+      e.N = d->N; e.mode = d->mode;
+      g_log.push_back(e);
+    }
+  }
+  return rc;
 }
 
 // ---------------------------------------------------------------------------------

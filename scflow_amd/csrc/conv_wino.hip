@@ -50,7 +50,7 @@ typedef float wn_f32x2 __attribute__((ext_vector_type(2)));
 // tools/lab/wino_phases.py builds this file with compile-time phase ablations (tools/lab/wino_lab_hooks.h,
 // -DSCF_WINO_LAB -DSCF_WINO_LAB_MASK=m); the product build sees constants
 #ifdef SCF_WINO_LAB
-#include "../../tools/lab/wino_lab_hooks.h"
+#include "wino_lab_hooks.h"      // lab builds only: -I tools/lab
 #else
 #define WN_LAB(bit) 0
 #define WN_LAB_FIELDS
@@ -411,10 +411,6 @@ extern "C" int scf_pack_conv_weight_wino(const float* w, int32_t cout, int32_t c
   return SCF_OK;
 }
 
-static int wino_lds_attr(const void* fn, size_t bytes) {
-  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? SCF_OK : SCF_ELAUNCH;
-}
-
 // Tile selection + launch; SCF_EUNSUPPORTED -> the caller goes on to the direct kernels.
 // info (optional): {16 transform positions, fragments per block, blocks, LDS bytes}.
 int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* info, hipStream_t st) {
@@ -467,14 +463,12 @@ int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* i
   if (ldsb > 80 * 1024) return SCF_EUNSUPPORTED;
   if (info) { info[0] = 16; info[1] = CW * TW; info[2] = (int)nblk; info[3] = (int)ldsb; }     // positions, fragments per block
   if (dry_run) return SCF_OK;
-  static bool raised[64][2] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SCF_ELAUNCH;
   const int cfg = px4 ? 1 : 0;
-  if (!raised[dev][cfg]) {          // more than 64 KB of dynamic LDS needs the attribute, once per device
-    const int rc = wino_lds_attr(cfg ? (const void*)conv_wino_kernel<1, 2, true> : (const void*)conv_wino_kernel<1, 2, false>, 80 * 1024);
+  {                                  // more than 64 KB of dynamic LDS needs the attribute, once per kernel and device
+    static std::atomic<unsigned long long> raised[2];
+    const int rc = scf_raise_dynamic_lds(raised[cfg], cfg ? (const void*)conv_wino_kernel<1, 2, true>
+                                                          : (const void*)conv_wino_kernel<1, 2, false>, 80 * 1024);
     if (rc != SCF_OK) return rc;
-    raised[dev][cfg] = true;
   }
   if (cfg) scf_launch((conv_wino_kernel<1, 2, true>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
   else scf_launch((conv_wino_kernel<1, 2, false>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);

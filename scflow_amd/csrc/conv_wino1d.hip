@@ -368,15 +368,13 @@ int scf_conv_wino1d_dispatch(ConvK k, const float* wu, int N, bool dry_run, int*
   const size_t ldsb = (size_t)(3 * 2 * W1_UF + 3 * npi * (px4 ? 1024 : 256)) * sizeof(float);
   if (info) { info[0] = 6; info[1] = 4; info[2] = (int)nblk; info[3] = (int)ldsb; }      // positions, fragments per block
   if (dry_run) return SCF_OK;
-  static bool raised[64][3] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SCF_ELAUNCH;
   const int cfg = vert ? 2 : (px4 ? 1 : 0);
   const void* fn = cfg == 2 ? (const void*)conv_wino1d_kernel<true, true> : cfg == 1 ? (const void*)conv_wino1d_kernel<false, true>
                                                                                     : (const void*)conv_wino1d_kernel<false, false>;
-  if (ldsb > 64 * 1024 && !raised[dev][cfg]) {
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return SCF_ELAUNCH;
-    raised[dev][cfg] = true;
+  if (ldsb > 64 * 1024) {
+    static std::atomic<unsigned long long> raised[3];
+    const int rc = scf_raise_dynamic_lds(raised[cfg], fn, 80 * 1024);
+    if (rc != SCF_OK) return rc;
   }
   if (cfg == 2) scf_launch((conv_wino1d_kernel<true, true>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
   else if (cfg == 1) scf_launch((conv_wino1d_kernel<false, true>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);

@@ -48,7 +48,7 @@
 // tools/lab/lookup_lab.hip compiles this file with per-wave timeline stamps and ablation switches;
 // their code lives in tools/lab/lookup_lab_hooks.h.  The product build sees empty hooks.
 #ifdef SCF_LOOKUP_LAB
-#include "../../tools/lab/lookup_lab_hooks.h"
+#include "lookup_lab_hooks.h"    // lab builds only: -I tools/lab
 #else
 #define LK_LAB_PARAMS
 #define LK_TRACE(slot) do { } while (0)

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <atomic>
 
 #include "../../include/scflow_hip.h"
 #include "../../include/scflow_hip_prof.h"
@@ -30,6 +31,19 @@ static inline int scf_cu_count() {
     cus[dev] = n;
   }
   return cus[dev];
+}
+
+// Opt a kernel in to more than 64 KiB of dynamic LDS, once per (kernel, device): `done` is that kernel's own
+// flag word (bit d = raised on device d).  Two host threads meeting here both call hipFuncSetAttribute -- the call
+// is idempotent -- and both set the bit: no unsynchronised flag, no lock on the launch path.
+static inline int scf_raise_dynamic_lds(std::atomic<unsigned long long>& done, const void* fn, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return SCF_ELAUNCH;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return SCF_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return SCF_ELAUNCH;
+  done.fetch_or(bit, std::memory_order_release);
+  return SCF_OK;
 }
 
 // A timer = two HIP events bound to ONE kernel launch (hipExtLaunchKernel start / stop events:

@@ -10,33 +10,50 @@
 
 namespace {
 
-// fork / join events of the optional side-stream branches: a small per-thread pool, created on first
-// use (timing disabled).  Re-recording an event after the wait that used it was enqueued is safe:
-// hipStreamWaitEvent captures the record that precedes it.
+// fork / join events of the optional side-stream branches: a small pool per (host thread, DEVICE), created on
+// first use on that device (timing disabled) -- an event belongs to the device that was current when it was
+// created, so a thread that drives cuda:0 and then cuda:1 must not reuse the first device's events.
+// Re-recording an event after the wait that used it was enqueued is safe: hipStreamWaitEvent captures the
+// record that precedes it.  The pools live as long as the thread (a handful of events per device).
 struct IterEvents {
-  hipEvent_t ev[6];
+  hipEvent_t ev[7];
   bool ok = false;
   bool init() {
     if (ok) return true;
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 7; ++i)
       if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
     return ok = true;
   }
 };
-IterEvents& iter_events() {
-  static thread_local IterEvents e;
-  return e;
+IterEvents* iter_events() {
+  static thread_local IterEvents pool[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  return pool[dev].init() ? &pool[dev] : nullptr;
 }
+
+bool fork_to(hipStream_t from, hipStream_t to, hipEvent_t ev) {
+  return hipEventRecord(ev, from) == hipSuccess && hipStreamWaitEvent(to, ev, 0) == hipSuccess;
+}
+
+// A side-stream branch that is open when the call leaves early (a launch inside it failed) is joined on the way
+// out: otherwise later work on the main stream would no longer be ordered behind the side stream's writes to the
+// scratch buffers, and under hipGraph capture the unjoined stream would invalidate the capture with an unrelated
+// error.
+struct OpenBranch {
+  hipStream_t mainq, sideq;
+  hipEvent_t join_ev;
+  bool open = false;
+  ~OpenBranch() {
+    if (open) (void)fork_to(sideq, mainq, join_ev);
+  }
+};
 
 #define SCF_TRY(call)                \
   do {                               \
     const int rc_ = (call);          \
     if (rc_ != SCF_OK) return rc_;   \
   } while (0)
-
-bool fork_to(hipStream_t from, hipStream_t to, hipEvent_t ev) {
-  return hipEventRecord(ev, from) == hipSuccess && hipStreamWaitEvent(to, ev, 0) == hipSuccess;
-}
 
 }  // namespace
 
@@ -51,8 +68,11 @@ extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stre
   const bool any_overlap = it->overlap_flow || it->overlap_mask || it->overlap_up;
   if (any_overlap && !it->side_stream) return SCF_EINVAL;
   hipStream_t mainq = scf_stream(stream), sideq = scf_stream(it->side_stream);
-  IterEvents& E = iter_events();
-  if (any_overlap && !E.init()) return SCF_ELAUNCH;
+  IterEvents* Ep = any_overlap ? iter_events() : nullptr;
+  if (any_overlap && !Ep) return SCF_ELAUNCH;
+  static IterEvents none;                 // never dereferenced without overlap
+  IterEvents& E = Ep ? *Ep : none;
+  OpenBranch br{mainq, sideq, E.ev[6]};
   const int N = it->N, hw = it->h * it->w;
   const float scale = (float)it->H / (float)it->h;
 
@@ -65,7 +85,10 @@ extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stre
     SCF_TRY(scf_mul_mask(it->flow_lr, (int64_t)2 * hw, it->mask_prev, it->flow_masked, (int64_t)2 * hw, N, 2, hw, stream));
     flow_enc = it->flow_masked;
   }
-  if (it->overlap_flow && !fork_to(mainq, sideq, E.ev[0])) return SCF_ELAUNCH;
+  if (it->overlap_flow) {
+    if (!fork_to(mainq, sideq, E.ev[0])) return SCF_ELAUNCH;
+    br.open = true;
+  }
   // ---- correlation lookup (:198) ----
   if (it->lookup_timer) scf_timer_arm(it->lookup_timer);
   const int rl = scf_corr_lookup_ex(it->levels, it->flow_lr, it->corr, N, it->h, it->w, it->radius, it->L,
@@ -84,7 +107,10 @@ extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stre
     SCF_TRY(scf_conv2d(&it->flow1, fq));
     SCF_TRY(scf_conv2d(&it->corr0, stream));
     SCF_TRY(scf_conv2d(&it->corr1, stream));
-    if (it->overlap_flow && !fork_to(sideq, mainq, E.ev[1])) return SCF_ELAUNCH;
+    if (it->overlap_flow) {
+      br.open = false;
+      if (!fork_to(sideq, mainq, E.ev[1])) return SCF_ELAUNCH;
+    }
     SCF_TRY(scf_conv2d(&it->outn, stream));
     SCF_TRY(scf_copy_strided(flow_enc, (int64_t)2 * hw, it->flow_copy_dst, it->hx_nstride, N, (int64_t)2 * hw, stream));
   }
@@ -101,17 +127,26 @@ extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stre
   SCF_TRY(scf_conv2d(&it->mpred, stream));
   {
     scf_stream_t mq = it->overlap_mask ? it->side_stream : stream;
-    if (it->overlap_mask && !fork_to(mainq, sideq, E.ev[2])) return SCF_ELAUNCH;
+    if (it->overlap_mask) {
+      if (!fork_to(mainq, sideq, E.ev[2])) return SCF_ELAUNCH;
+      br.open = true;
+    }
     SCF_TRY(scf_conv2d(&it->menc0, mq));
     SCF_TRY(scf_conv2d(&it->menc1, mq));
     SCF_TRY(scf_conv2d(&it->denc0, stream));
     SCF_TRY(scf_conv2d(&it->denc1, stream));
-    if (it->overlap_mask && !fork_to(sideq, mainq, E.ev[3])) return SCF_ELAUNCH;
+    if (it->overlap_mask) {
+      br.open = false;
+      if (!fork_to(sideq, mainq, E.ev[3])) return SCF_ELAUNCH;
+    }
   }
   // ---- full-resolution outputs (:222-227): they feed nothing, beside the pose head ----
   {
     scf_stream_t uq = it->overlap_up ? it->side_stream : stream;
-    if (it->overlap_up && !fork_to(mainq, sideq, E.ev[4])) return SCF_ELAUNCH;
+    if (it->overlap_up) {
+      if (!fork_to(mainq, sideq, E.ev[4])) return SCF_ELAUNCH;
+      br.open = true;
+    }
     SCF_TRY(scf_resize_bilinear(it->flow_lr, it->fpred.out, it->flow_pred, (int64_t)N * 2, it->h, it->w, it->H, it->W,
                                 scale, uq));
     SCF_TRY(scf_resize_bilinear(it->mpred.out, nullptr, it->mask_up, (int64_t)N, it->h, it->w, it->H, it->W, 1.0f, uq));
@@ -131,6 +166,9 @@ extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stre
                           it->d_rot, it->d_trans, it->R_out, it->t_out, N, stream));
   SCF_TRY(scf_reproject_flow(it->depth, it->K, it->R0, it->t0, it->R_out, it->t_out, it->flow_out, N, it->H, it->W,
                              it->invalid_flow_num, stream));
-  if (it->overlap_up && !fork_to(sideq, mainq, E.ev[5])) return SCF_ELAUNCH;
+  if (it->overlap_up) {
+    br.open = false;
+    if (!fork_to(sideq, mainq, E.ev[5])) return SCF_ELAUNCH;
+  }
   return SCF_OK;
 }

@@ -2,14 +2,12 @@
 models/utils/flow.py:64-88) and the ground-truth flow it is measured against --
 ``get_flow_from_delta_pose_and_depth`` (models/utils/pose.py:92-121) and ``filter_flow_by_mask``
 (models/utils/flow.py:6-26), as the RAFT refiners build it (raft_refiner_flow_mask.py:180-191).
-The two flow functions run on the HIP kernels of the hot path (dense re-projection, one
-element-wise filter); ``cal_epe`` is a handful of torch reductions.
+All three run on HIP kernels: the dense re-projection of the hot path, one element-wise filter, and
+``scf_cal_epe`` (metrics.hip: one pass over the two flow fields, fixed-order reductions).
 
-Not a kernel: a handful of reductions over the final flow field, run once per evaluation
-batch with torch ops on whatever device the flows live on.  Restated as-is, including the
-reference's quirk in the 'mean' branch (the errors of the *valid* pixels are overwritten with
-1e8 before the '<t>px' ratios are taken, flow.py:79) -- pass ``fix_threshold_quirk=True`` for
-the evidently intended behaviour.
+``cal_epe`` is restated as-is, including the reference's quirk in the 'mean' branch (the errors of
+the *valid* pixels are overwritten with 1e8 before the '<t>px' ratios are taken, flow.py:79) -- pass
+``fix_threshold_quirk=True`` for the evidently intended behaviour.
 """
 from __future__ import annotations
 
@@ -42,26 +40,51 @@ def filter_flow_by_mask(flow, gt_mask, invalid_num: float = 400, mode: str = 'bi
 
 def cal_epe(flow_tgt: torch.Tensor, flow_pred: torch.Tensor, mask, max_flow: float = 400,
             reduction: str = 'mean', threshs=(1, 3, 5), fix_threshold_quirk: bool = False):
-    mag = torch.sum(flow_tgt ** 2, dim=1).sqrt()
-    valid = (mag < max_flow) & (mask >= 0.5) if mask is not None else (mag < max_flow)
-    err = torch.sum((flow_tgt - flow_pred) ** 2, dim=1).sqrt()
+    """``cal_epe`` (models/utils/flow.py:64-88), same arguments and returns (a dict of tensors, or the
+    masked error map for ``reduction='none'``): one HIP pass over the two flow fields
+    (``scf_cal_epe``: |delta|, validity, masked sums and the threshold counts, fixed-order
+    reductions) plus a one-block combine.  GPU tensors only, like every other operator here."""
+    import ctypes as C
+    from . import _lib, ops
+    if reduction not in ('none', 'mean', 'total_mean'):
+        raise ValueError(reduction)
+    pt, pp = ops._dense(flow_tgt, 'flow_tgt'), ops._dense(flow_pred, 'flow_pred')
+    if flow_tgt.dim() != 4 or flow_tgt.shape[1] != 2 or flow_tgt.shape != flow_pred.shape:
+        raise _lib.ScflowHipError('cal_epe: flow_tgt / flow_pred must be equal-shape (N,2,H,W)')
+    n, _, h, w = flow_tgt.shape
+    pm = None
+    if mask is not None:
+        mask = mask.to(torch.float32).contiguous()
+        if tuple(mask.shape) != (n, h, w):
+            raise _lib.ScflowHipError(f'cal_epe: mask has shape {tuple(mask.shape)}, expected {(n, h, w)}')
+        pm = ops._dense(mask, 'mask')
+    lib = _lib.load()
+    dev = flow_tgt.device
+    thr = (C.c_float * max(len(threshs), 1))(*[float(t) for t in threshs])
+    ws = torch.empty((int(lib.scf_cal_epe_workspace_bytes(n, h, w)),), dtype=torch.uint8, device=dev)
+    E = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    err_map = mean = ratios = tmean = tratios = None
     if reduction == 'none':
-        return err * valid.to(err)
+        err_map = E(n, h, w)
+    elif reduction == 'mean':
+        mean, ratios = E(n), E(max(len(threshs), 1), n)
+    else:
+        tmean, tratios = E(1), E(max(len(threshs), 1))
+    P = lambda t: None if t is None else t.data_ptr()
+    _lib.check(lib.scf_cal_epe(pt, pp, pm, n, h, w, float(max_flow), thr, len(threshs), int(fix_threshold_quirk),
+                               P(err_map), P(mean), P(ratios), P(tmean), P(tratios), ws.data_ptr(), ops._stream()),
+               'scf_cal_epe')
+    if reduction == 'none':
+        return err_map
     acc = {}
     if reduction == 'mean':
-        total = valid.sum(dim=(-1, -2)) + 1e-10
-        acc['mean'] = (err * valid.to(err)).sum(dim=(-1, -2)) / total
-        thr_err = torch.where(valid, err, torch.full_like(err, 1e8)) if fix_threshold_quirk \
-            else torch.where(valid, torch.full_like(err, 1e8), err)
-        for t in threshs:
-            acc[f'{t}px'] = (thr_err < t).sum(dim=(-1, -2)) / total
-    elif reduction == 'total_mean':
-        total = valid.sum(dim=(-1, -2, -3)) + 1e-10
-        acc['mean'] = (err * valid.to(err.dtype)).sum(dim=(-1, -2, -3)) / total
-        for t in threshs:
-            acc[f'{t}px'] = (err[valid] < t).sum() / total
+        acc['mean'] = mean
+        for i, t in enumerate(threshs):
+            acc[f'{t}px'] = ratios[i]
     else:
-        raise ValueError(reduction)
+        acc['mean'] = tmean.reshape(())
+        for i, t in enumerate(threshs):
+            acc[f'{t}px'] = tratios[i]
     return acc
 
 

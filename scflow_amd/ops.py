@@ -25,7 +25,7 @@ from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_GRU_Q, CONV_G
 
 Tensor = torch.Tensor
 
-__all__ = ['PackedConv', 'conv_desc', 'gru_passes', 'scflow_iteration', 'side_stream_handle', 'pyramid_layout', 'untile_level', 'level_storage_shape', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision', 'set_conv_winograd', 'get_conv_winograd', 'pack_conv_weight_wino', 'pack_conv_weight_wino1d',
+__all__ = ['record_conv_kernels', 'PackedConv', 'conv_desc', 'gru_passes', 'scflow_iteration', 'side_stream_handle', 'pyramid_layout', 'untile_level', 'level_storage_shape', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision', 'set_conv_winograd', 'get_conv_winograd', 'pack_conv_weight_wino', 'pack_conv_weight_wino1d',
            'get_conv_precision', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
            'instance_norm', 'group_norm_relu', 'linear', 'pose_update', 'reproject_flow',
            'unproject_depth', 'linear_pair', 'resize_bilinear', 'convex_upsample', 'avgpool2x2', 'copy_channels',
@@ -264,51 +264,31 @@ def pack_conv_weight_taps(weight: Tensor) -> Tensor:
 
 
 def pack_conv_weight_wino(weight: Tensor) -> Tensor:
-    """(Cout, Cin, 3, 3) -> U = G g G^T in conv_wino.hip's layout (scf_pack_conv_weight_wino):
-    [chunk][Cout / 32][4 i' + j][channel & 1][Cout % 32][channel >> 1 & 1] with the rows i of the transform
-    domain stored in the order i' -> 0, 1, 3, 2 (conv_wino.hip gives each of the two rows-halves one wave), 4 channels per chunk,
-    computed in double and rounded once; zero padded."""
+    """(Cout, Cin, 3, 3) -> U = G g G^T in conv_wino.hip's layout, on the weight's device: the library's
+    own host packer (``scf_pack_conv_weight_wino``: computed in double, rounded once; layout in
+    include/scflow_hip.h) + one copy.  No vendor BLAS on the set-up path."""
     cout, cin, kh, kw = weight.shape
     if (kh, kw) != (3, 3):
         raise ValueError('Winograd packing: 3x3 kernels')
-    g = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]],
-                     dtype=torch.float64, device=weight.device)
-    u = torch.einsum('ia,ocab,jb->ijoc', g, weight.double(), g)[[0, 1, 3, 2]].reshape(16, cout, cin)   # rows stored 0, 1, 3, 2
-    f, nchunk = (cout + 31) // 32, (cin + 3) // 4
-    full = torch.zeros((16, f * 32, nchunk * 4), dtype=torch.float64, device=weight.device)
-    full[:, :cout, :cin] = u
-    # [xi][frag][m][chunk][s][kh] -> [chunk][frag][xi][kh][m][s]
-    full = full.reshape(16, f, 32, nchunk, 2, 2).permute(3, 1, 0, 5, 2, 4)
-    return full.contiguous().float().reshape(-1)
+    lib = _lib.load()
+    host_w = weight.detach().to('cpu', torch.float32).contiguous()
+    out = torch.empty((int(lib.scf_pack_conv_weight_wino_size(cout, cin)),), dtype=torch.float32)
+    _lib.check(lib.scf_pack_conv_weight_wino(host_w.data_ptr(), cout, cin, out.data_ptr()), 'scf_pack_conv_weight_wino')
+    return out.to(weight.device)
 
 
 def pack_conv_weight_wino1d(weight: Tensor) -> Tensor:
-    """(Cout, Cin, 1, 5) or (Cout, Cin, 5, 1) -> U = G g in conv_wino1d.hip's layout (scf_pack_conv_weight_wino1d):
-    [chunk][Cout / 32][position i][channel & 1][Cout % 32][channel >> 1 & 3], 8 channels per chunk; G = the 6 x 5
-    matrix of the points 0, 1, -1, 2, -2, infinity; computed in double and rounded once; zero padded."""
+    """(Cout, Cin, 1, 5) or (Cout, Cin, 5, 1) -> U = G g in conv_wino1d.hip's layout, on the weight's device
+    (``scf_pack_conv_weight_wino1d``: G = the 6 x 5 matrix of the points 0, 1, -1, 2, -2, infinity; computed
+    in double, rounded once)."""
     cout, cin, kh, kw = weight.shape
     if (kh, kw) not in ((1, 5), (5, 1)):
         raise ValueError('F(2, 5) packing: 1x5 / 5x1 kernels')
-    pts = [0.0, 1.0, -1.0, 2.0, -2.0]
-    g = torch.zeros((6, 5), dtype=torch.float64)
-    for i, a in enumerate(pts):
-        nrm = 1.0
-        for k, b in enumerate(pts):
-            if k != i:
-                nrm *= a - b
-        g[i] = torch.tensor([a ** k / nrm for k in range(5)], dtype=torch.float64)
-    g[5, 4] = 1.0
-    wd = weight.reshape(cout, cin, 5).double()
-    g = g.to(weight.device)
-    u = torch.zeros((6, cout, cin), dtype=torch.float64, device=weight.device)
-    for k in range(5):                   # the C packer's order of adds: bit-identical packings
-        u = u + g[:, k, None, None] * wd[None, :, :, k]
-    f, nchunk = (cout + 31) // 32, (cin + 7) // 8
-    full = torch.zeros((6, f * 32, nchunk * 8), dtype=torch.float64, device=weight.device)
-    full[:, :cout, :cin] = u
-    # [i][frag][m][chunk][s][kh] -> [chunk][frag][i][kh][m][s]
-    full = full.reshape(6, f, 32, nchunk, 4, 2).permute(3, 1, 0, 5, 2, 4)
-    return full.contiguous().float().reshape(-1)
+    lib = _lib.load()
+    host_w = weight.detach().to('cpu', torch.float32).reshape(cout, cin, 5).contiguous()
+    out = torch.empty((int(lib.scf_pack_conv_weight_wino1d_size(cout, cin)),), dtype=torch.float32)
+    _lib.check(lib.scf_pack_conv_weight_wino1d(host_w.data_ptr(), cout, cin, out.data_ptr()), 'scf_pack_conv_weight_wino1d')
+    return out.to(weight.device)
 
 
 _CONV_PRECISION = 'f32'
@@ -319,9 +299,14 @@ def set_conv_winograd(on: bool) -> bool:
     """3x3 / stride-1 / pad-1 layers with plain or affine epilogues through the Winograd F(2x2, 3x3)
     kernel (conv_wino.hip: fp32 throughout, 2.25x fewer matrix-core flops, sums re-associated: error vs
     fp64 1.5-1.8x the direct kernels' ~1e-6, end-to-end flow EPE unchanged at 6e-5 px) instead of the direct
-    kernels, on grids of >= CUs / 2 blocks (small grids stay direct).  On by default; only under conv
-    precision 'f32'.  ``False`` = the direct kernels everywhere (bit-for-bit fp32 fma chains in the
-    reference's summation order).  Returns the previous setting."""
+    kernels, on grids of >= CUs / 2 blocks (small grids stay direct); the 1x5 / 5x1 GRU gates likewise through
+    the F(2, 5) kernel (conv_wino1d.hip).  On by default.  Under conv precision 'f16x3' the layers that carry
+    a split-fp16 packing take that kernel instead; layers without one (Cin < 16) still take Winograd.
+    ``False`` = the direct kernels everywhere (bit-for-bit fp32 fma chains in the reference's summation
+    order).  NB the kernel choice depends on the grid size (batch x map size) and the device's CU count:
+    the same pair can differ by ~1e-6 between batch 1 and batch 32; ``set_conv_winograd(False)`` removes
+    the largest part of that dependence (the direct kernels still pick K-split tiles on small grids).
+    Returns the previous setting."""
     global _CONV_WINOGRAD
     prev, _CONV_WINOGRAD = _CONV_WINOGRAD, bool(on)
     return prev
@@ -516,11 +501,15 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
             lib = _lib.load()
             info = (C.c_int32 * 4)()
             use_alt = False
+            # the KC decision describes the DIRECT register-staged kernel: asked with the Winograd packings
+            # cleared, so that the cached plan does not depend on whether Winograd was on at the first call
+            ww, ww1, d.wp_wino, d.wp_wino1d = d.wp_wino, d.wp_wino1d, None, None
             if (lib.scf_conv2d_query(C.byref(d), info) == 0 and info[0] * info[1] == 1
                     and 0 <= info[3] * 64 < 6000):
                 d.wp, d.KC = pc.wp_alt.data_ptr(), 32
                 use_alt = lib.scf_conv2d_query(C.byref(d), info) == 0
                 d.wp, d.KC = pc.wp.data_ptr(), pc.kc
+            d.wp_wino, d.wp_wino1d = ww, ww1
             pc.plans[key] = use_alt
         if use_alt:
             d.wp, d.KC = pc.wp_alt.data_ptr(), 32
@@ -657,6 +646,33 @@ def conv_timing(enable: bool):
     evs, _CONV_EVENTS = _CONV_EVENTS or [], None
     torch.cuda.synchronize()
     return list(zip(_read_timers([e[0] for e in evs]), [e[1] for e in evs], [e[2] for e in evs]))
+
+
+class record_conv_kernels:
+    """``with ops.record_conv_kernels() as ran: ...`` -- afterwards ``ran`` is a list of
+    ``(layer tag, kernel family)`` for every convolution launch the library made inside the block, in
+    launch order, INCLUDING those issued inside ``scf_sepconv_gru*`` / ``scf_scflow_iteration``
+    (``scf_conv_log_*`` of scflow_hip_prof.h).  Tag = ``'<Cin>-><Cout> <KH>x<KW>/s<stride> @<Ho>x<Wo> N<N>'``
+    (the tag ``conv_timing`` uses), family = one of ``_lib.KERNEL_NAMES``' values.  Parity tests assert with
+    it that the kernel they name really ran (the choice depends on grid size and device)."""
+
+    def __init__(self, capacity: int = 1 << 16) -> None:
+        self.capacity, self.ran = capacity, []
+
+    def __enter__(self):
+        _lib.check(_lib.load().scf_conv_log_enable(self.capacity), 'scf_conv_log_enable')
+        return self.ran
+
+    def __exit__(self, *exc):
+        lib = _lib.load()
+        n = lib.scf_conv_log_read(None, 0)
+        buf = (_lib.ConvLogEntry * max(n, 1))()
+        n = min(lib.scf_conv_log_read(buf, n), n)
+        lib.scf_conv_log_enable(0)
+        for e in buf[:n]:
+            self.ran.append((f'{e.Cin}->{e.Cout} {e.KH}x{e.KW}/s{e.stride} @{e.Ho}x{e.Wo} N{e.N}',
+                             _lib.KERNEL_NAMES.get(e.kernel, str(e.kernel))))
+        return False
 
 
 def time_first_kernel(fn) -> float:

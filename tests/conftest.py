@@ -33,3 +33,36 @@ def _library_built():
     if mod.needs_build() and (os.path.exists(hipcc) or shutil.which('hipcc')):
         mod.build()
     yield
+
+
+# ---- which convolution kernel ran --------------------------------------------------
+# Kernel selection (Winograd vs direct, pixel-split vs K-split tiles) depends on the grid size and the CU count, so
+# a moved threshold could silently put a golden test on other arithmetic.  Parity tests record the launches of their
+# HIP run (ops.record_conv_kernels: the library's own dispatch log) and compare the SET of (layer, kernel family)
+# with the plan pinned in tests/golden/dispatch_plan.json (MI355X, 256 CUs).  SCF_WRITE_DISPATCH_PLAN=1 (on the GPU
+# box) records instead of checking and writes gpurun_out/dispatch_plan.json, which is then reviewed and committed.
+DISPATCH_PLAN = os.path.join(GOLDEN, 'dispatch_plan.json')
+
+
+def check_dispatch(name, ran):
+    import json
+    got = sorted({f'{tag} | {kind}' for tag, kind in ran})
+    assert got, f'{name}: no convolution launch was recorded'
+    if os.environ.get('SCF_WRITE_DISPATCH_PLAN'):
+        out = os.path.join(ROOT, 'gpurun_out', 'dispatch_plan.json')
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        plan = json.load(open(out)) if os.path.exists(out) else {}
+        plan[name] = got
+        with open(out, 'w') as f:
+            json.dump(plan, f, indent=1, sort_keys=True)
+        return
+    plan = json.load(open(DISPATCH_PLAN))
+    assert name in plan, f'{name}: no pinned dispatch plan (run the GPU tests with SCF_WRITE_DISPATCH_PLAN=1)'
+    want = plan[name]
+    assert got == want, (f'{name}: the convolution kernels that ran differ from the pinned plan -- '
+                         f'only in this run: {sorted(set(got) - set(want))}; only in the plan: {sorted(set(want) - set(got))}')
+
+
+@pytest.fixture(scope='session')
+def dispatch_check():
+    return check_dispatch

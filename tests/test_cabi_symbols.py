@@ -36,10 +36,10 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_operator_header_holds_no_measurement_entry_points():
     ops_abi = _declared_symbols(('scflow_hip.h',))
-    assert not [n for n in ops_abi if n.startswith('scf_timer') or n.endswith(('_timed', '_query'))]
+    assert not [n for n in ops_abi if n.startswith('scf_timer') or n.endswith(('_timed', '_query')) or n.startswith('scf_conv_log')]
     prof = set(_declared_symbols(('scflow_hip_prof.h',))) - set(ops_abi)
     assert prof == {'scf_timer_create', 'scf_timer_destroy', 'scf_timer_arm', 'scf_timer_elapsed_us',
-                    'scf_conv2d_query'}
+                    'scf_conv2d_query', 'scf_conv_log_enable', 'scf_conv_log_read'}
 
 
 def test_version_and_error_strings():

@@ -1,6 +1,6 @@
 """GPU: the N > 1 path on real hardware as far as ONE GPU allows.
 
-``bench.py --gpus 2 --share-device`` self-launches two ranks (torch.distributed.run, gloo), both on
+``bench.py --gpus N --share-device`` (N = 2 and N = 8) self-launches N ranks (torch.distributed.run, gloo), both on
 cuda:0: two processes load libscflow_hip.so side by side, run the REAL get_pose step on their own 16
 pairs, meet at the barriers, reduce the block time with MAX over ranks and gather the poses (device
 tensors) into job order.  The gathered poses must equal a single-process run of the same two shards
@@ -21,9 +21,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_share_one_gpu(tmp_path):
+@pytest.mark.parametrize('world,batch', [(2, 16), (8, 4)])
+def test_ranks_share_one_gpu(tmp_path, world, batch):
+    """world = 2: two shards of 16 (the r3 case).  world = 8: configs[3]'s process count on the one GPU this
+    box has -- eight concurrent library loads, eight sets of >64 KB LDS attribute raises, event / timer pools and
+    side streams, eight host launch loops pinned to their own CPUs inside the cgroup quota, eight-way barriers,
+    MAX-over-ranks timing and pose gather.  Functional only."""
     dump = os.path.join(tmp_path, 'poses.pt')
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--share-device', '--batch', '16',
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--share-device', '--batch', str(batch),
            '--steps', '2', '--warmup', '1', '--min-seconds', '0.2', '--min-warmup-seconds', '0.1', '--no-alt',
            '--no-batch1', '--no-config4', '--no-cpu-baseline', '--dump-poses', dump]
     env = dict(os.environ)
@@ -31,18 +36,20 @@ def test_two_ranks_share_one_gpu(tmp_path):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
-    assert line['n_gpus'] == 2 and line['collective_world_size'] == 2 and line['share_device'] is True
-    assert line['config']['global_batch'] == 32 and line['value'] > 0
+    assert line['n_gpus'] == world and line['collective_world_size'] == world and line['share_device'] is True
+    assert line['config']['global_batch'] == world * batch and line['value'] > 0
     pids = {r['pid'] for r in line['ranks']}
-    assert len(pids) == 2 and {r['device'] for r in line['ranks']} == {'cuda:0'}
-    assert 'NOT a scaling' in line['config']['parallelism']
+    assert len(pids) == world and {r['device'] for r in line['ranks']} == {'cuda:0'}
+    assert [r['rank'] for r in line['ranks']] == list(range(world))
+    assert 'NOT a scaling' in line['config']['parallelism'] and 'scaling_note' in line
     got = torch.load(dump)
-    assert got['rotation'].shape == (32, 3, 3) and got['translation'].shape == (32, 3)
+    assert got['rotation'].shape == (world * batch, 3, 3) and got['translation'].shape == (world * batch, 3)
+    assert got['seeds'] == [1000 + r for r in range(world)]
     # the same two shards in ONE process (each shard is its own batch: the pose head decodes a batch
     # with class label[0], pose_head.py:209-210, so the shards must not be merged)
     model, _ = bench.build_model(8, 'cuda:0')
     rots, trs = [], []
     for seed in got['seeds']:
-        outs = bench.run_step(model, bench.make_batch(16, seed, 'cuda:0'))
+        outs = bench.run_step(model, bench.make_batch(batch, seed, 'cuda:0'))
         rots.append(outs[2][-1].cpu()); trs.append(outs[3][-1].cpu())
     assert torch.equal(got['rotation'], torch.cat(rots)) and torch.equal(got['translation'], torch.cat(trs))

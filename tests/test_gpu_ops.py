@@ -458,6 +458,122 @@ def test_winograd_kernels_random_shapes(seed):
         assert err > 0.0, 'the two paths gave identical bits: the Winograd kernel did not run'
 
 
+# Winograd error scales with |input| and |weight|, not with |output|: the transforms add and subtract the RAW
+# operands (B^T d B scales by up to 4, F(2, 5)'s points 0, +-1, +-2, inf by up to 10; G by 1/2 ... 1/24) before
+# the products cancel.  N(0,1) operands hide that.  Stress operands: a DC offset far above
+# the signal (x = 50 + N(0,1)), post-ReLU |N(0,1)| activations, weights spread over three decades.  The budget is
+# stated in units of eps * sum|w||x| (eps = 2^-24: the forward error scale of ANY fp32 evaluation of the sum):
+#   direct kernels  measured <= 1.0   (an fma chain: ~sqrt(K) eps growth, K = Cin * taps)
+#   F(2x2, 3x3)     budget 8
+#   F(2, 5)         budget 24
+WINO_STRESS_OPERANDS = ['dc50', 'relu', 'wide_weights', 'dc50_wide']
+
+
+def _stress_operands(kind, shape_x, shape_w, seed):
+    x = rnd(shape_x, seed)
+    fan = shape_w[1] * shape_w[2] * shape_w[3]
+    wt = rnd(shape_w, seed + 1, (1.0 / fan) ** 0.5)
+    if kind in ('dc50', 'dc50_wide'):
+        x = x + 50.0
+    if kind == 'relu':
+        x = x.abs()
+    if kind in ('wide_weights', 'dc50_wide'):       # magnitudes log-uniform over 10^-1.5 ... 10^1.5 around the init scale
+        g = torch.Generator().manual_seed(seed + 2)
+        wt = wt * torch.pow(10.0, torch.rand(shape_w, generator=g) * 3.0 - 1.5)
+    return x, wt
+
+
+def _winograd_stress(kind, k, pad, n, cin, cout, H, W, budget, info0, seed):
+    import ctypes as C
+    x, wt = _stress_operands(kind, (n, cin, H, W), (cout, cin, *k), seed)
+    b = rnd((cout,), seed + 3, 0.1)
+    want = F.conv2d(x.double(), wt.double(), b.double(), padding=pad)
+    scale = F.conv2d(x.double().abs(), wt.double().abs(), b.double().abs(), padding=pad)     # sum |w||x| (+ |b|)
+    eps = 2.0 ** -24
+    pc = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), padding=pad)
+    assert (pc.wwino if k == (3, 3) else pc.wwino1d) is not None
+    lib = ops._lib.load()
+    xd = x.to(DEV)
+    prev = ops.set_conv_winograd(False)
+    try:
+        with ops.record_conv_kernels() as ran_d:
+            direct = ops.conv2d(pc, xd)
+        ops.set_conv_winograd(True)
+        with ops.record_conv_kernels() as ran_w:
+            got = ops.conv2d(pc, xd)
+    finally:
+        ops.set_conv_winograd(prev)
+    assert [kk for _, kk in ran_d] == ['direct-dma'], ran_d
+    assert [kk for _, kk in ran_w] == [info0], ran_w                   # the Winograd kernel really ran
+    r_dir = float(((direct.cpu().double() - want).abs() / (eps * scale)).max())
+    r_win = float(((got.cpu().double() - want).abs() / (eps * scale)).max())
+    r_rel = float(((got.cpu().double() - direct.cpu().double()).abs() / (eps * scale)).max())
+    print(f'[measured] {info0} {kind} {cin}->{cout} {k} @{H}x{W}: err / (eps sum|w||x|) = {r_win:.2f} '
+          f'(direct {r_dir:.2f}, winograd vs direct {r_rel:.2f}); max |out| {float(want.abs().max()):.1f}, '
+          f'max abs err {float((got.cpu().double() - want).abs().max()):.2e}')
+    assert r_dir <= 2.0, f'direct kernel {r_dir}'
+    assert r_win <= budget, f'{info0} on {kind}: {r_win} eps sum|w||x| > budget {budget}'
+    assert r_rel <= budget + 2.0
+
+
+@pytest.mark.parametrize('kind', WINO_STRESS_OPERANDS)
+@pytest.mark.parametrize('shape', [(4, 128, 512, 32, 32), (2, 64, 64, 128, 128), (8, 256, 192, 32, 32)])
+def test_conv2d_winograd_stress_operands(kind, shape):
+    """F(2x2, 3x3) vs torch fp64 AND vs the direct kernel on DC-offset / one-signed / wide-range operands,
+    tolerance relative to sum |w||x| (see above)."""
+    n, cin, cout, H, W = shape
+    _winograd_stress(kind, (3, 3), 1, n, cin, cout, H, W, budget=8.0, info0='winograd', seed=700 + cin)
+
+
+@pytest.mark.parametrize('kind', WINO_STRESS_OPERANDS)
+@pytest.mark.parametrize('shape', [(8, 256, 256, (1, 5), 32, 32), (8, 256, 128, (5, 1), 32, 32), (2, 256, 256, (5, 1), 60, 80)])
+def test_conv2d_winograd_1d_stress_operands(kind, shape):
+    """F(2, 5) (points 0, +-1, +-2, inf: the worse-conditioned of the two) on the same stress operands."""
+    n, cin, cout, k, H, W = shape
+    pad = (0, 2) if k == (1, 5) else (2, 0)
+    _winograd_stress(kind, k, pad, n, cin, cout, H, W, budget=24.0, info0='winograd F(2,5)', seed=800 + cout)
+
+
+def test_sepconv_gru_winograd_drift_12_iterations():
+    """configs[4]'s recurrence: 12 iterations of the SepConvGRU at (8, 60, 80) on the F(2, 5) kernel vs the direct
+    kernels from the same state, fresh motion features every iteration, post-ReLU (one-signed) context and motion
+    channels like the real network's.  The gates contract (|dh'| <= max(z, 1 - z) |dh| + ...), so the difference
+    must stay at round-off level instead of growing with the iteration count."""
+    from scflow_amd.modules import ConvGRU
+    torch.manual_seed(12)
+    n, h, w = 8, 60, 80
+    hc, cc, xc = 128, 128, 128
+    gru = ConvGRU(hc, cc + xc, 'SeqConv').to(DEV)
+    for prm in gru.parameters():
+        prm.data.mul_(1.5)
+    hx = rnd((n, hc + cc + xc, h, w), 195)
+    hx[:, :hc] = torch.tanh(hx[:, :hc])
+    hx[:, hc:] = torch.relu(hx[:, hc:] + 0.5)                      # context | motion features: post-ReLU, DC offset
+    hist = {}
+    for wino in (True, False):
+        prev = ops.set_conv_winograd(wino)
+        try:
+            gru.invalidate_packed()
+            a = hx.to(DEV)
+            ctx = gru.context_terms(a[:, hc:hc + cc])
+            states = []
+            with ops.record_conv_kernels() as ran:
+                for it in range(12):
+                    a[:, hc + cc:] = torch.relu(rnd((n, xc, h, w), 196 + it) + 0.5).to(DEV)
+                    gru.forward_inplace(a, ctx, cc)
+                    states.append(a[:, :hc].clone())
+            want_kind = 'winograd F(2,5)' if wino else 'direct-dma'
+            assert len(ran) == 48 and all(k == want_kind for _, k in ran), ran[:4]
+            hist[wino] = states
+        finally:
+            ops.set_conv_winograd(prev)
+    errs = [float((a_ - b_).abs().max()) for a_, b_ in zip(hist[True], hist[False])]
+    print('[measured] SepConvGRU F(2,5) vs direct, (8, 60, 80), max |dh| per iteration: ' + ' '.join(f'{e:.1e}' for e in errs))
+    assert errs[0] > 0.0
+    assert max(errs) <= 5e-5, errs
+    assert errs[-1] <= 4.0 * max(errs[:3]) + 1e-6, f'the difference grows with the iteration count: {errs}'
+
+
 def test_conv2d_dma_two_segments_gru_q():
     """the GRU candidate conv on the DMA kernel: two input segments, tanh gate epilogue."""
     n, h, w = 32, 32, 32

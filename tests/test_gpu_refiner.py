@@ -44,7 +44,7 @@ def model(golden_dir):
 
 
 @pytest.mark.parametrize('kind', ['IN', 'BN'])
-def test_encoder_golden(golden_dir, kind):
+def test_encoder_golden(golden_dir, kind, dispatch_check):
     g = _g(golden_dir, f'encoder_{kind}.npz')
     enc = build_from_cfg(dict(type='RAFTEncoder', in_channels=3, out_channels=256,
                               net_type='Basic', norm_cfg=dict(type=kind)), ENCODERS)
@@ -54,10 +54,13 @@ def test_encoder_golden(golden_dir, kind):
     enc.load_state_dict(sd, strict=True)
     enc = enc.to(DEV).eval()
     # tolerances here and below: <= 3x the error measured on the MI355X (gpurun r3b), not looser
-    close(enc(g['x'].to(DEV)), g['out'], atol={'IN': 6e-5, 'BN': 2e-5}[kind], what=f'encoder {kind}')
+    with ops.record_conv_kernels() as ran:
+        out = enc(g['x'].to(DEV))
+    dispatch_check(f'encoder_golden_{kind}', ran)
+    close(out, g['out'], atol={'IN': 6e-5, 'BN': 2e-5}[kind], what=f'encoder {kind}')
 
 
-def test_update_block_golden(golden_dir, model):
+def test_update_block_golden(golden_dir, model, dispatch_check):
     g = _g(golden_dir, 'update_block.npz')
     shapes = {k: v for k, v in _shapes(golden_dir).items()
               if k.startswith(('decoder.encoder.', 'decoder.gru.', 'decoder.flow_pred.',
@@ -67,12 +70,15 @@ def test_update_block_golden(golden_dir, model):
     dec.load_state_dict(sd, strict=False)
     dec = dec.to(DEV)
     corr, flow = g['corr'].to(DEV), g['flow'].to(DEV)
-    motion = dec.encoder(corr, flow)
+    with ops.record_conv_kernels() as ran:
+        motion = dec.encoder(corr, flow)
+        h_new = dec.gru(g['h'].to(DEV), torch.cat([g['cxt'].to(DEV), motion], 1))
+        d_flow, mask_logit = dec.flow_pred(h_new.contiguous()), dec.mask_pred(h_new.contiguous())
+    dispatch_check('update_block_golden', ran)
     close(motion, g['motion'], atol=8e-6, what='motion')
-    h_new = dec.gru(g['h'].to(DEV), torch.cat([g['cxt'].to(DEV), motion], 1))
     close(h_new, g['h_new'], atol=3e-6, what='gru')
-    close(dec.flow_pred(h_new.contiguous()), g['d_flow'], atol=2e-6, what='flow head')
-    close(dec.mask_pred(h_new.contiguous()), g['mask_logit'], atol=2e-6, what='mask head')
+    close(d_flow, g['d_flow'], atol=2e-6, what='flow head')
+    close(mask_logit, g['mask_logit'], atol=2e-6, what='mask head')
 
 
 def test_pose_head_golden_label_quirk(golden_dir):
@@ -90,7 +96,7 @@ def test_pose_head_golden_label_quirk(golden_dir):
     close(r5, g['rot_label5'], atol=5e-7, what='rot label 5')
 
 
-def test_full_refiner_golden(golden_dir, model):
+def test_full_refiner_golden(golden_dir, model, dispatch_check):
     """3 iterations, N=3 mixed labels, 256x256: against the reference's own output."""
     g = _g(golden_dir, 'refiner_full.npz')
     inp = {k: v.to(DEV) for k, v in scflow_amd.make_inputs(int(g['n']), 256, 256,
@@ -101,8 +107,10 @@ def test_full_refiner_golden(golden_dir, model):
     close(hf[:, ::8], g['h_feat'], atol=2.5e-5, what='h_feat')
     close(cf[:, ::8], g['cxt_feat'], atol=2e-5, what='cxt_feat')
     model.decoder.iters = int(g['iters'])
-    outs = model.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'],
-                          inp['ref_translation'], inp['depth'], inp['internel_k'], inp['label'])
+    with ops.record_conv_kernels() as ran:
+        outs = model.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'],
+                              inp['ref_translation'], inp['depth'], inp['internel_k'], inp['label'])
+    dispatch_check('full_refiner_golden_n3', ran)       # N=3: which layers are on the Winograd kernels is pinned
     names = ['flow_from_pose', 'flow_from_pred', 'rotation', 'translation', 'mask',
              'delta_rotation', 'delta_translation']
     # measured (px, px, -, mm, -, -, -): 9.2e-5, 8.0e-5, 1.8e-7, 3.1e-4, 2.0e-6, 1.2e-7, 2.6e-7
@@ -176,7 +184,7 @@ def test_full_refiner_vs_oracle_epe(golden_dir, model, n, iters):
     assert float((got[0][-1].cpu()[:, :, ~valid[0]] if n == 1 else torch.zeros(1)).abs().max()) == 0.0
 
 
-def test_config2_full_size_vs_oracle(golden_dir, model):
+def test_config2_full_size_vs_oracle(golden_dir, model, dispatch_check):
     """BASELINE configs[2] at its STATED size: 32 pairs x 8 iterations, every pair against the CPU
     oracle (batch 32 selects other convolution tiles / K splits than the N = 1, 2 cases above).
     Mixed labels: the whole batch is decoded with class label[0] (pose_head.py:209-210), in the
@@ -192,8 +200,10 @@ def test_config2_full_size_vs_oracle(golden_dir, model):
                                inp['label'], sd, iters=iters)
     model.decoder.iters = iters
     d = {k: v.to(DEV) for k, v in inp.items()}
-    got = model.get_pose(d['render_images'], d['real_images'], d['ref_rotation'],
-                         d['ref_translation'], d['depth'], d['internel_k'], d['label'])
+    with ops.record_conv_kernels() as ran:
+        got = model.get_pose(d['render_images'], d['real_images'], d['ref_rotation'],
+                             d['ref_translation'], d['depth'], d['internel_k'], d['label'])
+    dispatch_check('config2_batch32', ran)
     valid = inp['depth'] > 0
     worst = 0.0
     for it in range(iters):

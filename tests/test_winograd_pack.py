@@ -10,6 +10,55 @@ import torch
 from scflow_amd import _lib, ops
 
 
+# independent restatement of the two packings (torch, fp64 einsum) -- the product packs through the C entry points
+def _ref_pack_wino(weight):
+    """(Cout, Cin, 3, 3) -> U = G g G^T in conv_wino.hip's layout (scf_pack_conv_weight_wino):
+    [chunk][Cout / 32][4 i' + j][channel & 1][Cout % 32][channel >> 1 & 1] with the rows i of the transform
+    domain stored in the order i' -> 0, 1, 3, 2 (conv_wino.hip gives each of the two rows-halves one wave), 4 channels per chunk,
+    computed in double and rounded once; zero padded."""
+    cout, cin, kh, kw = weight.shape
+    if (kh, kw) != (3, 3):
+        raise ValueError('Winograd packing: 3x3 kernels')
+    g = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]],
+                     dtype=torch.float64, device=weight.device)
+    u = torch.einsum('ia,ocab,jb->ijoc', g, weight.double(), g)[[0, 1, 3, 2]].reshape(16, cout, cin)   # rows stored 0, 1, 3, 2
+    f, nchunk = (cout + 31) // 32, (cin + 3) // 4
+    full = torch.zeros((16, f * 32, nchunk * 4), dtype=torch.float64, device=weight.device)
+    full[:, :cout, :cin] = u
+    # [xi][frag][m][chunk][s][kh] -> [chunk][frag][xi][kh][m][s]
+    full = full.reshape(16, f, 32, nchunk, 2, 2).permute(3, 1, 0, 5, 2, 4)
+    return full.contiguous().float().reshape(-1)
+
+
+def _ref_pack_wino1d(weight):
+    """(Cout, Cin, 1, 5) or (Cout, Cin, 5, 1) -> U = G g in conv_wino1d.hip's layout (scf_pack_conv_weight_wino1d):
+    [chunk][Cout / 32][position i][channel & 1][Cout % 32][channel >> 1 & 3], 8 channels per chunk; G = the 6 x 5
+    matrix of the points 0, 1, -1, 2, -2, infinity; computed in double and rounded once; zero padded."""
+    cout, cin, kh, kw = weight.shape
+    if (kh, kw) not in ((1, 5), (5, 1)):
+        raise ValueError('F(2, 5) packing: 1x5 / 5x1 kernels')
+    pts = [0.0, 1.0, -1.0, 2.0, -2.0]
+    g = torch.zeros((6, 5), dtype=torch.float64)
+    for i, a in enumerate(pts):
+        nrm = 1.0
+        for k, b in enumerate(pts):
+            if k != i:
+                nrm *= a - b
+        g[i] = torch.tensor([a ** k / nrm for k in range(5)], dtype=torch.float64)
+    g[5, 4] = 1.0
+    wd = weight.reshape(cout, cin, 5).double()
+    g = g.to(weight.device)
+    u = torch.zeros((6, cout, cin), dtype=torch.float64, device=weight.device)
+    for k in range(5):                   # the C packer's order of adds: bit-identical packings
+        u = u + g[:, k, None, None] * wd[None, :, :, k]
+    f, nchunk = (cout + 31) // 32, (cin + 7) // 8
+    full = torch.zeros((6, f * 32, nchunk * 8), dtype=torch.float64, device=weight.device)
+    full[:, :cout, :cin] = u
+    # [i][frag][m][chunk][s][kh] -> [chunk][frag][i][kh][m][s]
+    full = full.reshape(6, f, 32, nchunk, 4, 2).permute(3, 1, 0, 5, 2, 4)
+    return full.contiguous().float().reshape(-1)
+
+
 @pytest.fixture(scope='module')
 def lib():
     return _lib.load()
@@ -35,7 +84,8 @@ def test_wino2d_packing_reproduces_the_convolution(lib):
     assert n == ((cin + 3) // 4) * 2 * 16 * 128
     host = torch.empty(n)
     assert lib.scf_pack_conv_weight_wino(w.data_ptr(), cout, cin, host.data_ptr()) == 0
-    assert torch.equal(host, ops.pack_conv_weight_wino(w))           # the torch packer: bit-identical
+    assert torch.equal(host, _ref_pack_wino(w))           # the torch restatement: bit-identical
+    assert torch.equal(host, ops.pack_conv_weight_wino(w))   # what PackedConv uses = the C packer
     u, full = _unpack(host.numpy().astype(np.float64), 16, cout, cin, 4)
     assert np.all(full[:, cout:, :] == 0) and np.all(full[:, :, cin:] == 0)      # zero padding
     # storage rows of the transform domain: 0, 1, 3, 2
@@ -67,6 +117,7 @@ def test_wino1d_packing_reproduces_the_convolution(lib):
     host = torch.empty(n)
     taps = w.reshape(cout, cin, 5).contiguous()
     assert lib.scf_pack_conv_weight_wino1d(taps.data_ptr(), cout, cin, host.data_ptr()) == 0
+    assert torch.equal(host, _ref_pack_wino1d(w))
     assert torch.equal(host, ops.pack_conv_weight_wino1d(w))
     assert torch.equal(host, ops.pack_conv_weight_wino1d(w.reshape(cout, cin, 5, 1)))     # 5x1: the same taps
     u, full = _unpack(host.numpy().astype(np.float64), 6, cout, cin, 8)

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun): tools/gpu_suite.sh <tag> <stage> [<stage> ...]; everything lands in gpurun_out/<tag>/.
+#   tests      the whole -m gpu suite (checks the pinned dispatch plan)
+#   plan       the -m gpu suite with SCF_WRITE_DISPATCH_PLAN=1 (records gpurun_out/dispatch_plan.json), then re-checks
+#              the parity tests that carry a plan against the freshly recorded one
+#   measured   the tests that print [measured] lines (Winograd stress, GRU drift, configs[2]/[4]) with -s
+#   smoke      __graft_entry__.smoke()
+#   bench      python bench.py (defaults)
+#   profiles   tools/collect_profiles.sh <tag> + the batch-32-only kernel trace
+set -u
+TAG=$1; shift
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd $R
+for stage in "$@"; do
+  case $stage in
+    tests)
+      timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 > $OUT/tests.log; tail -5 $OUT/tests.log ;;
+    plan)
+      rm -f $R/gpurun_out/dispatch_plan.json
+      SCF_WRITE_DISPATCH_PLAN=1 timeout 3000 python -m pytest tests -m gpu -q 2>&1 | tail -60 > $OUT/tests_plan.log; tail -15 $OUT/tests_plan.log
+      cp $R/gpurun_out/dispatch_plan.json $R/tests/golden/dispatch_plan.json
+      timeout 1200 python -m pytest tests/test_gpu_refiner.py tests/test_next_rows.py -m gpu -q -k "golden or config2 or config4" 2>&1 | tail -5 > $OUT/tests_plan_check.log; tail -3 $OUT/tests_plan_check.log ;;
+    measured)
+      timeout 1800 python -m pytest tests -m gpu -q -s -k "stress or drift or config2 or config4_full or winograd" 2>&1 | grep -a "measured\|passed\|failed\|Error\|assert" > $OUT/measured.log; tail -60 $OUT/measured.log ;;
+    smoke)
+      timeout 600 python __graft_entry__.py smoke 2>&1 | tail -3 | tee $OUT/smoke.log ;;
+    bench)
+      timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 1500 $OUT/bench.json; tail -3 $OUT/bench.err ;;
+    profiles)
+      bash tools/collect_profiles.sh $TAG > $OUT/collect.log 2>&1; tail -5 $OUT/collect.log
+      bash tools/lab/b32_profile.sh $TAG > $OUT/b32_profile.log 2>&1; tail -3 $OUT/b32_profile.log ;;
+    *) echo "unknown stage $stage" ;;
+  esac
+done

@@ -4,12 +4,12 @@
 set -e
 cd "$(dirname "$0")/../../scflow_amd/csrc"
 O=/tmp/scf_exp_obj_base; mkdir -p $O
-for f in capi corr_lookup corr_gemm conv_mfma conv_f16x3 conv_dma conv_thin conv_taps conv_wino1d resample pose norm scflow_iter; do
-  [ $O/$f.o -nt $f.hip ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -c $f.hip -o $O/$f.o &
+for f in capi corr_lookup corr_gemm conv_mfma conv_f16x3 conv_dma conv_thin conv_taps conv_wino1d resample pose norm metrics scflow_iter; do
+  [ $O/$f.o -nt $f.hip ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I../../tools/lab -c $f.hip -o $O/$f.o &
 done
 wait
 for m in $1; do
-  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-slp-vectorize -DSCF_WINO_LAB -DSCF_WINO_LAB_MASK=$m -c conv_wino.hip -o /tmp/scf_wino_m$m.o &&
+  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I../../tools/lab -fno-slp-vectorize -DSCF_WINO_LAB -DSCF_WINO_LAB_MASK=$m -c conv_wino.hip -o /tmp/scf_wino_m$m.o &&
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $O/*.o /tmp/scf_wino_m$m.o -o ../../tools/lab/bin/libscflow_hip_exp_m$m.so ) &
 done
 wait

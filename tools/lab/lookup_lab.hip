@@ -1,5 +1,5 @@
 // Stand-alone laboratory for the correlation-lookup kernel (not part of the product).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/lab/lookup_lab.hip -o tools/lab/bin/lookup_lab
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Itools/lab tools/lab/lookup_lab.hip -o tools/lab/bin/lookup_lab
 // Compiles the PRODUCT kernel source with SCF_LOOKUP_LAB (lookup_lab_hooks.h: s_memrealtime stamps per
 // wave + two ablation switches) and times it against streaming ceilings on a pyramid that cannot sit in the
 // 256 MiB Infinity Cache (two batch-B halves used alternately + a 1 GiB flush between launches).
