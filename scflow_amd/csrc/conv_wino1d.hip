@@ -8,7 +8,8 @@
 //     positions = 96 accumulator registers: the output transform is lane-local, no pair exchange;
 //   * a block = 2 channel fragments x 2 tile groups (the copy of a U chunk serves two waves, the copy of a patch
 //     chunk two); 8 channels per chunk: one ds_read_b128 per position feeds four k-steps, 24 MFMAs per barrier;
-//   * the input transform is 12 fmas per window (4 windows per lane and chunk = 2 vector instructions per MFMA);
+//   * the input transform is 6 packed fmas per window (4 windows per lane and chunk = 1 vector instruction per MFMA;
+//     r4: was 12 scalar fmas);
 //   * after the output transform a lane holds 16 channel rows of two pixels -- exactly two accumulator
 //     fragments of the direct kernels, so the shared fused epilogue (conv_kernels.h) finishes them: bias, BN,
 //     residual, activations, both GRU gates with the hoisted context term.
@@ -159,24 +160,37 @@ void conv_wino1d_kernel(ConvK p, Wino1K q) {
     const int off = VERT ? 2 * ty * q.PWp + tx : ty * q.PWp + 2 * tx + (PX4 ? 2 : 0);
     prow[s] = p_lds + (unsigned)(((2 * s + half) * q.PPL + off) * 4);
   }
-  float dw[4][6];
+  // The transform runs on PACKED fp32 pairs (r4): vector-ALU instructions of either co-resident wave cost
+  // matrix-pipe time on their SIMD (conv_wino.hip), and the scalar form was 12 fmas per window = 2 per MFMA.
+  // With the window held as the pairs P01 = (d0, d1), P23 = (d2, d3), P45 = (d4, d5) -- exactly what the three
+  // ds_read_b64 of a horizontal window return -- six v_pk_fma_f32 give all six positions, each fma the one the
+  // scalar form evaluated (same operands, same order: identical bits):
+  //     (r0, r5) = 4 P01 + (-5 P23 + P45)
+  //     T = (t1, t3) = (-4, -1) (d2, d2) + (d4, d4)        S = (t2, sd) = (-4, -1) (d1, d1) + (d3, d3)
+  //     (r1, r3) = (1, 2) S + T                             (r2, r4) = (-1, -2) S + T
+  // The op_sel forms (both result halves from the same half of an operand) are written in asm; an MFMA takes its
+  // B operand from either half of a result pair directly, so nothing is moved.
+  w1_f32x2 dwp[4][3];
   auto win_load = [&](unsigned slot_bytes, int s) {
     const __attribute__((address_space(3))) float* r =
         (const __attribute__((address_space(3))) float*)(uintptr_t)(prow[s] + slot_bytes);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) dw[s][i] = VERT ? r[i * 32] : r[i];       // vertical: pitch 32 floats
+    for (int i = 0; i < 3; ++i)       // vertical: pitch 32 floats
+      dwp[s][i] = VERT ? w1_f32x2{r[(2 * i) * 32], r[(2 * i + 1) * 32]} : w1_f32x2{r[2 * i], r[2 * i + 1]};
   };
-  auto win_transform = [&](w1_f32x4 (&bo)[6], int s) {
-    const float (&d)[6] = dw[s];
-    const float t1 = __builtin_fmaf(-4.f, d[2], d[4]), t2 = __builtin_fmaf(-4.f, d[1], d[3]);
-    const float t3 = d[4] - d[2], sd = d[3] - d[1];
-    bo[0][s] = __builtin_fmaf(4.f, d[0], __builtin_fmaf(-5.f, d[2], d[4]));
-    bo[1][s] = t1 + t2;
-    bo[2][s] = t1 - t2;
-    bo[3][s] = __builtin_fmaf(2.f, sd, t3);
-    bo[4][s] = __builtin_fmaf(-2.f, sd, t3);
-    bo[5][s] = __builtin_fmaf(4.f, d[1], __builtin_fmaf(-5.f, d[3], d[5]));
+  const w1_f32x2 k_4 = {4.f, 4.f}, k_m5 = {-5.f, -5.f}, k_m4m1 = {-4.f, -1.f}, k_12 = {1.f, 2.f}, k_m12 = {-1.f, -2.f};
+  auto win_transform = [&](w1_f32x2 (&bo)[4][3], int s) {      // -> bo[s] = {(r0, r5), (r1, r3), (r2, r4)}
+    const w1_f32x2 (&d)[3] = dwp[s];
+    w1_f32x2 in, T, S;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(in) : "v"(k_m5), "v"(d[1]), "v"(d[2]));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(bo[s][0]) : "v"(k_4), "v"(d[0]), "v"(in));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(T) : "v"(k_m4m1), "v"(d[1]), "v"(d[2]));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "=v"(S) : "v"(k_m4m1), "v"(d[0]), "v"(d[1]));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(bo[s][1]) : "v"(k_12), "v"(S), "v"(T));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(bo[s][2]) : "v"(k_m12), "v"(S), "v"(T));
   };
+// B operand of position X, k-step S
+#define W1_B(b, X, S) ((X) == 0 ? b[S][0][0] : (X) == 5 ? b[S][0][1] : (X) == 1 ? b[S][1][0] : (X) == 3 ? b[S][1][1] : (X) == 2 ? b[S][2][0] : b[S][2][1])
 
   w1_f32x16 acc[6];
 #pragma unroll
@@ -214,7 +228,8 @@ void conv_wino1d_kernel(ConvK p, Wino1K q) {
   scf_wait_vmcnt_imm<GRP>();
   __syncthreads();
   const float* ua = Us + cw * W1_UF + lane * 4;                        // + position * 256
-  w1_f32x4 a0[6], b0[6], a1[6], b1[6];
+  w1_f32x4 a0[6], a1[6];
+  w1_f32x2 b0[4][3], b1[4][3];
 #pragma unroll
   for (int x = 0; x < 6; ++x) a0[x] = *reinterpret_cast<const w1_f32x4*>(ua + x * 256);
 #pragma unroll
@@ -225,13 +240,13 @@ void conv_wino1d_kernel(ConvK p, Wino1K q) {
   // (patch) under its MFMAs; the copies of the chunk three ahead are issued, those two ahead must have landed
   // at its end.  The MFMAs go first, everything else sits between them in the order its results are needed.
   int s1 = 1;                          // ring slot of the next chunk
-  auto chunk = [&](const w1_f32x4 (&a)[6], const w1_f32x4 (&b)[6], w1_f32x4 (&an)[6], w1_f32x4 (&bn)[6]) {
+  auto chunk = [&](const w1_f32x4 (&a)[6], const w1_f32x2 (&b)[4][3], w1_f32x4 (&an)[6], w1_f32x2 (&bn)[4][3]) {
     const float* uc = ua + s1 * USLOT;
     const unsigned pcb = (unsigned)(s1 * PSLOT * 4);
     int s3 = s1 + 2;                   // ring slot of the chunk three ahead
     s3 = s3 >= 3 ? s3 - 3 : s3;
 #define W1_M(X, S)                                                                              \
-    acc[X] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[X][S], b[X][S], acc[X], 0, 0, 0);           \
+    acc[X] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[X][S], W1_B(b, X, S), acc[X], 0, 0, 0);     \
     __builtin_amdgcn_sched_barrier(0);
     W1_M(0, 0) win_load(pcb, 0); __builtin_amdgcn_sched_barrier(0);
     W1_M(1, 0) win_load(pcb, 1); __builtin_amdgcn_sched_barrier(0);

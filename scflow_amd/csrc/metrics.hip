@@ -31,6 +31,10 @@ struct EpeK {
 
 __global__ __launch_bounds__(EPE_THREADS)
 void cal_epe_partial_kernel(EpeK k, unsigned long long* ws) {
+  // every operation below is the separately rounded fp32 operation torch performs: no fma contraction, and sqrtf /
+  // the divisions are the correctly rounded ones (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt; the
+  // __fsqrt_rn / __fdiv_rn intrinsics are the 1-ulp NATIVE instructions in this toolchain and must not be used)
+#pragma clang fp contract(off)
   const int n = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
   const float* tx = k.tgt + (long long)n * 2 * k.HW;
   const float* ty = tx + k.HW;
@@ -48,12 +52,12 @@ void cal_epe_partial_kernel(EpeK k, unsigned long long* ws) {
     const int p = p0 + i;
     if (p >= k.HW) break;
     const float a = tx[p], c = ty[p];
-    const float mag = __fsqrt_rn(__fadd_rn(__fmul_rn(a, a), __fmul_rn(c, c)));
-    const float dx = __fsub_rn(a, px[p]), dy = __fsub_rn(c, py[p]);
-    const float err = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+    const float mag = sqrtf(a * a + c * c);          // contraction is off in this function: mul, mul, add, sqrt
+    const float dx = a - px[p], dy = c - py[p];
+    const float err = sqrtf(dx * dx + dy * dy);
     bool valid = mag < k.max_flow;
     if (mk) valid = valid && (mk[p] >= 0.5f);
-    const float ev = __fmul_rn(err, valid ? 1.0f : 0.0f);          // NaN * 0 stays NaN, as in torch
+    const float ev = err * (valid ? 1.0f : 0.0f);                  // NaN * 0 stays NaN, as in torch
     if (em) em[p] = ev;
     sum += (double)ev;
     cv += valid ? 1u : 0u;
@@ -104,6 +108,7 @@ void cal_epe_partial_kernel(EpeK k, unsigned long long* ws) {
 // (sample, block) order for 'total_mean' (an evaluation batch: tens to thousands of samples x <= a few hundred blocks)
 __global__ void cal_epe_final_kernel(const unsigned long long* ws, int N, int bps, int nthr, int fix_quirk,
                                      float* mean, float* ratios, float* total_mean, float* total_ratios) {
+#pragma clang fp contract(off)
   if (mean || ratios) {
     for (int n = (int)threadIdx.x; n < N; n += (int)blockDim.x) {
       double s = 0.0;
@@ -114,12 +119,12 @@ __global__ void cal_epe_final_kernel(const unsigned long long* ws, int N, int bp
         s += __longlong_as_double((long long)o[0]);
         for (int j = 0; j < 1 + 2 * EPE_MAX_THR; ++j) c[j] += o[1 + j];
       }
-      const float total = __fadd_rn((float)(long long)c[0], 1e-10f);
-      if (mean) mean[n] = __fdiv_rn((float)s, total);
+      const float total = ((float)(long long)c[0] + 1e-10f);
+      if (mean) mean[n] = ((float)s / total);
       if (ratios)
         for (int t = 0; t < nthr; ++t)
           ratios[(long long)t * N + n] =
-              __fdiv_rn((float)(long long)(fix_quirk ? c[1 + t] : c[1 + EPE_MAX_THR + t]), total);
+              ((float)(long long)(fix_quirk ? c[1 + t] : c[1 + EPE_MAX_THR + t]) / total);
     }
   }
   if ((total_mean || total_ratios) && threadIdx.x == 0) {
@@ -131,10 +136,10 @@ __global__ void cal_epe_final_kernel(const unsigned long long* ws, int N, int bp
       s += __longlong_as_double((long long)o[0]);
       for (int j = 0; j < 1 + EPE_MAX_THR; ++j) c[j] += o[1 + j];
     }
-    const float total = __fadd_rn((float)(long long)c[0], 1e-10f);
-    if (total_mean) total_mean[0] = __fdiv_rn((float)s, total);
+    const float total = ((float)(long long)c[0] + 1e-10f);
+    if (total_mean) total_mean[0] = ((float)s / total);
     if (total_ratios)
-      for (int t = 0; t < nthr; ++t) total_ratios[t] = __fdiv_rn((float)(long long)c[1 + t], total);
+      for (int t = 0; t < nthr; ++t) total_ratios[t] = ((float)(long long)c[1 + t] / total);
   }
 }
 
