@@ -40,12 +40,14 @@ int scf_conv2d_query(const scf_conv_desc* desc, int32_t* info);
 enum {
   SCF_KERNEL_THIN = 1,        /* conv_thin_kernel: Cout <= 4, vector ALU                           */
   SCF_KERNEL_TAPS = 2,        /* conv_taps_kernel: Cin <= 4, contraction over taps                 */
-  SCF_KERNEL_WINO = 3,        /* conv_wino_kernel: Winograd F(2x2, 3x3)                            */
+  SCF_KERNEL_WINO = 3,        /* conv_wino_kernel: Winograd F(2x2, 3x3), wave pair per fragment    */
   SCF_KERNEL_WINO1D = 4,      /* conv_wino1d_kernel: Winograd F(2, 5)                              */
   SCF_KERNEL_F16X3 = 5,       /* conv_f16x3_kernel: split-fp16 3xMFMA                              */
   SCF_KERNEL_DMA = 6,         /* conv_dma_kernel: direct, LDS-DMA staged (pixel-split or K-split)  */
   SCF_KERNEL_MFMA = 7,        /* conv_mfma_kernel: direct, register staged                         */
-  SCF_KERNEL_MFMA_KSPLIT = 8  /* conv_mfma_ksplit_kernel                                           */
+  SCF_KERNEL_MFMA_KSPLIT = 8, /* conv_mfma_ksplit_kernel                                           */
+  SCF_KERNEL_WINO_Q = 9       /* conv_wino_q_kernel: Winograd F(2x2, 3x3), one transform row x two channel
+                                 fragments per wave (even fragment counts)                           */
 };
 typedef struct scf_conv_log_entry {
   int32_t kernel;             /* SCF_KERNEL_*                                                      */
@@ -53,6 +55,12 @@ typedef struct scf_conv_log_entry {
   int32_t mode;               /* SCF_CONV_*                                                        */
 } scf_conv_log_entry;
 int scf_conv_log_enable(int capacity);
+/* measurement knobs (A/B runs of kernel variants from bench.py / tools): returns the previous value, or
+ * SCF_EINVAL for an unknown key.  0 always means "the dispatch's own choice". */
+enum {
+  SCF_TUNE_WINO_VARIANT = 1   /* F(2x2,3x3): 1 = pair kernel, 2 / 3 = quarter-domain kernel with 4 / 8 waves */
+};
+int scf_tune(int key, int value);
 int scf_conv_log_read(scf_conv_log_entry* out, int max_entries);
 
 #ifdef __cplusplus

@@ -76,7 +76,7 @@ class ConvLogEntry(C.Structure):
 
 
 KERNEL_NAMES = {1: 'thin', 2: 'taps', 3: 'winograd', 4: 'winograd F(2,5)', 5: 'f16x3', 6: 'direct-dma',
-                7: 'direct-mfma', 8: 'direct-mfma-ksplit'}
+                7: 'direct-mfma', 8: 'direct-mfma-ksplit', 9: 'winograd-q'}
 
 
 class IterGN(C.Structure):
@@ -142,6 +142,7 @@ SIGNATURES = {
     'scf_timer_elapsed_us': (C.c_int, [_fp, C.POINTER(C.c_float)]),
     'scf_conv2d': (C.c_int, [C.POINTER(ConvDesc), _fp]),
     'scf_conv2d_query': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int32)]),
+    'scf_tune': (C.c_int, [C.c_int, C.c_int]),
     'scf_conv_log_enable': (C.c_int, [C.c_int]),
     'scf_conv_log_read': (C.c_int, [C.POINTER(ConvLogEntry), C.c_int]),
     'scf_pack_conv_weight_size': (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

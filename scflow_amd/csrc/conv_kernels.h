@@ -360,7 +360,7 @@ int scf_conv_f16x3_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t
 int scf_conv_taps_dispatch(ConvK k, const float* wt, int N, bool dry_run, int* info, hipStream_t st);
 // conv_wino.hip: 3x3 / stride-1 / pad-1 layers with an affine epilogue in the Winograd F(2x2, 3x3) form
 // (wu = the G g G^T packing).  info: {16, fragments per block, blocks, LDS bytes}.
-int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* info, hipStream_t st);
+int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* info, hipStream_t st, int* which = nullptr);
 // conv_wino1d.hip: 1x5 / 5x1 stride-1 'same' layers, any epilogue kind, in the Winograd F(2, 5) form (wu = the G g packing).
 int scf_conv_wino1d_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* info, hipStream_t st);
 // conv_thin.hip: Cout <= 4 layers on the vector ALUs.

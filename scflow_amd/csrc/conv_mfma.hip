@@ -559,8 +559,9 @@ static int conv2d_launch(const scf_conv_desc* d, scf_stream_t stream, int* which
     if (rp != SCF_EUNSUPPORTED) return rp;
   }
   if (d->wp_wino) {
-    *which = SCF_KERNEL_WINO;
-    const int rw = scf_conv_wino_dispatch(pl.k, d->wp_wino, d->N, false, nullptr, scf_stream(stream));
+    int quarter = 0;
+    const int rw = scf_conv_wino_dispatch(pl.k, d->wp_wino, d->N, false, nullptr, scf_stream(stream), &quarter);
+    *which = quarter ? SCF_KERNEL_WINO_Q : SCF_KERNEL_WINO;
     if (rw != SCF_EUNSUPPORTED) return rw;
   }
   if (d->wp_wino1d) {
@@ -603,6 +604,13 @@ namespace {
 std::mutex g_log_mu;
 std::vector<scf_conv_log_entry> g_log;
 std::atomic<int> g_log_cap{0};
+}
+
+int scf_wino_variant_set(int v);      // conv_wino.hip
+
+extern "C" int scf_tune(int key, int value) {
+  if (key == SCF_TUNE_WINO_VARIANT) return scf_wino_variant_set(value);
+  return SCF_EINVAL;
 }
 
 extern "C" int scf_conv_log_enable(int capacity) {

@@ -46,6 +46,9 @@ typedef float wn_f32x2 __attribute__((ext_vector_type(2)));
 // slot's padding): 16-byte cells (256 cells per block-instruction) when the rows are 16-byte aligned, else dwords
 #define WN_NPI(TW, PX4) ((PX4) ? ((TW) == 2 ? 3 : 2) : ((TW) == 2 ? 8 : 5))
 #define WN_KC 4             // channels per chunk
+#ifndef SCF_WINO_DEFAULT_VARIANT
+#define SCF_WINO_DEFAULT_VARIANT 2      // 1 = pair kernel, 2 = quarter-domain kernel (4 waves); 3 = its 8-wave form, lab builds only
+#endif
 
 // tools/lab/wino_phases.py builds this file with compile-time phase ablations (tools/lab/wino_lab_hooks.h,
 // -DSCF_WINO_LAB -DSCF_WINO_LAB_MASK=m); the product build sees constants
@@ -284,8 +287,10 @@ void conv_wino_kernel(ConvK p, WinoK q) {
     if (!WN_LAB(2)) issue_p(s3);
     __builtin_amdgcn_sched_barrier(0);
     WN_M(4, 0)
+    if (!WN_LAB(5)) {
 #pragma unroll
-    for (int x = 0; x < 8; ++x) an[x] = *reinterpret_cast<const wn_f32x2*>(uc + x * 128);
+      for (int x = 0; x < 8; ++x) an[x] = *reinterpret_cast<const wn_f32x2*>(uc + x * 128);
+    }
     __builtin_amdgcn_sched_barrier(0);
     WN_M(5, 0)
     if (!WN_LAB(1)) win_transform(bn, 0);
@@ -379,6 +384,302 @@ void conv_wino_kernel(ConvK p, WinoK q) {
   }
 }
 
+// ===================================================================================================
+// Quarter-domain kernel (r4): one computed B operand feeds TWO output-channel fragments.
+//
+// In the pair kernel above every MFMA has its own B operand: a wave holds 8 transform positions of ONE channel
+// fragment, so the input transform (16 packed adds per chunk) is paid once per fragment -- a 128 -> 512 layer
+// transforms every patch 16 times -- and vector-ALU instructions cost matrix-pipe time here (see above).  In this
+// kernel a wave holds ONE ROW of the transform domain (4 positions) for TWO channel fragments = the same 128
+// accumulator registers: 16 MFMAs per chunk again, but only 8 packed instructions of transform (one fma per
+// column pair for the row stage, two adds for the column stage, per channel) and 8 instead of 12 window reads.
+//   block   4 TW waves: wave = (tile group tw, storage row of the transform domain); 2 channel fragments x TW
+//           tile groups.  TW = 1: 256 threads, two blocks per CU (as above).  TW = 2: 512 threads, one block per
+//           CU, the U chunk (16 KB) serves both tile groups: least L2 -> LDS traffic per MFMA.
+//   rows    storage rows 0, 1, 2, 3 = transform rows 0, 1, 3, 2 (the packing's order): B^T d row = e_a + sigma e_b
+//           with (a, b, sigma) = (0, 2, -), (1, 2, +), (1, 3, -), (2, 1, -): one packed fma per column pair.
+//   output  A^T M A: the column transform is lane-local (2 values per accumulator row), the row sums need all four
+//           waves: each wave finishes 8 of the 32 (fragment, row) combinations of its tile group and passes the
+//           other 24 pairs through LDS (12 b128 writes, 12 reads); sums in the fixed order (t0 + t1) + t2,
+//           (t1 - t2) - t3.
+// Needs an even number of channel fragments (the dispatch keeps other layers on the pair kernel).
+// ===================================================================================================
+#define WQ_NPI(TW, PX4) ((PX4) ? 1 : ((TW) == 2 ? 3 : 4))
+
+template <int TW, bool PX4>
+__global__ __launch_bounds__(256 * TW, TW == 1 ? 2 : 1)
+void conv_wino_q_kernel(ConvK p, WinoK q) {
+  extern __shared__ __attribute__((aligned(16))) float wn_lds[];
+  constexpr int NW = 4 * TW, NT = 64 * NW;                      // waves, threads
+  constexpr int CW = 2;
+  constexpr int USLOT = CW * 2048;                              // floats per ring slot
+  constexpr int NUI = 16 / NW;                                  // U copy instructions (1 KB each) per wave per chunk
+  constexpr int NPI = WQ_NPI(TW, PX4);
+  constexpr int PSLOT = NPI * NT * (PX4 ? 4 : 1);
+  constexpr int GRP = NUI + NPI;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tw = TW == 2 ? wave >> 2 : 0, row = wave & 3;
+  const int half = lane >> 5, l32 = lane & 31;
+
+  int lb = scf_xcd_remap(blockIdx.x, gridDim.x);
+  const int mb = __builtin_amdgcn_readfirstlane(lb % q.mblocks);
+  lb /= q.mblocks;
+  const int xs = __builtin_amdgcn_readfirstlane(lb % q.sx);
+  lb /= q.sx;
+  const int ys = __builtin_amdgcn_readfirstlane(lb % q.sy);
+  const int n = __builtin_amdgcn_readfirstlane(lb / q.sy);
+  const int TXW = 1 << q.txl, TYW = 32 >> q.txl;
+  const int y0 = ys * (2 * TW * TYW), x0 = xs * (2 * TXW);
+  const int f0 = mb * CW;
+  const int HW = p.H * p.W;
+
+  float* Us = wn_lds;
+  float* Ps = Us + 3 * USLOT;
+  const unsigned u_lds = scf_lds_addr(Us), p_lds = scf_lds_addr(Ps);
+
+  // ---- chunk-invariant copy offsets (as in the pair kernel) ----
+  unsigned pvo[NPI];
+  {
+    const int NC = PX4 ? q.PWp >> 2 : q.PWp, PPC = q.PH * NC;
+    const float rPPC = 1.0f / (float)PPC, rNC = 1.0f / (float)NC;
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+      const int e = i * NT + tid;
+      const int c = wn_div(e, PPC, rPPC), r = e - c * PPC;
+      const int py = wn_div(r, NC, rNC), px = r - py * NC;
+      const int iy = y0 - 1 + py, ix = PX4 ? x0 - 4 + 4 * px : x0 - 1 + px;
+      const bool ok = c < WN_KC && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && (PX4 || px < q.PW);
+      pvo[i] = ok ? (unsigned)((c * HW + iy * p.W + ix) * 4) : SCF_BUF_OOB;
+    }
+  }
+  unsigned uvo[NUI], uld[NUI];
+#pragma unroll
+  for (int i = 0; i < NUI; ++i) {               // the block's two fragments: 2 x 8 KB per chunk, 16 pieces of 1 KB
+    const int j = wave + NW * i;
+    const int f = j >> 3, part = j & 7;
+    uvo[i] = (unsigned)((f0 + f) * 8192 + part * 1024 + lane * 16);
+    uld[i] = (unsigned)(f * 8192 + part * 1024);
+  }
+  const unsigned u_chunk_bytes = (unsigned)(q.F * 8192);
+  const unsigned u_total = (unsigned)q.nchunk * u_chunk_bytes;
+  scf_rsrc4 urs = scf_make_rsrc(q.wu, u_total);
+  int u_left = (int)u_total;
+  auto issue_u = [&](int slot) {
+    const unsigned dst = u_lds + (unsigned)(slot * USLOT * 4);
+#pragma unroll
+    for (int i = 0; i < NUI; ++i) scf_bdma_b128(urs, uvo[i], dst + uld[i]);
+    const unsigned lo = (unsigned)urs[0] + u_chunk_bytes;
+    urs[1] += lo < u_chunk_bytes ? 1 : 0;
+    urs[0] = (int)lo;
+    u_left -= (int)u_chunk_bytes;
+    urs[2] = u_left > 0 ? u_left : 0;
+  };
+  const unsigned p_chunk_bytes = (unsigned)(WN_KC * HW * 4);
+  const float* p_seg = p.in0 + (long long)n * p.in0_ns;
+  int p_left = p.C0;
+  bool p_second = p.in1 == nullptr;
+  scf_rsrc4 prs = scf_make_rsrc(p_seg, (unsigned)((p_left < WN_KC ? p_left : WN_KC) * HW * 4));
+  auto issue_p = [&](int slot) {
+    const unsigned dst = p_lds + (unsigned)((slot * PSLOT + wave * (PX4 ? 256 : 64)) * 4);
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+      if (PX4) scf_bdma_b128(prs, pvo[i], dst + (unsigned)(i * NT * 16));
+      else scf_bdma_b32(prs, pvo[i], dst + (unsigned)(i * NT * 4));
+    }
+    p_left -= WN_KC;
+    if (p_left <= 0 && !p_second) {
+      p_second = true;
+      p_seg = p.in1 + (long long)n * p.in1_ns;
+      p_left = p.Cin - p.C0;
+      prs = scf_make_rsrc(p_seg, 0u);
+    } else {
+      const unsigned lo = (unsigned)prs[0] + p_chunk_bytes;
+      prs[1] += lo < p_chunk_bytes ? 1 : 0;
+      prs[0] = (int)lo;
+    }
+    const int cl = p_left < WN_KC ? p_left : WN_KC;
+    prs[2] = cl > 0 ? cl * HW * 4 : 0;
+  };
+
+  // ---- input transform: lane (tile l32, k-half) computes ITS ROW of B^T d B for channels half and 2 + half ----
+  const int ty = tw * TYW + (l32 >> q.txl), tx = l32 & (TXW - 1);
+  const int ra = row == 0 ? 0 : row == 3 ? 2 : 1, rb = row == 2 ? 3 : row == 3 ? 1 : 2;
+  const float sigma = row == 1 ? 1.0f : -1.0f;
+  const wn_f32x2 sigma2 = {sigma, sigma};
+  unsigned prow[2][2];                              // absolute LDS byte address of input rows a, b; slot 0
+  {
+    const int poff = half * q.PPL + 2 * ty * q.PWp + 2 * tx + (PX4 ? 3 : 0);
+#pragma unroll
+    for (int sI = 0; sI < 2; ++sI) {
+      prow[sI][0] = p_lds + (unsigned)((poff + 2 * sI * q.PPL + ra * q.PWp) * 4);
+      prow[sI][1] = p_lds + (unsigned)((poff + 2 * sI * q.PPL + rb * q.PWp) * 4);
+    }
+  }
+  wn_f32x2 dws[2][2][2];                            // [channel][row a / b][column pair]
+  auto win_load = [&](unsigned slot_bytes, int sI) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const __attribute__((address_space(3))) float* r =
+          (const __attribute__((address_space(3))) float*)(uintptr_t)(prow[sI][i] + slot_bytes);
+      dws[sI][i][0] = wn_f32x2{r[0], r[1]};
+      dws[sI][i][1] = wn_f32x2{r[2], r[3]};
+    }
+  };
+  auto win_transform = [&](wn_f32x2 (&bo)[2][2], int sI) {       // -> bo[sI] = {(j0, j1), (j2, j3)}
+    wn_f32x2 v01, v23;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(v01) : "v"(sigma2), "v"(dws[sI][1][0]), "v"(dws[sI][0][0]));     // e_a + sigma e_b
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(v23) : "v"(sigma2), "v"(dws[sI][1][1]), "v"(dws[sI][0][1]));
+    // (v0 - v2, v1 + v2) and (v2 - v1, v1 - v3): the column stage of the pair kernel
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(bo[sI][0]) : "v"(v01), "v"(v23));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(bo[sI][1]) : "v"(v23), "v"(v01));
+  };
+
+  wn_f32x16 acc[8];                                 // [fragment][column j]
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+  issue_p(0); issue_u(0);
+  issue_u(1); issue_p(1);
+  issue_u(2); issue_p(2);
+  scf_wait_vmcnt_imm<GRP>();
+  __syncthreads();
+  const float* ua = Us + row * 512 + lane * 2;      // + fragment * 2048 + j * 128
+  wn_f32x2 a0[8], a1[8], b0[2][2], b1[2][2];
+#pragma unroll
+  for (int x = 0; x < 8; ++x) a0[x] = *reinterpret_cast<const wn_f32x2*>(ua + (x >> 2) * 2048 + (x & 3) * 128);
+  win_load(0u, 0); win_transform(b0, 0);
+  win_load(0u, 1); win_transform(b0, 1);
+  __syncthreads();
+
+  int s1 = 1;
+  auto chunk = [&](const wn_f32x2 (&a)[8], const wn_f32x2 (&b)[2][2], wn_f32x2 (&an)[8], wn_f32x2 (&bn)[2][2]) {
+    const float* uc = ua + s1 * USLOT;
+    const unsigned pcb = (unsigned)(s1 * PSLOT * 4);
+#define WQ_M(X, S)                                                                                             \
+    if (!WN_LAB(0)) acc[X] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[X][S], b[S][((X) & 3) >> 1][(X) & 1], acc[X], 0, 0, 0);    \
+    __builtin_amdgcn_sched_barrier(0);
+    WQ_M(0, 0)
+    if (!WN_LAB(1)) win_load(pcb, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    WQ_M(1, 0)
+    if (!WN_LAB(1)) win_load(pcb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    WQ_M(2, 0)
+    int s3 = s1 + 2;
+    s3 = s3 >= 3 ? s3 - 3 : s3;
+    if (!WN_LAB(2)) issue_u(s3);
+    __builtin_amdgcn_sched_barrier(0);
+    WQ_M(3, 0)
+    if (!WN_LAB(2)) issue_p(s3);
+    __builtin_amdgcn_sched_barrier(0);
+    WQ_M(4, 0)
+    if (!WN_LAB(5)) {
+#pragma unroll
+      for (int x = 0; x < 8; ++x) an[x] = *reinterpret_cast<const wn_f32x2*>(uc + (x >> 2) * 2048 + (x & 3) * 128);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    WQ_M(5, 0)
+    if (!WN_LAB(1)) win_transform(bn, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    WQ_M(6, 0) WQ_M(7, 0)
+    WQ_M(0, 1) WQ_M(1, 1)
+    if (!WN_LAB(1)) win_transform(bn, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    WQ_M(2, 1) WQ_M(3, 1) WQ_M(4, 1) WQ_M(5, 1) WQ_M(6, 1) WQ_M(7, 1)
+#undef WQ_M
+    scf_wait_vmcnt_imm<GRP>();
+    if (!WN_LAB(4)) __syncthreads();
+    s1 = s1 == 2 ? 0 : s1 + 1;
+  };
+  int c = 0;
+  for (; c + 1 < q.nchunk; c += 2) {
+    chunk(a0, b0, a1, b1);
+    chunk(a1, b1, a0, b0);
+  }
+  if (c < q.nchunk) chunk(a0, b0, a1, b1);
+  scf_wait_vmcnt_imm<0>();
+  __syncthreads();                     // the rings are free for the exchange
+
+  // ---- output transform.  Column stage (lane-local): t = ((m0 + m1) + m2, (m1 - m2) - m3) per (fragment, row r).
+  //      Combination q = 16 f + r is finished by wave q >> 3 of the tile group; the others' pairs go through LDS:
+  //      outbox[source wave][slot of the owner: 3][pair of combinations: 4][lane][4 floats] ----
+  float* box = wn_lds + tw * (4 * 3072);
+  wn_f32x4 own[4];
+#pragma unroll
+  for (int qq = 0; qq < 32; qq += 2) {
+    wn_f32x4 t;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int f = (qq + h2) >> 4, r = (qq + h2) & 15;
+      const float m0 = acc[4 * f][r], m1 = acc[4 * f + 1][r], m2 = acc[4 * f + 2][r], m3 = acc[4 * f + 3][r];
+      t[2 * h2] = (m0 + m1) + m2;
+      t[2 * h2 + 1] = (m1 - m2) - m3;
+    }
+    const int d = qq >> 3, kp = (qq & 7) >> 1;          // owner wave, pair index
+    if (d == row) own[kp] = t;
+    else *reinterpret_cast<wn_f32x4*>(box + (((row * 3 + (d < row ? d : d - 1)) * 4 + kp) * 64 + lane) * 4) = t;
+  }
+  __syncthreads();
+
+  const ConvEpi e = scf_conv_epi(p, n);
+  const int oy = y0 + 2 * ty, ox = x0 + 2 * tx;
+  if (ox >= p.Wo || oy >= p.Ho || WN_LAB(3)) return;
+  const bool row1 = oy + 1 < p.Ho;
+  const bool relu = p.act == SCF_ACT_RELU;
+  // every load of the epilogue is issued before the first store (loads and stores share the in-order vmcnt)
+  wn_f32x4 in[4][4];                                    // [storage row of the source][pair]
+#pragma unroll
+  for (int sw = 0; sw < 4; ++sw)
+#pragma unroll
+    for (int kp = 0; kp < 4; ++kp) {
+      if (sw == row) in[sw][kp] = own[kp];
+      else in[sw][kp] = *reinterpret_cast<const wn_f32x4*>(box + (((sw * 3 + (row < sw ? row : row - 1)) * 4 + kp) * 64 + lane) * 4);
+    }
+  const int cb = (f0 + (row >> 1)) * 32 + 16 * (row & 1) + 4 * half;
+  float bv[8], sc[8], sh[8];
+  wn_f32x2 rr[8][2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int co = cb + 8 * (k >> 2) + (k & 3);
+    const int cc = co < p.Cout ? co : 0;
+    bv[k] = p.bias ? p.bias[cc] : 0.f;
+    sc[k] = p.scale ? p.scale[cc] : 1.f;
+    sh[k] = p.scale ? p.shift[cc] : 0.f;
+    const int off = cc * e.HWo + oy * p.Wo + ox;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      rr[k][i] = (e.res && (i == 0 || row1)) ? *reinterpret_cast<const wn_f32x2*>(e.res + off + i * p.Wo) : wn_f32x2{0.f, 0.f};
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int co = cb + 8 * (k >> 2) + (k & 3);
+    if (co >= p.Cout) continue;
+    const int kp = k >> 1, h2 = 2 * (k & 1);
+    // storage rows 0, 1, 2, 3 hold transform rows 0, 1, 3, 2:  Y0 = (t0 + t1) + t2,  Y1 = (t1 - t2) - t3
+    wn_f32x2 y[2];
+#pragma unroll
+    for (int cI = 0; cI < 2; ++cI) {
+      const float t0 = in[0][kp][h2 + cI], t1 = in[1][kp][h2 + cI], t3 = in[2][kp][h2 + cI], t2 = in[3][kp][h2 + cI];
+      y[0][cI] = (t0 + t1) + t2;
+      y[1][cI] = (t1 - t2) - t3;
+    }
+    const int off = co * e.HWo + oy * p.Wo + ox;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i == 1 && !row1) break;
+      wn_f32x2 v = {y[i][0] + bv[k], y[i][1] + bv[k]};
+      if (p.scale) { v[0] = v[0] * sc[k] + sh[k]; v[1] = v[1] * sc[k] + sh[k]; }
+      v[0] += rr[k][i][0]; v[1] += rr[k][i][1];
+      if (relu) { v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f; }
+      *reinterpret_cast<wn_f32x2*>(e.out + off + i * p.Wo) = v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Host side: packing and launch
 // ---------------------------------------------------------------------------------------------------
@@ -411,9 +712,15 @@ extern "C" int scf_pack_conv_weight_wino(const float* w, int32_t cout, int32_t c
   return SCF_OK;
 }
 
+// measurement knob (scflow_hip_prof.h: scf_tune(SCF_TUNE_WINO_VARIANT, v)): 0 = the dispatch's own choice,
+// 1 = pair kernel, 2 = quarter-domain kernel with 4 waves, 3 = quarter-domain kernel with 8 waves
+static std::atomic<int> g_wino_variant{0};
+int scf_wino_variant_set(int v) { return g_wino_variant.exchange(v); }
+
 // Tile selection + launch; SCF_EUNSUPPORTED -> the caller goes on to the direct kernels.
 // info (optional): {16 transform positions, fragments per block, blocks, LDS bytes}.
-int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* info, hipStream_t st) {
+int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* info, hipStream_t st, int* which) {
+  if (which) *which = 0;      // 1: the quarter-domain kernel took the launch
   if (!wu || k.KH != 3 || k.KW != 3 || k.stride != 1 || k.pad_h != 1 || k.pad_w != 1) return SCF_EUNSUPPORTED;
   if (k.w_ns != 0 || k.out_tile || k.mode != SCF_CONV_PLAIN || k.out_div != 1.0f || k.act_split > 0) return SCF_EUNSUPPORTED;
   if (k.act != SCF_ACT_NONE && k.act != SCF_ACT_RELU) return SCF_EUNSUPPORTED;
@@ -421,9 +728,6 @@ int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* i
   if (k.in1 && (k.C0 % WN_KC) != 0) return SCF_EUNSUPPORTED;
   if (((uintptr_t)wu & 15) || (long long)WN_KC * k.H * k.W * 4 >= 0x7fffffffLL) return SCF_EUNSUPPORTED;
   const int F = (k.Cout + 31) / 32;
-  // a block = one channel fragment of two vertically stacked tile groups (8 x 32 outputs on a wide map): the
-  // two wave pairs share the U chunk
-  const int CW = 1, TW = 2;
   // tiles per row of a wave's group: 16 unless a narrower group wastes clearly fewer columns
   const int tcols = (k.Wo + 1) / 2;
   int txl = 4;
@@ -436,34 +740,79 @@ int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* i
     }
   }
   const int TXW = 1 << txl, TYW = 32 >> txl;
-  WinoK q;
-  q.wu = wu; q.F = F; q.txl = txl;
   // 16-byte patch cells when every row of every plane is 16-byte aligned
   const bool px4 = (k.W % 4) == 0 && (((uintptr_t)k.in0 | (uintptr_t)k.in1) & 15) == 0 && (k.in0_ns % 4) == 0 && (k.in1_ns % 4) == 0;
-  const int npi = WN_NPI(TW, px4);
-  q.PH = 2 * TW * TYW + 2; q.PW = px4 ? 2 * TXW + 8 : 2 * TXW + 2;
-  // row pitch = TXW mod 32 floats: the TYW tile rows a half-wave reads together then start 2 TXW banks apart
-  // (fewer bank conflicts in the window reads), when the wider patch still fits the slot
-  q.PWp = q.PW + ((TXW - q.PW) & 31);
-  if (WN_KC * q.PH * q.PWp > npi * (px4 ? 1024 : 256)) q.PWp = q.PW;
-  q.PPL = q.PH * q.PWp;
-  if (WN_KC * q.PPL > npi * (px4 ? 1024 : 256)) return SCF_EUNSUPPORTED;
+  const int cfg = px4 ? 1 : 0;
+  WinoK q;
+  q.wu = wu; q.F = F; q.txl = txl;
   q.nchunk = (k.Cin + WN_KC - 1) / WN_KC;
   q.sx = (k.Wo + 2 * TXW - 1) / (2 * TXW);
-  q.sy = (k.Ho + 2 * TW * TYW - 1) / (2 * TW * TYW);
-  q.mblocks = F / CW;
-  const long long nblk = (long long)N * q.sx * q.sy * q.mblocks;
-  if (nblk <= 0 || nblk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
+  // geometry of a variant: CW channel fragments x TW tile groups per block, pslot floats per patch ring slot
+  auto shape = [&](int CW, int TW, int pslot) -> long long {
+    q.PH = 2 * TW * TYW + 2; q.PW = px4 ? 2 * TXW + 8 : 2 * TXW + 2;
+    // row pitch = TXW mod 32 floats: the TYW tile rows a half-wave reads together then start 2 TXW banks apart
+    // (fewer bank conflicts in the window reads), when the wider patch still fits the slot
+    q.PWp = q.PW + ((TXW - q.PW) & 31);
+    if (WN_KC * q.PH * q.PWp > pslot) q.PWp = q.PW;
+    q.PPL = q.PH * q.PWp;
+    if (WN_KC * q.PPL > pslot || (F % CW) != 0) return -1;
+    q.sy = (k.Ho + 2 * TW * TYW - 1) / (2 * TW * TYW);
+    q.mblocks = F / CW;
+    const long long nblk = (long long)N * q.sx * q.sy * q.mblocks;
+    return (nblk <= 0 || nblk > 0x7fffffffLL) ? -1 : nblk;
+  };
   // Small grids stay on the direct kernels: a block here is a serial chain of Cin / 4 chunks (27 us at 128
   // input channels, 48 us at 256, whatever the grid) and the direct path has a K-split tile for them.  Measured
   // on all layer shapes of the refiner (tools/lab/wino_sweep.py): 0.4-0.87x at <= 96 blocks, 1.25-1.35x at 128,
-  // 1.5-2x from 192 blocks on.
-  if (nblk < scf_cu_count() / 2) return SCF_EUNSUPPORTED;
+  // 1.5-2x from 192 blocks on.  (In units of 4-wave blocks: an 8-wave block counts twice.)
+  const int min_blocks4 = scf_cu_count() / 2;
+  int variant = g_wino_variant.load(std::memory_order_relaxed);
+  if (variant == 0) variant = SCF_WINO_DEFAULT_VARIANT;
+#ifndef SCF_WINO_LAB
+  if (variant == 3) variant = 2;          // the 8-wave form is instantiated in lab builds only (measured: no faster)
+#endif
+  if (variant == 2 || variant == 3) {
+    const int TW = variant == 3 ? 2 : 1;
+    const int npi = WQ_NPI(TW, px4), pslot = npi * 256 * TW * (px4 ? 4 : 1);
+    const long long nblk = shape(2, TW, pslot);
+    if (nblk > 0 && nblk * TW >= min_blocks4) {
+      size_t ldsf = (size_t)(3 * 2 * 2048 + 3 * pslot);
+      if (ldsf < (size_t)TW * 4 * 3072) ldsf = (size_t)TW * 4 * 3072;      // the output exchange reuses the rings
+      const size_t ldsb = ldsf * sizeof(float);
+      if (info) { info[0] = 16; info[1] = 2 * TW; info[2] = (int)nblk; info[3] = (int)ldsb; }
+      if (dry_run) return SCF_OK;
+      static std::atomic<unsigned long long> raised_q[4];
+#ifdef SCF_WINO_LAB
+      if (TW == 2) {
+        const void* fn8 = cfg ? (const void*)conv_wino_q_kernel<2, true> : (const void*)conv_wino_q_kernel<2, false>;
+        const int rc8 = scf_raise_dynamic_lds(raised_q[2 + cfg], fn8, 96 * 1024);
+        if (rc8 != SCF_OK) return rc8;
+        if (cfg) scf_launch((conv_wino_q_kernel<2, true>), dim3((unsigned)nblk), dim3(512), ldsb, st, k, q);
+        else scf_launch((conv_wino_q_kernel<2, false>), dim3((unsigned)nblk), dim3(512), ldsb, st, k, q);
+        return scf_launch_status();
+      }
+#endif
+      const void* fn = cfg ? (const void*)conv_wino_q_kernel<1, true> : (const void*)conv_wino_q_kernel<1, false>;
+      const int rc = scf_raise_dynamic_lds(raised_q[cfg], fn, 64 * 1024);
+      if (rc != SCF_OK) return rc;
+      if (which) *which = 1;
+      if (cfg) scf_launch((conv_wino_q_kernel<1, true>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
+      else scf_launch((conv_wino_q_kernel<1, false>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
+      return scf_launch_status();
+    }
+    // odd fragment counts, patches that do not fit the quarter kernel's slot: the pair kernel
+  }
+  // pair kernel: a block = one channel fragment of two vertically stacked tile groups (8 x 32 outputs on a wide
+  // map): the two wave pairs share the U chunk
+  const int CW = 1, TW = 2;
+  const int npi = WN_NPI(TW, px4);
+  const long long nblk = shape(CW, TW, npi * (px4 ? 1024 : 256));
+  if (nblk < 0) return SCF_EUNSUPPORTED;
+  if (nblk < min_blocks4) return SCF_EUNSUPPORTED;
   const size_t ldsb = (size_t)(3 * CW * 2048 + 3 * npi * (px4 ? 1024 : 256)) * sizeof(float);
   if (ldsb > 80 * 1024) return SCF_EUNSUPPORTED;
   if (info) { info[0] = 16; info[1] = CW * TW; info[2] = (int)nblk; info[3] = (int)ldsb; }     // positions, fragments per block
   if (dry_run) return SCF_OK;
-  const int cfg = px4 ? 1 : 0;
   {                                  // more than 64 KB of dynamic LDS needs the attribute, once per kernel and device
     static std::atomic<unsigned long long> raised[2];
     const int rc = scf_raise_dynamic_lds(raised[cfg], cfg ? (const void*)conv_wino_kernel<1, 2, true>

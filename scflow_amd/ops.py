@@ -648,6 +648,15 @@ def conv_timing(enable: bool):
     return list(zip(_read_timers([e[0] for e in evs]), [e[1] for e in evs], [e[2] for e in evs]))
 
 
+TUNE_KEYS = {'wino_variant': 1}
+
+
+def tune(key: str, value: int) -> int:
+    """measurement knob of the library (``scf_tune``, scflow_hip_prof.h): returns the previous value.
+    ``'wino_variant'``: 0 = the dispatch's choice, 1 = pair kernel, 2 / 3 = quarter-domain kernel (4 / 8 waves)."""
+    return int(_lib.load().scf_tune(TUNE_KEYS[key], int(value)))
+
+
 class record_conv_kernels:
     """``with ops.record_conv_kernels() as ran: ...`` -- afterwards ``ran`` is a list of
     ``(layer tag, kernel family)`` for every convolution launch the library made inside the block, in

@@ -39,7 +39,7 @@ def test_operator_header_holds_no_measurement_entry_points():
     assert not [n for n in ops_abi if n.startswith('scf_timer') or n.endswith(('_timed', '_query')) or n.startswith('scf_conv_log')]
     prof = set(_declared_symbols(('scflow_hip_prof.h',))) - set(ops_abi)
     assert prof == {'scf_timer_create', 'scf_timer_destroy', 'scf_timer_arm', 'scf_timer_elapsed_us',
-                    'scf_conv2d_query', 'scf_conv_log_enable', 'scf_conv_log_read'}
+                    'scf_conv2d_query', 'scf_conv_log_enable', 'scf_conv_log_read', 'scf_tune'}
 
 
 def test_version_and_error_strings():

@@ -306,10 +306,13 @@ WINO_CASES = [
 ]
 
 
+@pytest.mark.parametrize('variant', [1, 2])
 @pytest.mark.parametrize('case', WINO_CASES)
-def test_conv2d_winograd(case):
-    """F(2x2, 3x3) kernel vs torch fp64 and vs the direct kernel: same fp32 arithmetic with re-associated
-    sums, so the error budget is a small multiple of the direct kernel's."""
+def test_conv2d_winograd(case, variant):
+    """F(2x2, 3x3) kernels vs torch fp64 and vs the direct kernel: same fp32 arithmetic with re-associated
+    sums, so the error budget is a small multiple of the direct kernel's.  variant 1 = the pair kernel (a wave pair
+    per channel fragment) forced on every case, variant 2 = the dispatch's choice: the quarter-domain kernel
+    (one transform row x two channel fragments per wave) where the fragment count is even, else the pair kernel."""
     import ctypes as C
     n, cin, cout, H, W, c0, bn, with_res, relu = case
     x = rnd((n, cin, H, W), 40)
@@ -345,16 +348,21 @@ def test_conv2d_winograd(case):
     try:
         direct = ops.conv2d(pc, x0, x1, **kw)
         ops.set_conv_winograd(True)
+        ops.tune('wino_variant', variant)
         d, _ = ops.conv_desc(pc, x0, x1, **kw)
         info = (C.c_int32 * 4)()
         assert lib.scf_conv2d_query(C.byref(d), info) == 0
         assert info[3] < 0 and info[0] == 16, list(info)     # the Winograd kernel is the one that runs
-        got = ops.conv2d(pc, x0, x1, **kw)
+        with ops.record_conv_kernels() as ran:
+            got = ops.conv2d(pc, x0, x1, **kw)
+        even_frags = ((cout + 31) // 32) % 2 == 0
+        assert [k_ for _, k_ in ran] == ['winograd-q' if (variant == 2 and even_frags) else 'winograd'], ran
     finally:
+        ops.tune('wino_variant', 0)
         ops.set_conv_winograd(prev)
     e_dir = float((direct.cpu() - want).abs().max())
     e_win = float((got.cpu() - want).abs().max())
-    print(f'winograd {case}: max err {e_win:.2e} (direct kernel {e_dir:.2e})')
+    print(f'winograd {case} variant {variant}: max err {e_win:.2e} (direct kernel {e_dir:.2e})')
     close(got, want, atol=1e-5, what='winograd ' + str(case))      # measured <= 3.5e-6
     # small grids stay on the direct kernels
     xs = xd[:1, :, :8, :10].contiguous() if W >= 10 and H >= 8 else xd[:1]
@@ -508,7 +516,7 @@ def _winograd_stress(kind, k, pad, n, cin, cout, H, W, budget, info0, seed):
     finally:
         ops.set_conv_winograd(prev)
     assert [kk for _, kk in ran_d] == ['direct-dma'], ran_d
-    assert [kk for _, kk in ran_w] == [info0], ran_w                   # the Winograd kernel really ran
+    assert len(ran_w) == 1 and ran_w[0][1].startswith(info0), ran_w       # the Winograd kernel really ran
     r_dir = float(((direct.cpu().double() - want).abs() / (eps * scale)).max())
     r_win = float(((got.cpu().double() - want).abs() / (eps * scale)).max())
     r_rel = float(((got.cpu().double() - direct.cpu().double()).abs() / (eps * scale)).max())
@@ -521,10 +529,11 @@ def _winograd_stress(kind, k, pad, n, cin, cout, H, W, budget, info0, seed):
 
 
 @pytest.mark.parametrize('kind', WINO_STRESS_OPERANDS)
-@pytest.mark.parametrize('shape', [(4, 128, 512, 32, 32), (2, 64, 64, 128, 128), (8, 256, 192, 32, 32)])
+@pytest.mark.parametrize('shape', [(4, 128, 512, 32, 32), (2, 64, 64, 128, 128), (8, 256, 192, 32, 32), (8, 96, 96, 64, 64)])
 def test_conv2d_winograd_stress_operands(kind, shape):
     """F(2x2, 3x3) vs torch fp64 AND vs the direct kernel on DC-offset / one-signed / wide-range operands,
-    tolerance relative to sum |w||x| (see above)."""
+    tolerance relative to sum |w||x| (see above).  96 -> 96 has an odd fragment count: the pair kernel; the other
+    shapes run the quarter-domain kernel."""
     n, cin, cout, H, W = shape
     _winograd_stress(kind, (3, 3), 1, n, cin, cout, H, W, budget=12.0, info0='winograd', seed=700 + cin)
 

@@ -175,7 +175,7 @@ def test_config4_full_size_480x640_12iters_batch8(dispatch_check):
     # batch 8 at 60x80: the 3x3 stride-1 layers of the loop run the F(2x2,3x3) kernel, the GRU gates F(2,5)
     dispatch_check('config4_batch8', ran)
     kinds = {(tag, k) for tag, k in ran}
-    assert ('256->192 3x3/s1 @60x80 N8', 'winograd') in kinds, sorted(kinds)
+    assert ('256->192 3x3/s1 @60x80 N8', 'winograd-q') in kinds, sorted(kinds)
     assert any(k == 'winograd F(2,5)' and '1x5' in tag for tag, k in kinds), sorted(kinds)
     assert any(k == 'winograd F(2,5)' and '5x1' in tag for tag, k in kinds), sorted(kinds)
     with torch.no_grad():
@@ -349,7 +349,11 @@ def test_cal_epe_hip_vs_oracle_sizes(shape):
             for k in want:
                 _close(got[k], want[k].float(), atol=1e-6, rtol=2e-6, what=f'{shape} {red} {k}')
         got = cal_epe(tgt.to(DEV), pred.to(DEV), None if m is None else m.to(DEV), reduction='none')
-        assert torch.equal(got.cpu(), oracle.cal_epe(tgt, pred, m, reduction='none'))      # bit for bit
+        # torch's CPU sqrt (MKL VML on large tensors) is off by one ulp on ~0.6 % of the inputs; ours is the
+        # correctly rounded one: equal within 1 ulp, and identical zeros (the masked-out pixels)
+        want_map = oracle.cal_epe(tgt, pred, m, reduction='none')
+        _close(got, want_map, atol=0.0, rtol=1.2e-7, what=f'{shape} none')
+        assert torch.equal(got.cpu() == 0, want_map == 0)
     # a NaN prediction on a valid pixel poisons that sample's mean, like torch's err * valid
     pred2 = pred.clone()
     pred2[0, 0, h - 1, w - 1] = float('nan')
