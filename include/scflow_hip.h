@@ -54,8 +54,8 @@ enum {
  * returns the number the LIBRARY was built with: a C caller compares scf_version() / 100 with
  * SCF_ABI_MAJOR before its first call; structs additionally carry no size field,
  * so a mismatch must be refused, not worked around. */
-#define SCF_ABI_MAJOR 3
-#define SCF_VERSION (SCF_ABI_MAJOR * 100 + 6)
+#define SCF_ABI_MAJOR 4
+#define SCF_VERSION (SCF_ABI_MAJOR * 100 + 0)
 int scf_version(void);
 const char* scf_error_string(int code);
 /* number of HIP devices visible (>=0) or SCF_ENODEVICE */
@@ -312,6 +312,10 @@ typedef struct scf_scflow_iter {
   scf_iter_gn gn[3];
   const float* fc1_w; const float* fc1_b; float* fc1_out; int32_t fc1_K, fc1_O;
   const float* fc2_w; const float* fc2_b; float* fc2_out; int32_t fc2_O;
+  /* fc_fused != 0: the tail runs as three scf_fc_splitk launches -- the third GroupNorm + ReLU is applied by
+   * fc1's operand load (gn[2].out unused), fc1_out / fc2_out are (fc1_slices, N, fc1_O) / (fc2_slices, N, fc2_O)
+   * partial-sum buffers whose bias + ReLU the next layer's load applies.  0: scf_linear launches as before. */
+  int32_t fc_fused, fc1_slices, fc2_slices;
   const float* rot_w; const float* rot_b; float* rot_all; int32_t rot_O;
   const float* trans_w; const float* trans_b; float* trans_all; int32_t trans_O;
   const int64_t* label; int32_t num_class, label_mode;
@@ -352,6 +356,35 @@ int scf_linear(const float* x, const float* W, const float* b, float* y, int N, 
 int scf_linear_pair(const float* x, const float* W1, const float* b1, float* y1, int O1,
                     const float* W2, const float* b2, float* y2, int O2, int N, int K, int act,
                     scf_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * nn.Linear as a split-K GEMM on the matrix cores, with its element-wise neighbours folded into the operand
+ * loads: the pose head's flatten -> fc1 -> ReLU -> fc2 -> ReLU -> rotation_pred | translation_pred
+ * (pose_head.py:166-172, 201-211) in three launches that read every weight once per batch.
+ *   input    x[n][k] = f( sum_{s < x_parts} x[s][n][k] + x_bias[k] ), f = ReLU if x_relu: the partial sums a
+ *            previous scf_fc_splitk wrote (x_part_stride floats between parts; x_parts = 1, x_bias = NULL: a plain
+ *            (N, K) tensor);
+ *            gn_groups > 0: GroupNorm(gn_groups, gn_eps, affine) + ReLU over the K features of each sample first
+ *            (group = K / gn_groups consecutive features, channel of feature k = k / gn_hw: the flattened
+ *            (C, h, w) map of pose_head.py:151-159 with gn_hw = h w) -- replaces scf_group_norm_relu on that map;
+ *   output   slices == 1: y[n][o] = act(sum_k W[o][k] x[n][k] + bias[o]), and the same for the optional second
+ *            matrix (W2, bias2, y2, O2: rotation_pred and translation_pred read the same features);
+ *            slices  > 1: y = (slices, N, O) partial sums over K / slices features each, no bias / act -- the
+ *            consumer adds them in slice order (x_parts, x_bias, x_relu of the next call).
+ * K % slices == 0, K / slices <= 256 and a multiple of 8 (and of the group size), 16-byte aligned rows.
+ * W row-major (O, K) like nn.Linear.weight.  Sums are fp32 fma chains in a fixed order (deterministic).
+ * --------------------------------------------------------------------------------- */
+typedef struct scf_fc_desc {
+  const float* x; int32_t x_parts; int64_t x_part_stride;
+  const float* x_bias; int32_t x_relu;
+  int32_t gn_groups, gn_hw; const float* gn_gamma; const float* gn_beta; float gn_eps;
+  int32_t N, K;
+  const float* W; const float* bias; float* y; int32_t O;
+  const float* W2; const float* bias2; float* y2; int32_t O2;
+  int32_t act;                          /* SCF_ACT_* of the finished outputs (slices == 1)  */
+  int32_t slices;
+} scf_fc_desc;
+int scf_fc_splitk(const scf_fc_desc* desc, scf_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Pose head tail + pose update.  replaces pose_head.py:207-210 (class select) and

@@ -15,7 +15,7 @@ SCF_OK = 0
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 CONV_PLAIN, CONV_GRU_ZR, CONV_GRU_Q = 0, 1, 2
 MAX_LEVELS = 12
-ABI_MAJOR = 3            # SCF_ABI_MAJOR of include/scflow_hip.h this binding was written against
+ABI_MAJOR = 4            # SCF_ABI_MAJOR of include/scflow_hip.h this binding was written against
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -79,6 +79,17 @@ KERNEL_NAMES = {1: 'thin', 2: 'taps', 3: 'winograd', 4: 'winograd F(2,5)', 5: 'f
                 7: 'direct-mfma', 8: 'direct-mfma-ksplit', 9: 'winograd-q'}
 
 
+class FcDesc(C.Structure):
+    """mirror of ``scf_fc_desc`` (include/scflow_hip.h)."""
+    _fields_ = [('x', _fp), ('x_parts', C.c_int32), ('x_part_stride', C.c_int64),
+                ('x_bias', _fp), ('x_relu', C.c_int32),
+                ('gn_groups', C.c_int32), ('gn_hw', C.c_int32), ('gn_gamma', _fp), ('gn_beta', _fp), ('gn_eps', C.c_float),
+                ('N', C.c_int32), ('K', C.c_int32),
+                ('W', _fp), ('bias', _fp), ('y', _fp), ('O', C.c_int32),
+                ('W2', _fp), ('bias2', _fp), ('y2', _fp), ('O2', C.c_int32),
+                ('act', C.c_int32), ('slices', C.c_int32)]
+
+
 class IterGN(C.Structure):
     """mirror of ``scf_iter_gn``."""
     _fields_ = [('gamma', _fp), ('beta', _fp), ('out', _fp),
@@ -104,6 +115,7 @@ class ScflowIter(C.Structure):
         ('pose', ConvDesc * 3), ('gn', IterGN * 3),
         ('fc1_w', _fp), ('fc1_b', _fp), ('fc1_out', _fp), ('fc1_K', C.c_int32), ('fc1_O', C.c_int32),
         ('fc2_w', _fp), ('fc2_b', _fp), ('fc2_out', _fp), ('fc2_O', C.c_int32),
+        ('fc_fused', C.c_int32), ('fc1_slices', C.c_int32), ('fc2_slices', C.c_int32),
         ('rot_w', _fp), ('rot_b', _fp), ('rot_all', _fp), ('rot_O', C.c_int32),
         ('trans_w', _fp), ('trans_b', _fp), ('trans_all', _fp), ('trans_O', C.c_int32),
         ('label', _fp), ('num_class', C.c_int32), ('label_mode', C.c_int32),
@@ -164,6 +176,7 @@ SIGNATURES = {
     'scf_instance_norm': (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int, C.c_float, C.c_int, _fp]),
     'scf_group_norm_relu': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_float, _fp]),
+    'scf_fc_splitk': (C.c_int, [C.POINTER(FcDesc), _fp]),
     'scf_linear': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'scf_linear_pair': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int,
                                   C.c_int, _fp]),

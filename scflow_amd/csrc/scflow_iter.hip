@@ -155,12 +155,30 @@ extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stre
   for (int i = 0; i < 3; ++i) {
     SCF_TRY(scf_conv2d(&it->pose[i], stream));
     const scf_iter_gn& g = it->gn[i];
+    if (it->fc_fused && i == 2) break;          // the last GroupNorm + ReLU is folded into fc1's operand load
     SCF_TRY(scf_group_norm_relu(it->pose[i].out, g.gamma, g.beta, g.out, N, g.C, g.HW, g.G, g.eps, stream));
   }
-  SCF_TRY(scf_linear(it->gn[2].out, it->fc1_w, it->fc1_b, it->fc1_out, N, it->fc1_K, it->fc1_O, SCF_ACT_RELU, stream));
-  SCF_TRY(scf_linear(it->fc1_out, it->fc2_w, it->fc2_b, it->fc2_out, N, it->fc1_O, it->fc2_O, SCF_ACT_RELU, stream));
-  SCF_TRY(scf_linear_pair(it->fc2_out, it->rot_w, it->rot_b, it->rot_all, it->rot_O, it->trans_w, it->trans_b,
-                          it->trans_all, it->trans_O, N, it->fc2_O, SCF_ACT_NONE, stream));
+  if (it->fc_fused) {
+    const scf_iter_gn& g = it->gn[2];
+    scf_fc_desc f = {};
+    f.x = it->pose[2].out; f.x_parts = 1; f.gn_groups = g.G; f.gn_hw = g.HW; f.gn_gamma = g.gamma; f.gn_beta = g.beta;
+    f.gn_eps = g.eps; f.N = N; f.K = it->fc1_K; f.W = it->fc1_w; f.y = it->fc1_out; f.O = it->fc1_O; f.slices = it->fc1_slices;
+    SCF_TRY(scf_fc_splitk(&f, stream));
+    scf_fc_desc f2 = {};
+    f2.x = it->fc1_out; f2.x_parts = it->fc1_slices; f2.x_part_stride = (int64_t)N * it->fc1_O; f2.x_bias = it->fc1_b;
+    f2.x_relu = 1; f2.N = N; f2.K = it->fc1_O; f2.W = it->fc2_w; f2.y = it->fc2_out; f2.O = it->fc2_O; f2.slices = it->fc2_slices;
+    SCF_TRY(scf_fc_splitk(&f2, stream));
+    scf_fc_desc f3 = {};
+    f3.x = it->fc2_out; f3.x_parts = it->fc2_slices; f3.x_part_stride = (int64_t)N * it->fc2_O; f3.x_bias = it->fc2_b;
+    f3.x_relu = 1; f3.N = N; f3.K = it->fc2_O; f3.W = it->rot_w; f3.bias = it->rot_b; f3.y = it->rot_all; f3.O = it->rot_O;
+    f3.W2 = it->trans_w; f3.bias2 = it->trans_b; f3.y2 = it->trans_all; f3.O2 = it->trans_O; f3.act = SCF_ACT_NONE; f3.slices = 1;
+    SCF_TRY(scf_fc_splitk(&f3, stream));
+  } else {
+    SCF_TRY(scf_linear(it->gn[2].out, it->fc1_w, it->fc1_b, it->fc1_out, N, it->fc1_K, it->fc1_O, SCF_ACT_RELU, stream));
+    SCF_TRY(scf_linear(it->fc1_out, it->fc2_w, it->fc2_b, it->fc2_out, N, it->fc1_O, it->fc2_O, SCF_ACT_RELU, stream));
+    SCF_TRY(scf_linear_pair(it->fc2_out, it->rot_w, it->rot_b, it->rot_all, it->rot_O, it->trans_w, it->trans_b,
+                            it->trans_all, it->trans_O, N, it->fc2_O, SCF_ACT_NONE, stream));
+  }
   // ---- pose update (pose.py:124-169) and the pose-induced flow (pose.py:44-88) ----
   SCF_TRY(scf_pose_update(it->rot_all, it->trans_all, it->label, it->num_class, it->label_mode, it->R_in, it->t_in,
                           it->d_rot, it->d_trans, it->R_out, it->t_out, N, stream));

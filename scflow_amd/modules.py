@@ -476,6 +476,9 @@ class MultiClassPoseHead(HipModule):
         # reference label selection uses label[0] for the whole batch (pose_head.py:209-210,
         # SURVEY.md 8 a8); label_mode=1 selects per sample instead.
         self.label_mode = 0
+        # fc1 / fc2 / heads as split-K MFMA GEMMs with the last GroupNorm folded in (scf_fc_splitk); False = one
+        # scf_linear launch per layer after a separate GroupNorm (A/B measurements, parity tests)
+        self.fused_fc = True
         self.init_weights()
 
     def init_weights(self):
@@ -486,9 +489,35 @@ class MultiClassPoseHead(HipModule):
         with torch.no_grad():
             self.rotation_pred.bias.copy_(torch.tensor([1., 0., 0., 0., 1., 0.] * self.num_class))
 
+    def fc_plan(self) -> Tuple[int, int]:
+        """(K-slices of fc1, of fc2) when the fully connected tail fits ``scf_fc_splitk`` (three launches: the last
+        GroupNorm + ReLU folded into fc1's load, every weight read once per batch), else (0, 0): plain
+        ``scf_linear`` launches."""
+        fc1, fc2, last = self.fc_layers[0][0], self.fc_layers[1][0], self.conv_layers[2]
+        s1, s2 = ops.fc_slices(fc1.in_features), ops.fc_slices(fc2.in_features)
+        ok = (s1 > 0 and s2 > 0 and ops.fc_slices(fc2.out_features) == 1 and last.groups is not None
+              and last.act == ACT_RELU and self.fused_fc)
+        if ok:      # a K-slice of fc1 must hold whole normalisation groups
+            gsz = fc1.in_features // last.groups
+            ok = fc1.in_features % last.groups == 0 and gsz % 2 == 0 and (fc1.in_features // s1) % gsz == 0
+        return (s1, s2) if ok else (0, 0)
+
     def features(self, x0: Tensor, x1: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
         x = self.conv_layers[0](x0, x1)
         x = self.conv_layers[1](x)
+        s1, s2 = self.fc_plan()
+        fc1, fc2 = self.fc_layers[0][0], self.fc_layers[1][0]
+        if s1:
+            last = self.conv_layers[2]
+            y = ops.conv2d(last.packed, x)                     # GroupNorm + ReLU: applied by fc1's operand load
+            hw = y.shape[2] * y.shape[3]
+            if y[0].numel() != fc1.in_features:
+                raise _lib_error(f'pose head expects {fc1.in_features} features, the maps give {y[0].numel()}')
+            p1 = ops.fc_splitk(y.view(y.shape[0], -1), fc1.weight, gn=(last.groups, hw, last.gn.weight, last.gn.bias, last.gn.eps),
+                               slices=s1)
+            p2 = ops.fc_splitk(p1, fc2.weight, x_bias=fc1.bias, x_relu=True, slices=s2)
+            return ops.fc_splitk(p2, self.rotation_pred.weight, self.rotation_pred.bias, x_bias=fc2.bias, x_relu=True,
+                                 weight2=self.translation_pred.weight, bias2=self.translation_pred.bias)
         x = self.conv_layers[2](x)
         x = x.view(x.shape[0], -1)
         for fc in self.fc_layers:
@@ -720,7 +749,9 @@ def _scflow_forward_c(self, pyramid, tiled, hx, ctx, rot0, trans0, depth, intern
     fc1, fc2 = ph.fc_layers[0][0], ph.fc_layers[1][0]
     if fc1.in_features != x0[0].numel():
         raise _lib_error(f'pose head expects {fc1.in_features} features, the maps give {x0[0].numel()}')
-    y1, y2 = E(n, fc1.out_features), E(n, fc2.out_features)
+    s1, s2 = ph.fc_plan()
+    it.fc_fused, it.fc1_slices, it.fc2_slices = int(s1 > 0), max(s1, 1), max(s2, 1)
+    y1, y2 = E(max(s1, 1), n, fc1.out_features), E(max(s2, 1), n, fc2.out_features)
     ra, ta = E(n, ph.rotation_pred.out_features), E(n, ph.translation_pred.out_features)
     keep += [y1, y2, ra, ta]
     P = lambda t: None if t is None else t.data_ptr()

@@ -27,7 +27,7 @@ Tensor = torch.Tensor
 
 __all__ = ['record_conv_kernels', 'PackedConv', 'conv_desc', 'gru_passes', 'scflow_iteration', 'side_stream_handle', 'pyramid_layout', 'untile_level', 'level_storage_shape', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision', 'set_conv_winograd', 'get_conv_winograd', 'pack_conv_weight_wino', 'pack_conv_weight_wino1d',
            'get_conv_precision', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
-           'instance_norm', 'group_norm_relu', 'linear', 'pose_update', 'reproject_flow',
+           'instance_norm', 'group_norm_relu', 'linear', 'fc_splitk', 'fc_slices', 'pose_update', 'reproject_flow',
            'unproject_depth', 'linear_pair', 'resize_bilinear', 'convex_upsample', 'avgpool2x2', 'copy_channels',
            'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_TANH', 'CONV_PLAIN', 'CONV_GRU_ZR',
            'CONV_GRU_Q']
@@ -940,6 +940,49 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int = ACT_NON
     _lib.check(_lib.load().scf_linear(px, _dense(weight, 'weight'), _opt(bias, 'bias'),
                                       _dense(out, 'out'), n, k, o, act, _stream()), 'scf_linear')
     return out
+
+
+def fc_slices(k: int) -> int:
+    """K-slices ``fc_splitk`` is given for an input of ``k`` features: 256 features per slice (one block tile's
+    worth of LDS) where K allows it, else 0 = the shape does not fit (callers use ``linear``)."""
+    if k % 8 == 0 and k <= 256:
+        return 1
+    return k // 256 if k % 256 == 0 else 0
+
+
+def fc_splitk(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, *, x_bias: Optional[Tensor] = None,
+              x_relu: bool = False, gn=None, weight2: Optional[Tensor] = None, bias2: Optional[Tensor] = None,
+              act: int = ACT_NONE, slices: int = 1):
+    """nn.Linear as a split-K MFMA GEMM with fused neighbours (``scf_fc_splitk``).  ``x``: (N, K), or
+    (parts, N, K) partial sums of a previous ``fc_splitk(..., slices=parts)`` whose bias / ReLU this call applies
+    (``x_bias``, ``x_relu``); ``gn`` = (groups, hw, gamma, beta, eps): GroupNorm + affine + ReLU over the features
+    first (the flattened (C, h, w) map of the pose head, hw = h * w).  ``slices`` > 1: returns (slices, N, O)
+    partial sums (no bias / act); 1: the finished (N, O) [and (N, O2) for ``weight2``]."""
+    _dev(x, 'x')
+    if x.dim() == 2:
+        x = x.unsqueeze(0)
+    if x.dim() != 3 or not x.is_contiguous():
+        raise _lib.ScflowHipError('fc_splitk: x must be a contiguous (N, K) or (parts, N, K) tensor')
+    parts, n, k = x.shape
+    o = weight.shape[0]
+    if weight.shape[1] != k or (weight2 is not None and weight2.shape[1] != k):
+        raise _lib.ScflowHipError('fc_splitk: weight / in_features mismatch')
+    d = _lib.FcDesc()
+    d.x, d.x_parts, d.x_part_stride = x.data_ptr(), parts, n * k
+    d.x_bias, d.x_relu = _opt(x_bias, 'x_bias'), int(bool(x_relu))
+    if gn is not None:
+        groups, hw, gamma, beta, eps = gn
+        d.gn_groups, d.gn_hw, d.gn_gamma, d.gn_beta, d.gn_eps = groups, hw, _dense(gamma, 'gamma'), _dense(beta, 'beta'), eps
+    d.N, d.K = n, k
+    y = torch.empty((slices, n, o) if slices > 1 else (n, o), dtype=torch.float32, device=x.device)
+    d.W, d.bias, d.y, d.O = _dense(weight, 'weight'), _opt(bias, 'bias'), y.data_ptr(), o
+    y2 = None
+    if weight2 is not None:
+        y2 = torch.empty((n, weight2.shape[0]), dtype=torch.float32, device=x.device)
+        d.W2, d.bias2, d.y2, d.O2 = _dense(weight2, 'weight2'), _opt(bias2, 'bias2'), y2.data_ptr(), weight2.shape[0]
+    d.act, d.slices = act, slices
+    _lib.check(_lib.load().scf_fc_splitk(C.byref(d), _stream()), 'scf_fc_splitk')
+    return y if y2 is None else (y, y2)
 
 
 def linear_pair(x: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor],

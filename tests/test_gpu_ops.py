@@ -355,8 +355,12 @@ def test_conv2d_winograd(case, variant):
         assert info[3] < 0 and info[0] == 16, list(info)     # the Winograd kernel is the one that runs
         with ops.record_conv_kernels() as ran:
             got = ops.conv2d(pc, x0, x1, **kw)
+        # the quarter-domain kernel needs an even fragment count and its own grid of >= CUs / 2 blocks: the ragged
+        # 20 x 28 case gives it 120 blocks (5 strips of 4 rows) where the pair kernel has 144 (3 strips of 8 rows x 2
+        # fragments), so that one stays on the pair kernel
         even_frags = ((cout + 31) // 32) % 2 == 0
-        assert [k_ for _, k_ in ran] == ['winograd-q' if (variant == 2 and even_frags) else 'winograd'], ran
+        quarter = variant == 2 and even_frags and (H, W) != (20, 28)
+        assert [k_ for _, k_ in ran] == ['winograd-q' if quarter else 'winograd'], ran
     finally:
         ops.tune('wino_variant', 0)
         ops.set_conv_winograd(prev)
@@ -778,6 +782,81 @@ def test_linear(n, k, o):
     x, wt, b = rnd((n, k), 55), rnd((o, k), 56, k ** -0.5), rnd((o,), 57, 0.1)
     close(ops.linear(x.to(DEV), wt.to(DEV), b.to(DEV), ops.ACT_RELU), torch.relu(F.linear(x, wt, b)),
           atol=2e-5, what='linear')
+
+
+@pytest.mark.parametrize('n,k,o,slices', [(32, 2048, 1024, 8), (3, 2048, 1024, 8), (1, 1024, 256, 4), (40, 512, 70, 2),
+                                          (32, 256, 126, 1), (5, 64, 33, 1), (33, 1024, 256, 4)])
+def test_fc_splitk_vs_torch(n, k, o, slices):
+    """scf_fc_splitk (split-K MFMA GEMM): finished outputs (slices = 1) and partial sums whose slice-ordered sum
+    + bias + ReLU -- what the next layer's operand load computes -- equals nn.Linear + ReLU"""
+    x, wt, b = rnd((n, k), 155), rnd((o, k), 156, k ** -0.5), rnd((o,), 157, 0.1)
+    want = torch.relu(F.linear(x.double(), wt.double(), b.double())).float()
+    if slices == 1:
+        got = ops.fc_splitk(x.to(DEV), wt.to(DEV), b.to(DEV), act=ops.ACT_RELU)
+        close(got, want, atol=2e-6, what='fc finished')
+    else:
+        parts = ops.fc_splitk(x.to(DEV), wt.to(DEV), slices=slices)
+        assert parts.shape == (slices, n, o)
+        got = torch.relu(parts.sum(0) + b.to(DEV))
+        close(got, want, atol=2e-6, what='fc partial sums')
+        # consumed by a next layer: identity weights read the summed, biased, rectified features back
+        if o % 8 == 0 and o <= 256:
+            eye = torch.eye(o, device=DEV)
+            back = ops.fc_splitk(parts, eye, x_bias=b.to(DEV), x_relu=True)
+            close(back, want, atol=2e-6, what='fc partials through the next load')
+    assert ops.fc_slices(k) == slices or slices in (1, 2)
+
+
+def test_fc_splitk_group_norm_and_two_heads():
+    """the pose head's tail as three launches: GroupNorm(32) + ReLU folded into fc1's load, bias + ReLU of fc1 / fc2
+    folded into the next loads, rotation | translation heads in one launch -- against torch, and the rejected shapes"""
+    from scflow_amd._lib import ScflowHipError
+    n = 32
+    y3 = rnd((n, 128, 4, 4), 160, 1.5) + 0.3
+    gamma, beta = 1 + 0.1 * rnd((128,), 161), 0.1 * rnd((128,), 162)
+    w1, b1 = rnd((1024, 2048), 163, 2048 ** -0.5), rnd((1024,), 164, 0.1)
+    w2, b2 = rnd((256, 1024), 165, 1024 ** -0.5), rnd((256,), 166, 0.1)
+    wr, br, wt_, bt = rnd((126, 256), 167, 0.06), rnd((126,), 168, 0.1), rnd((63, 256), 169, 0.06), rnd((63,), 170, 0.1)
+    f = torch.relu(F.group_norm(y3.double(), 32, gamma.double(), beta.double(), 1e-5)).flatten(1)
+    h1 = torch.relu(F.linear(f, w1.double(), b1.double()))
+    h2 = torch.relu(F.linear(h1, w2.double(), b2.double()))
+    want_r, want_t = F.linear(h2, wr.double(), br.double()).float(), F.linear(h2, wt_.double(), bt.double()).float()
+    D = lambda t: t.to(DEV)
+    p1 = ops.fc_splitk(D(y3).view(n, -1), D(w1), gn=(32, 16, D(gamma), D(beta), 1e-5), slices=8)
+    close(torch.relu(p1.sum(0) + D(b1)), h1.float(), atol=5e-6, what='gn + fc1')
+    p2 = ops.fc_splitk(p1, D(w2), x_bias=D(b1), x_relu=True, slices=4)
+    got_r, got_t = ops.fc_splitk(p2, D(wr), D(br), x_bias=D(b2), x_relu=True, weight2=D(wt_), bias2=D(bt))
+    close(got_r, want_r, atol=3e-6, what='rotation head')
+    close(got_t, want_t, atol=3e-6, what='translation head')
+    # deterministic: the same bits run after run
+    again = ops.fc_splitk(p2, D(wr), D(br), x_bias=D(b2), x_relu=True, weight2=D(wt_), bias2=D(bt))
+    assert torch.equal(again[0], got_r) and torch.equal(again[1], got_t)
+    with pytest.raises(ScflowHipError):          # a K-slice of 300 features is not a multiple of 8
+        ops.fc_splitk(D(rnd((4, 600), 1)), D(rnd((8, 600), 2)), slices=2)
+    with pytest.raises(ScflowHipError):          # groups of 48 features do not tile a 256-feature slice
+        ops.fc_splitk(D(rnd((4, 768), 1)), D(rnd((8, 768), 2)), gn=(16, 16, D(gamma), D(beta), 1e-5), slices=3)
+
+
+def test_pose_head_fused_tail_vs_linear_launches():
+    """MultiClassPoseHead.features with the fused tail (default) against the GroupNorm + scf_linear launches"""
+    from scflow_amd.registry import HEAD, build_from_cfg
+    import scflow_amd
+    head = build_from_cfg(scflow_amd.scflow_model_cfg()['decoder']['pose_head_cfg'], HEAD)
+    torch.manual_seed(5)
+    for prm in head.parameters():
+        prm.data.copy_(torch.randn_like(prm) * (0.05 if prm.dim() > 1 else 0.1))
+    head = head.to(DEV)
+    for n in (1, 3, 32):
+        x = rnd((n, 224, 32, 32), 180 + n).to(DEV)
+        assert head.fc_plan() == (8, 4)
+        with ops.record_conv_kernels() as ran:
+            r1, t1 = head.features(x)
+        head.fused_fc = False
+        r0, t0 = head.features(x)
+        head.fused_fc = True
+        assert len(ran) == 3
+        close(r1, r0.cpu(), atol=2e-6, what=f'rotation rows, N={n}')
+        close(t1, t0.cpu(), atol=2e-6, what=f'translation rows, N={n}')
 
 
 @pytest.mark.parametrize('n,k', [(1, 256), (3, 256), (32, 250), (2, 2048)])

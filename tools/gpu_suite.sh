@@ -27,7 +27,7 @@ for stage in "$@"; do
     smoke)
       timeout 600 python __graft_entry__.py smoke 2>&1 | tail -3 | tee $OUT/smoke.log ;;
     bench)
-      timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 1500 $OUT/bench.json; tail -3 $OUT/bench.err ;;
+      timeout 900 python bench.py --top-layers 80 > $OUT/bench.json 2> $OUT/bench.err; tail -c 1500 $OUT/bench.json; tail -3 $OUT/bench.err ;;
     profiles)
       bash tools/collect_profiles.sh $TAG > $OUT/collect.log 2>&1; tail -5 $OUT/collect.log
       bash tools/lab/b32_profile.sh $TAG > $OUT/b32_profile.log 2>&1; tail -3 $OUT/b32_profile.log ;;
