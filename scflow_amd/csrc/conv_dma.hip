@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel
       const int py = fast_div(r, PW, rPW), pxs = r - py * PW;
       const int px = st == 1 ? pxs : (pxs >= PWh ? 2 * (pxs - PWh) + 1 : 2 * pxs);
       const int c = 8 * (gh >> 1) + 2 * s + (gh & 1);
-      const int iy = iy0 + py, ix = ix0 + px;
+      const int iy = (iy0 + py) * p.in_step, ix = (ix0 + px) * p.in_step;      // in_step 2: the dilated gather of a 1x1 / s2 layer
       ok = e < PE && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && px < p.PWin;
       o = (unsigned)(c * HWin + iy * p.W + ix) * 4u;
     }
@@ -495,6 +495,13 @@ static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st
 //   small grids  : the K-split tile (32 channels x 32 pixels, 4x the blocks), double buffer too
 int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st) {
   if ((!k.wp4 && !k.wp4s) || (k.stride != 1 && k.stride != 2) || k.w_ns != 0) return SCF_EUNSUPPORTED;
+  // A 1x1 / stride-2 / pad-0 layer (the ResNet shortcuts, resnet.py:721-730) reads every second row and column of
+  // its input and nothing else: it runs as a DENSE 1x1 over that sub-grid -- the gather table of the dword staging
+  // path doubles its row / column steps (in_step), everything behind the staging sees a stride-1 layer on an
+  // Ho x Wo map.  (Staged as a stride-2 patch it would move four times the floats it uses; on the register-staged
+  // kernel these layers ran at 23-37 TF/s.)
+  const bool dilated = k.T == 1 && k.stride == 2 && k.pad_h == 0 && k.pad_w == 0;
+  if (dilated) { k.stride = 1; k.in_step = 2; }
   // byte offsets inside a staged chunk (<= 32 channel planes) are 32-bit and must stay below SCF_DMA_OOB
   if ((long long)k.H * k.W * 32 * 4 >= 0x7fffffffLL) return SCF_EUNSUPPORTED;
   const int FC = 1 << k.fc_log2, FR = 32 / FC;
@@ -502,7 +509,7 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   int G = k.wp4 ? k.G4 : 0;
   int KC = 8 * G;
   // aligned dwordx4 patch staging (PX4): stride 1, rows and planes that keep 16-byte alignment
-  const bool px4_ok = FC * k.stride >= 4 && (k.W & 3) == 0 && (k.in0_ns & 3) == 0 &&
+  const bool px4_ok = !dilated && FC * k.stride >= 4 && (k.W & 3) == 0 && (k.in0_ns & 3) == 0 &&
                       ((uintptr_t)k.in0 & 15) == 0 &&
                       (!k.in1 || ((k.in1_ns & 3) == 0 && ((uintptr_t)k.in1 & 15) == 0));
   const bool px4_large = px4_ok && (SCF_PX4_MODE & 1), px4_small = px4_ok && (SCF_PX4_MODE & 2);
@@ -558,7 +565,7 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   const bool large = best >= 0 && best_blk >= slots;
   // dense 1x1 on a full grid: stride 1 runs here since the aligned-x4 staging (90 vs 78 TF/s for the
   // register-staged KC = 32 kernel); stride 2 would stage four times the columns it uses
-  if (k.T == 1 && large && (k.stride != 1 || !px4_large)) return SCF_EUNSUPPORTED;
+  if (k.T == 1 && large && !dilated && (k.stride != 1 || !px4_large)) return SCF_EUNSUPPORTED;
   if (!pix_ok) {
     // only the small-grid packing is present (dense 1x1): it is for small grids only -- fewer than
     // 256 blocks even with the smallest pixel-split tile (32 channels x 128 pixels)

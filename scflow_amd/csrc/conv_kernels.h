@@ -17,6 +17,7 @@ struct ConvK {
   int KH, KW, T, stride, pad_h, pad_w, KC, nchunk;
   int fc_log2, tiles_x, tiles_y, mblocks, PH, PW, PWin;
   int px_off;                // PX4 patch staging: columns between the 16-byte-aligned row start and ix0
+  int in_step;               // 2: a 1x1 / stride-2 layer run as a dense 1x1 over every second input row and column (conv_dma.hip)
   int wvec;
   int out_tile;              // 1: 8x4-float tiled output planes (correlation level 0)
   int ksplit;                // 32-pixel tile, the 4 waves split the k-steps (small grids)

@@ -430,7 +430,7 @@ static int conv_plan(const scf_conv_desc* d, ConvPlan* plan) {
   k.wp4s = d->wp_a4s; k.G4s = d->a4s_groups;
   k.wp4t = d->wp_a4t; k.G4t = d->a4t_groups;
   k.out_tile = d->out_tile8x4;
-  k.KH = d->KH; k.KW = d->KW; k.T = d->KH * d->KW; k.stride = d->stride;
+  k.KH = d->KH; k.KW = d->KW; k.T = d->KH * d->KW; k.stride = d->stride; k.in_step = 1;
   k.pad_h = d->pad_h; k.pad_w = d->pad_w; k.KC = d->KC;
   k.nchunk = (k.Cin + k.KC - 1) / k.KC;
   // shared packed weights carry zero rows up to nchunk*KC*T; per-sample "weights" (correlation

@@ -203,8 +203,8 @@ def choose_a4_groups(cin: int, kh: int, kw: int, stride: int) -> int:
     t = kh * kw
     if stride not in (1, 2) or cin < 8 or t >= 25:
         return 0
-    if t == 1:      # dense 1x1: 32-channel chunks, stride 1 only (stride 2 would stage 4x the columns it
-        return 4 if (stride == 1 and cin >= 64) else 0      # uses: the register-staged kernel keeps those)
+    if t == 1:      # dense 1x1: 32-channel chunks (stride 2 = the ResNet shortcuts: staged as a dense 1x1 over
+        return 4 if cin >= 64 else 0                        # every second row / column, conv_dma.hip)
     return 2 if t <= 5 else 1
 
 

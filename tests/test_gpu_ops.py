@@ -264,6 +264,12 @@ DMA_CASES = [
     (32, 64, 32, (3, 3), (1, 1), 32, 32),           # small grid (256 pixel-split blocks): K-split tile, 1024 blocks
     (48, 48, 32, (3, 3), (1, 1), 25, 32),           # the same with an odd number of rows
     (40, 40, 64, (1, 5), (0, 2), 18, 24),           # K-split with 16-channel chunks of a 1x5 layer, Wo = 24
+    # 1x1 / stride-2 shortcuts (resnet.py:721-730): a dense 1x1 over every second row / column (dilated gather)
+    (64, 64, 96, (1, 1), (0, 0), 128, 128, 2),      # full grid, (3,1) tile, 2 chunks of 32 channels
+    (32, 96, 128, (1, 1), (0, 0), 64, 64, 2),       # (2,1) tile, 3 chunks
+    (8, 72, 96, (1, 1), (0, 0), 33, 41, 2),         # odd sizes (Ho = 17, Wo = 21), short last chunk, ragged tiles
+    (2, 64, 96, (1, 1), (0, 0), 128, 128, 2),       # small grid: K-split tile on the dilated gather
+    (1, 96, 128, (1, 1), (0, 0), 60, 80, 2),        # batch 1, 30 x 40 map
 ]
 
 
