@@ -32,12 +32,38 @@ struct FcK {
   int act, N, K, Ks, slices, tiles1;
 };
 
+// GroupNorm + affine + ReLU of one half group (HSZ consecutive floats in LDS), the pair of threads of a group
+// exchange their partial sums with one shuffle
+template <int HSZ>
+__device__ __forceinline__ void fc_group_norm_half(float* xp, int gn_size, float eps, const float* gamma, const float* beta,
+                                                   int f0, int gn_hw) {
+  float v[HSZ];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < HSZ; ++i) { v[i] = xp[i]; s += v[i]; }
+  s += __shfl_xor(s, 1);
+  const float mean = s / (float)gn_size;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < HSZ; ++i) { const float a = v[i] - mean; q += a * a; }
+  q += __shfl_xor(q, 1);
+  const float rstd = 1.0f / sqrtf(q / (float)gn_size + eps);
+#pragma unroll
+  for (int i = 0; i < HSZ; ++i) {
+    const int c = (f0 + i) / gn_hw;
+    xp[i] = fmaxf((v[i] - mean) * rstd * gamma[c] + beta[c], 0.f);
+  }
+}
+
+// KS = the slice width the tile is laid out for (64, 128 or 256 floats per row); the real width p.Ks <= KS
+template <int KS>
 __global__ __launch_bounds__(256)
 void fc_splitk_kernel(FcK p) {
   extern __shared__ __attribute__((aligned(16))) float fc_lds[];
+  constexpr int P = FC_PITCH(KS), KQ = KS / 4, NLD = 32 * KQ / 256;     // float4 groups per row, loads per thread
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l32 = lane & 31;
-  const int Ks = p.Ks, P = FC_PITCH(Ks);
+  const int Ks = p.Ks;
   float* Wt = fc_lds;                 // [32][P]
   float* Xt = fc_lds + 32 * P;        // [32][P]
   // which weight matrix / output this feature tile belongs to
@@ -45,77 +71,101 @@ void fc_splitk_kernel(FcK p) {
   const float* W = p.W; const float* bias = p.bias; float* y = p.y; int O = p.O;
   if (ot >= p.tiles1) { ot -= p.tiles1; W = p.W2; bias = p.bias2; y = p.y2; O = p.O2; }
   const int o0 = ot * 32, ks0 = blockIdx.y * Ks, n0 = blockIdx.z * 32;
-  const int kq = Ks >> 2;             // float4 groups per row
 
-  // ---- stage the weight tile: rows o0 .. o0 + 31, columns ks0 .. ks0 + Ks - 1 (coalesced float4 reads) ----
-  for (int e = tid; e < 32 * kq; e += 256) {
-    const int r = e / kq, c4 = e - r * kq;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (o0 + r < O) v = *reinterpret_cast<const float4*>(W + (long long)(o0 + r) * p.K + ks0 + 4 * c4);
-    float* d = Wt + r * P + 4 * c4;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  // ---- operand tiles: every global load of the block is issued before the first one is used (a block is one
+  //      memory round trip, not a chain of them) ----
+  float4 wv[NLD], xv[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int e = tid + 256 * i, r = e / KQ, c4 = e - r * KQ;
+    wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (o0 + r < O && 4 * c4 < Ks) wv[i] = *reinterpret_cast<const float4*>(W + (long long)(o0 + r) * p.K + ks0 + 4 * c4);
   }
-  // ---- stage the activation tile: the sum of the producer's partial buffers in slice order, + bias, ReLU ----
-  for (int e = tid; e < 32 * kq; e += 256) {
-    const int r = e / kq, c4 = e - r * kq;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n0 + r < p.N) {
-      const float* xp = p.x + (long long)(n0 + r) * p.K + ks0 + 4 * c4;
-      v = *reinterpret_cast<const float4*>(xp);
-      for (int s = 1; s < p.parts; ++s) {
-        const float4 u = *reinterpret_cast<const float4*>(xp + (long long)s * p.part_stride);
-        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int e = tid + 256 * i, r = e / KQ, c4 = e - r * KQ;
+    xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n0 + r < p.N && 4 * c4 < Ks) xv[i] = *reinterpret_cast<const float4*>(p.x + (long long)(n0 + r) * p.K + ks0 + 4 * c4);
+  }
+  // the producer's other partial buffers, in slice order (two slices of loads in flight)
+  for (int s = 1; s < p.parts; s += 2) {
+    float4 u0[NLD], u1[NLD];
+    const bool two = s + 1 < p.parts;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + 256 * i, r = e / KQ, c4 = e - r * KQ;
+      u0[i] = u1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n0 + r < p.N && 4 * c4 < Ks) {
+        const float* xp = p.x + (long long)(n0 + r) * p.K + ks0 + 4 * c4 + (long long)s * p.part_stride;
+        u0[i] = *reinterpret_cast<const float4*>(xp);
+        if (two) u1[i] = *reinterpret_cast<const float4*>(xp + p.part_stride);
       }
-      if (p.x_bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.x_bias + ks0 + 4 * c4);
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-      }
-      if (p.x_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     }
-    float* d = Xt + r * P + 4 * c4;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      xv[i].x += u0[i].x; xv[i].y += u0[i].y; xv[i].z += u0[i].z; xv[i].w += u0[i].w;
+      if (two) { xv[i].x += u1[i].x; xv[i].y += u1[i].y; xv[i].z += u1[i].z; xv[i].w += u1[i].w; }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int e = tid + 256 * i, r = e / KQ, c4 = e - r * KQ;
+    float4 v = xv[i];
+    if (p.x_bias && 4 * c4 < Ks) {
+      const float4 b = *reinterpret_cast<const float4*>(p.x_bias + ks0 + 4 * c4);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (p.x_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (n0 + r >= p.N) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* dx = Xt + r * P + 4 * c4;
+    dx[0] = v.x; dx[1] = v.y; dx[2] = v.z; dx[3] = v.w;
+    float* dw = Wt + r * P + 4 * c4;
+    dw[0] = wv[i].x; dw[1] = wv[i].y; dw[2] = wv[i].z; dw[3] = wv[i].w;
   }
   __syncthreads();
   // ---- GroupNorm + affine + ReLU on the staged tile: a group = gn_size consecutive features of one sample, two-pass
-  //      statistics like group_norm_relu_kernel; (sample, group) pairs are dealt to pairs of threads ----
+  //      statistics like group_norm_relu_kernel; a (sample, group) pair is dealt to a pair of threads ----
   if (p.gn_size > 0) {
     const int gpr = Ks / p.gn_size, ngroups = 32 * gpr, hsz = p.gn_size >> 1;
     for (int gi = tid >> 1; gi < ngroups; gi += 128) {
       const int r = gi / gpr, g = gi - r * gpr;
       float* xp = Xt + r * P + g * p.gn_size + (tid & 1) * hsz;
-      float s = 0.f;
-      for (int i = 0; i < hsz; ++i) s += xp[i];
-      s += __shfl_xor(s, 1);
-      const float mean = s / (float)p.gn_size;
-      float q = 0.f;
-      for (int i = 0; i < hsz; ++i) { const float a = xp[i] - mean; q += a * a; }
-      q += __shfl_xor(q, 1);
-      const float rstd = 1.0f / sqrtf(q / (float)p.gn_size + p.eps);
       const int f0 = ks0 + g * p.gn_size + (tid & 1) * hsz;      // global feature index of xp[0]
-      for (int i = 0; i < hsz; ++i) {
-        const int c = (f0 + i) / p.gn_hw;
-        xp[i] = fmaxf((xp[i] - mean) * rstd * p.gamma[c] + p.beta[c], 0.f);
+      if (hsz == 32) {
+        fc_group_norm_half<32>(xp, p.gn_size, p.eps, p.gamma, p.beta, f0, p.gn_hw);
+      } else {
+        float s = 0.f;
+        for (int i = 0; i < hsz; ++i) s += xp[i];
+        s += __shfl_xor(s, 1);
+        const float mean = s / (float)p.gn_size;
+        float q = 0.f;
+        for (int i = 0; i < hsz; ++i) { const float a = xp[i] - mean; q += a * a; }
+        q += __shfl_xor(q, 1);
+        const float rstd = 1.0f / sqrtf(q / (float)p.gn_size + p.eps);
+        for (int i = 0; i < hsz; ++i) {
+          const int c = (f0 + i) / p.gn_hw;
+          xp[i] = fmaxf((xp[i] - mean) * rstd * p.gamma[c] + p.beta[c], 0.f);
+        }
       }
     }
     __syncthreads();
   }
 
-  // ---- contraction: wave w takes k in [w Ks / 4, (w + 1) Ks / 4) ----
+  // ---- contraction: wave w takes k in [w KS / 4, (w + 1) KS / 4) (columns past Ks hold zeros) ----
   fc_f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int kw = Ks >> 2;
+  constexpr int kw = KS / 4;
   const float* ap = Wt + l32 * P + wave * kw + half;
   const float* bp = Xt + l32 * P + wave * kw + half;
-  int k = 0;
-  for (; k + 8 <= kw; k += 8) {             // operands of four k-steps requested together
+#pragma unroll
+  for (int k = 0; k < kw; k += 8) {           // operands of four k-steps requested together
     const float a0 = ap[k], b0 = bp[k], a1 = ap[k + 2], b1 = bp[k + 2], a2 = ap[k + 4], b2 = bp[k + 4], a3 = ap[k + 6], b3 = bp[k + 6];
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc, 0, 0, 0);
   }
-  for (; k < kw; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bp[k], acc, 0, 0, 0);
   __syncthreads();                    // the operand tiles are dead: their LDS holds the four partial tiles now
   float* red = fc_lds;                // [4 waves][16][64]
 #pragma unroll
@@ -165,14 +215,19 @@ extern "C" int scf_fc_splitk(const scf_fc_desc* d, scf_stream_t stream) {
   const int tiles = p.tiles1 + (d->O2 + 31) / 32;
   const int ntiles = (d->N + 31) / 32;
   if (ntiles > 65535) return SCF_EUNSUPPORTED;
-  size_t lds = (size_t)2 * 32 * FC_PITCH(Ks) * sizeof(float);
+  const int KS = Ks <= 64 ? 64 : Ks <= 128 ? 128 : 256;       // tile layout (columns past Ks are zero-filled)
+  size_t lds = (size_t)2 * 32 * FC_PITCH(KS) * sizeof(float);
   if (lds < (size_t)4 * 16 * 64 * sizeof(float)) lds = (size_t)4 * 16 * 64 * sizeof(float);
-  if (lds > 64 * 1024) {
-    static std::atomic<unsigned long long> raised;
-    const int rc = scf_raise_dynamic_lds(raised, (const void*)fc_splitk_kernel, 2 * 32 * FC_PITCH(FC_KS_MAX) * (int)sizeof(float));
+  const dim3 grid((unsigned)tiles, (unsigned)d->slices, (unsigned)ntiles);
+  if (KS == 256) {
+    static std::atomic<unsigned long long> raised;      // 65.8 KB of dynamic LDS
+    const int rc = scf_raise_dynamic_lds(raised, (const void*)fc_splitk_kernel<256>, (int)lds);
     if (rc != SCF_OK) return rc;
+    scf_launch(fc_splitk_kernel<256>, grid, dim3(256), lds, scf_stream(stream), p);
+  } else if (KS == 128) {
+    scf_launch(fc_splitk_kernel<128>, grid, dim3(256), lds, scf_stream(stream), p);
+  } else {
+    scf_launch(fc_splitk_kernel<64>, grid, dim3(256), lds, scf_stream(stream), p);
   }
-  scf_launch(fc_splitk_kernel, dim3((unsigned)tiles, (unsigned)d->slices, (unsigned)ntiles), dim3(256), lds,
-             scf_stream(stream), p);
   return scf_launch_status();
 }
