@@ -42,7 +42,7 @@ __device__ __forceinline__ void do_x(float& v0, float& v1, f32x2& p0, f32x2& p1,
 
 // mode 0: partner (waves 4-7 run X only, waves 0-3 MFMA only); mode 1: same wave [MFMA, k x X], 4 waves;
 // mode 2: all 8 waves run [MFMA, k x X]
-template <int X, int K>
+template <int X, int K, int G = 1>
 __global__ __launch_bounds__(512, 1) void co_kernel(unsigned long long* out, int iters, int mode, const float* gbuf, float a, float b) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -81,12 +81,15 @@ __global__ __launch_bounds__(512, 1) void co_kernel(unsigned long long* out, int
   } else {
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[u], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+      for (int u = 0; u < 4; u += G) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          acc[u + g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[u + g], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if (mode != 0) {
 #pragma unroll
-          for (int k = 0; k < K; ++k) do_x<X>(v0, v1, p0, p1, lds, ldsa, rs, voff, acc2, a, b);
+          for (int k = 0; k < K * G; ++k) do_x<X>(v0, v1, p0, p1, lds, ldsa, rs, voff, acc2, a, b);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -102,45 +105,54 @@ __global__ __launch_bounds__(512, 1) void co_kernel(unsigned long long* out, int
   if (lane == 0) out[blockIdx.x * 8 + wave] = (mode == 0 && !mf) ? (unsigned long long)xcount : t1 - t0;
 }
 
-template <int X, int K>
+template <int X, int K, int G = 1>
 void run(int mode, const char* what) {
   int dev; hipGetDevice(&dev); hipDeviceProp_t pr; hipGetDeviceProperties(&pr, dev);
   const int grid = pr.multiProcessorCount;
   unsigned long long* out; hipMalloc(&out, (grid * 8 + 8192) * 8);
   float* gbuf; hipMalloc(&gbuf, 1 << 20); hipMemset(gbuf, 0, 1 << 20);
   const int iters = 2000;
-  hipFuncSetAttribute((const void*)co_kernel<X, K>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  hipFuncSetAttribute((const void*)co_kernel<X, K, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   std::vector<unsigned long long> h(grid * 8);
-  double best = 1e30, bestx = 0;
+  double best = 1e30, bestx = 0, besto = 0;
   for (int rep = 0; rep < 3; ++rep) {
     hipMemset(out, 0, grid * 8 * 8);
-    co_kernel<X, K><<<grid, 512, 48 * 1024>>>(out, iters, mode, gbuf, 1.0f, 0.5f);
+    co_kernel<X, K, G><<<grid, 512, 48 * 1024>>>(out, iters, mode, gbuf, 1.0f, 0.5f);
     hipDeviceSynchronize();
     hipMemcpy(h.data(), out, grid * 8 * 8, hipMemcpyDeviceToHost);
-    // median over blocks of wave 0 (an MFMA wave) and wave 4 (the partner)
-    std::vector<double> m, x;
-    for (int b = 0; b < grid; ++b) { m.push_back((double)h[b * 8]); x.push_back((double)h[b * 8 + 4]); }
-    std::sort(m.begin(), m.end()); std::sort(x.begin(), x.end());
-    if (m[grid / 2] < best) { best = m[grid / 2]; bestx = x[grid / 2]; }
+    // median over blocks: the slower and the faster of the two waves of SIMD 0 (waves 0 and 4), and the partner's count
+    std::vector<double> m, x, o;
+    for (int b = 0; b < grid; ++b) {
+      const double w0 = (double)h[b * 8], w4 = (double)h[b * 8 + 4];
+      m.push_back(mode == 2 ? std::max(w0, w4) : w0); o.push_back(std::min(w0, w4)); x.push_back(w4);
+    }
+    std::sort(m.begin(), m.end()); std::sort(x.begin(), x.end()); std::sort(o.begin(), o.end());
+    if (m[grid / 2] < best) { best = m[grid / 2]; bestx = x[grid / 2]; besto = o[grid / 2]; }
   }
-  const double per_mfma = best / (iters * 4.0);
+  const double n = iters * 4.0;
   if (mode == 0)
-    printf("partner    %-30s : %6.1f clk per MFMA of the MFMA wave; the partner issued %6.2f X per MFMA (%5.1f clk per X)\n", xname[X], per_mfma,
-           bestx * 16.0 / (iters * 4.0), bestx > 0 ? best / (bestx * 16.0) : 0.0);
+    printf("partner    %-28s : %6.1f clk per MFMA of the MFMA wave; the partner issued %6.2f X per MFMA\n", xname[X], best / n, bestx * 16.0 / n);
+  else if (mode == 1)
+    printf("one wave   [%d MFMA + %2d x %-28s] : %6.1f clk per MFMA  (%+5.1f; %4.1f per X)\n", G, K * G, xname[X], best / n, best / n - 64.0,
+           K ? (best / n - 64.0) / K : 0.0);
   else
-    printf("%s %-30s k=%d : %6.1f clk per [MFMA + k x X] group of one wave (%+.1f vs MFMA alone)\n", what, xname[X], K, per_mfma, per_mfma - (mode == 1 ? 64.0 : 128.0));
+    printf("two waves  [%d MFMA + %2d x %-28s] : %6.1f clk per MFMA of the SIMD (both waves done; the first after %5.1f%% of that)  (%+5.1f; %4.1f per X)\n",
+           G, K * G, xname[X], best / (2 * n), 100.0 * besto / best, best / (2 * n) - 64.0, K ? (best / (2 * n) - 64.0) / K : 0.0);
   hipFree(out); hipFree(gbuf);
 }
 
 int main() {
-  // s_memtime counts at the constant 100 MHz on this part?  Calibrate: MFMA alone must read 64 shader clocks.
-  run<X_NONE, 0>(1, "same-wave ");
-  run<X_NONE, 0>(2, "two waves ");
-  run<X_FMA, 0>(0, ""); run<X_PKFMA, 0>(0, ""); run<X_DSREAD64, 0>(0, ""); run<X_DSREAD128, 0>(0, ""); run<X_DSREAD2_CONFLICT, 0>(0, "");
-  run<X_DMA, 0>(0, ""); run<X_SNOP, 0>(0, ""); run<X_MFMA, 0>(0, "");
-  run<X_FMA, 1>(1, "same-wave "); run<X_FMA, 4>(1, "same-wave "); run<X_PKFMA, 4>(1, "same-wave "); run<X_DSREAD64, 2>(1, "same-wave ");
-  run<X_DSREAD2_CONFLICT, 2>(1, "same-wave "); run<X_DMA, 1>(1, "same-wave "); run<X_SNOP, 4>(1, "same-wave ");
-  run<X_FMA, 4>(2, "two waves "); run<X_PKFMA, 4>(2, "two waves "); run<X_DSREAD64, 2>(2, "two waves "); run<X_DSREAD2_CONFLICT, 2>(2, "two waves ");
-  run<X_DSREAD128, 2>(2, "two waves "); run<X_DMA, 1>(2, "two waves "); run<X_SNOP, 4>(2, "two waves "); run<X_FMA, 8>(2, "two waves "); run<X_DSREAD64, 4>(2, "two waves ");
+  run<X_NONE, 0>(1, ""); run<X_NONE, 0>(2, "");
+  run<X_FMA, 0>(0, ""); run<X_DSREAD64, 0>(0, ""); run<X_SNOP, 0>(0, ""); run<X_MFMA, 0>(0, "");
+  // one wave per SIMD
+  run<X_FMA, 1>(1, ""); run<X_FMA, 2>(1, ""); run<X_FMA, 4>(1, ""); run<X_FMA, 8>(1, ""); run<X_PKFMA, 1>(1, ""); run<X_PKFMA, 4>(1, "");
+  run<X_DSREAD64, 1>(1, ""); run<X_DSREAD64, 2>(1, ""); run<X_DSREAD64, 4>(1, ""); run<X_DSREAD2_CONFLICT, 2>(1, ""); run<X_DSREAD128, 2>(1, "");
+  run<X_DMA, 1>(1, ""); run<X_SNOP, 1>(1, ""); run<X_SNOP, 4>(1, "");
+  run<X_FMA, 1, 2>(1, ""); run<X_FMA, 4, 2>(1, ""); run<X_FMA, 4, 4>(1, ""); run<X_DSREAD64, 2, 2>(1, ""); run<X_DSREAD64, 2, 4>(1, "");
+  // two waves per SIMD, aggregate
+  run<X_FMA, 1>(2, ""); run<X_FMA, 2>(2, ""); run<X_FMA, 4>(2, ""); run<X_FMA, 8>(2, ""); run<X_PKFMA, 1>(2, ""); run<X_PKFMA, 4>(2, "");
+  run<X_DSREAD64, 1>(2, ""); run<X_DSREAD64, 2>(2, ""); run<X_DSREAD64, 4>(2, ""); run<X_DSREAD2_CONFLICT, 2>(2, ""); run<X_DSREAD128, 2>(2, "");
+  run<X_DMA, 1>(2, ""); run<X_SNOP, 1>(2, ""); run<X_SNOP, 4>(2, "");
+  run<X_FMA, 1, 2>(2, ""); run<X_FMA, 4, 2>(2, ""); run<X_FMA, 4, 4>(2, ""); run<X_DSREAD64, 2, 2>(2, ""); run<X_DSREAD64, 2, 4>(2, ""); run<X_PKFMA, 2, 2>(2, "");
   return 0;
 }
