@@ -405,9 +405,6 @@ void conv_wino_kernel(ConvK p, WinoK q) {
 // Needs an even number of channel fragments (the dispatch keeps other layers on the pair kernel).
 // ===================================================================================================
 #define WQ_NPI(TW, PX4) ((PX4) ? 1 : ((TW) == 2 ? 3 : 4))
-#ifndef WQ_SCHED
-#define WQ_SCHED 0          // instruction placement inside a chunk: 0 one gap per MFMA, 1 grouped (see the chunk lambda)
-#endif
 
 template <int TW, bool PX4>
 __global__ __launch_bounds__(256 * TW, TW == 1 ? 2 : 1)
@@ -566,25 +563,8 @@ void conv_wino_q_kernel(ConvK p, WinoK q) {
     __builtin_amdgcn_sched_barrier(0);
     int s3 = s1 + 2;
     s3 = s3 >= 3 ? s3 - 3 : s3;
-#if WQ_SCHED == 1
-    // Fewer, larger gaps in the MFMA stream (tools/lab/coissue.hip: every interruption of a wave's MFMA stream costs
-    // the SIMD ~9 cycles whatever fills it, LDS reads are otherwise free, VALU / DMA instructions cost their issue
-    // time): the 16 MFMAs run as groups of 2-2-4-4-4 with the non-MFMA work in the four gaps
-    WQ_M(0, 0) WQ_M(1, 0)
-    if (!WN_LAB(1)) { win_load(pcb, 0); win_load(pcb, 1); }
-    __builtin_amdgcn_sched_barrier(0);
-    WQ_M(2, 0) WQ_M(3, 0)
-    if (!WN_LAB(2)) { issue_u(s3); issue_p(s3); }
-    __builtin_amdgcn_sched_barrier(0);
-    WQ_M(4, 0) WQ_M(5, 0) WQ_M(6, 0) WQ_M(7, 0)
-    if (!WN_LAB(5)) {
-#pragma unroll
-      for (int x = 0; x < 8; ++x) an[x] = *reinterpret_cast<const wn_f32x2*>(uc + (x >> 2) * 2048 + (x & 3) * 128);
-    }
-    if (!WN_LAB(1)) { win_transform(bn, 0); win_transform(bn, 1); }
-    __builtin_amdgcn_sched_barrier(0);
-    WQ_M(0, 1) WQ_M(1, 1) WQ_M(2, 1) WQ_M(3, 1) WQ_M(4, 1) WQ_M(5, 1) WQ_M(6, 1) WQ_M(7, 1)
-#else
+    // (measured, r4: the same work as groups of 2-2-4-8 MFMAs with the non-MFMA instructions in three gaps -- what
+    // tools/lab/coissue.hip suggests -- runs within +-2 % of this placement on every layer shape; not kept)
     WQ_M(0, 0)
     if (!WN_LAB(1)) win_load(pcb, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -611,7 +591,6 @@ void conv_wino_q_kernel(ConvK p, WinoK q) {
     if (!WN_LAB(1)) win_transform(bn, 1);
     __builtin_amdgcn_sched_barrier(0);
     WQ_M(2, 1) WQ_M(3, 1) WQ_M(4, 1) WQ_M(5, 1) WQ_M(6, 1) WQ_M(7, 1)
-#endif
 #undef WQ_M
     scf_wait_vmcnt_imm<GRP>();
     if (!WN_LAB(4)) __syncthreads();

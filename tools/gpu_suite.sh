@@ -6,7 +6,8 @@
 #   measured   the tests that print [measured] lines (Winograd stress, GRU drift, configs[2]/[4]) with -s
 #   smoke      __graft_entry__.smoke()
 #   bench      python bench.py (defaults)
-#   profiles   tools/collect_profiles.sh <tag> + the batch-32-only kernel trace
+#   profiles   tools/collect_profiles.sh <tag>, the counter summaries, the batch-32-only kernel trace, tools/lab/coissue
+#              (tools/publish_profiles.py <tag> then copies what is cited into profiles/)
 set -u
 TAG=$1; shift
 R=$GRAFT_REPO_ROOT
@@ -28,9 +29,13 @@ for stage in "$@"; do
       timeout 600 python __graft_entry__.py smoke 2>&1 | tail -3 | tee $OUT/smoke.log ;;
     bench)
       timeout 900 python bench.py --top-layers 80 > $OUT/bench.json 2> $OUT/bench.err; tail -c 1500 $OUT/bench.json; tail -3 $OUT/bench.err ;;
-    profiles)
-      bash tools/collect_profiles.sh $TAG > $OUT/collect.log 2>&1; tail -5 $OUT/collect.log
-      bash tools/lab/b32_profile.sh $TAG > $OUT/b32_profile.log 2>&1; tail -3 $OUT/b32_profile.log ;;
+    profiles)      # rocprofv3 passes of bench.py (stats f32 / f16x3, FETCH, WRITE, SQ MFMA), summaries, batch-32-only trace, co-issue lab
+      bash tools/collect_profiles.sh $TAG > $OUT/collect.log 2>&1; tail -2 $OUT/collect.log
+      P=$R/gpurun_out/profiles_$TAG
+      python tools/summarize_mfma.py $(find $P/pmc_mfma -name "*counter_collection.csv" | head -1) $(find $P/pmc_mfma -name "*kernel_trace.csv" | head -1) $OUT/mfma_pmc.json $TAG 2>&1 | tail -14
+      python tools/summarize_pmc.py $(find $P/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $P/pmc_write -name "*counter_collection.csv" | head -1) $OUT/lookup_pmc.json $TAG $(find $P/stats_f32 -name "*kernel_trace.csv" | head -1) > $OUT/summarize_pmc.log 2>&1; grep -n "traffic_bytes\|avg_us" $OUT/summarize_pmc.log
+      bash tools/lab/b32_profile.sh ${TAG}_b32 > /dev/null 2>&1
+      [ -x tools/lab/bin/coissue ] && timeout 120 tools/lab/bin/coissue > $OUT/coissue.txt 2>&1 ;;
     *) echo "unknown stage $stage" ;;
   esac
 done

@@ -35,7 +35,7 @@ calls = collections.Counter()
 seen = set()
 for r in csv.DictReader(open(pmc_csv)):
     k = short(r['Kernel_Name'])
-    if not any(t in k for t in ('corr_gemm', 'conv_dma', 'conv_mfma', 'conv_f16x3', 'conv_taps', 'conv_wino')):
+    if not any(t in k for t in ('corr_gemm', 'conv_dma', 'conv_mfma', 'conv_f16x3', 'conv_taps', 'conv_wino', 'fc_splitk')):
         continue
     cnt[k][r['Counter_Name']] += float(r['Counter_Value'])
     key = (r['Dispatch_Id'], k)
