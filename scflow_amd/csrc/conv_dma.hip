@@ -493,6 +493,11 @@ static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st
 // shapes that exceed the DMA kernel's staging budget).
 //   large grids  (>= 2 blocks per CU): pixel-split tiles, double buffer (co-resident blocks overlap)
 //   small grids  : the K-split tile (32 channels x 32 pixels, 4x the blocks), double buffer too
+// measurement knob (scf_tune(SCF_TUNE_DMA_FORCE_KSPLIT, 1)): every launch takes the K-split tile (32 channels x 32
+// pixels per block: each block stages the full weight slab of its 32 output channels for 32 pixels)
+static std::atomic<int> g_force_ksp{0};
+int scf_dma_force_ksplit_set(int v) { return g_force_ksp.exchange(v); }
+
 int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st) {
   if ((!k.wp4 && !k.wp4s) || (k.stride != 1 && k.stride != 2) || k.w_ns != 0) return SCF_EUNSUPPORTED;
   // A 1x1 / stride-2 / pad-0 layer (the ResNet shortcuts, resnet.py:721-730) reads every second row and column of
@@ -582,7 +587,7 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   // several small blocks per CU hide each other's memory round trips better than one block with a
   // deep ring does (measured, graph replay of get_pose: batch 1 3.84 -> 3.45 ms, batch 4 6.55 -> 5.40,
   // batch 8 8.95 -> 8.14; the 4- and 6-deep rings of round 2 lost at every batch size).
-  bool use_ksp = !large;
+  bool use_ksp = !large || g_force_ksp.load(std::memory_order_relaxed) != 0;
   const ConvK k_in = k;
   const long long ksp_blk = (long long)N * ((k.Ho + FR - 1) / FR) * ((k.Wo + FC - 1) / FC) * frags_m;
   // TINY grids (no more blocks than CUs: every block alone on its CU): a launch is a chain of one
