@@ -59,7 +59,8 @@ int scf_conv_log_enable(int capacity);
  * SCF_EINVAL for an unknown key.  0 always means "the dispatch's own choice". */
 enum {
   SCF_TUNE_WINO_VARIANT = 1,  /* F(2x2,3x3): 1 = pair kernel, 2 / 3 = quarter-domain kernel with 4 / 8 waves */
-  SCF_TUNE_DMA_FORCE_KSPLIT = 2 /* 1: the LDS-DMA kernel takes its K-split tile (32 channels x 32 pixels per block) on every grid */
+  SCF_TUNE_DMA_FORCE_KSPLIT = 2, /* 1: the LDS-DMA kernel takes its K-split tile (32 channels x 32 pixels per block) on every grid */
+  SCF_TUNE_DMA_KSPLIT_GROUPS = 3 /* 1: K-split blocks keep one wave group (no intra-block split of the chunk chain) */
 };
 int scf_tune(int key, int value);
 int scf_conv_log_read(scf_conv_log_entry* out, int max_entries);

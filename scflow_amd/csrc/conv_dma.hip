@@ -121,18 +121,24 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) { scf_wait_vmcnt_le(n); }
 //         ~125 vs 4 x 117 cycles of texture-path time per KiB).  B operands are then read with four
 //         ds_read_b32 per (tap, group) step instead of one ds_read_b128 (stride 2: every second
 //         column, a 2-way bank conflict the MFMA-bound loop does not notice).
-template <int WM, int WN, int NST = 2, bool KSP = false, bool PX4 = false>
-__global__ __launch_bounds__(256, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel(ConvK p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+// NG    : (K-split tile only, r4) wave GROUPS per block: group g stages and contracts chunks g, g + NG, ... in its own
+//         double buffer, so a block's serial chain of "one memory round trip per chunk" is 1 / NG as long -- the
+//         split of K across more waves of the SAME block (the partial sums already meet in LDS at the end), for
+//         grids with at most one block per CU (batch 1: a launch was 8 ... 16 such round trips whatever it computed).
+template <int WM, int WN, int NST = 2, bool KSP = false, bool PX4 = false, int NG = 1>
+__global__ __launch_bounds__(256 * NG, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel(ConvK p) {
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
   static_assert(!KSP || (WM == 1 && WN == 1), "K-split tile is one 32x32 fragment");
+  static_assert(NG == 1 || (KSP && NST == 2), "wave groups: K-split tile, double buffer");
   constexpr int BM = WM * 32;
   constexpr int NFRAG = KSP ? 1 : WN * 4;
   constexpr int PU = PX4 ? SCF_DMA_PU_X4 : KSP ? SCF_DMA_PU_KSP : SCF_DMA_PU;
 
   __builtin_amdgcn_s_setprio(3);       // setup / staging / epilogue instructions go first
   CTRACE(0);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x & 255, lane = tid & 63;            // thread / wave index inside the wave group
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) & 3);
+  const int grp = NG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
   const int l32 = lane & 31, half = lane >> 5;
 
   // block-uniform tile coordinates, pinned to SGPRs (the integer divisions are expanded on the
@@ -160,6 +166,7 @@ __global__ __launch_bounds__(256, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel
   const int WF4 = NIT * 2 * BM;        // weight float4 per chunk
   const int PE = KC * PHW;             // patch floats per chunk
   const int bufsz = WF4 * 4 + PE;      // floats per buffer (multiple of 4)
+  float* const lds = lds_all + grp * (NST * bufsz);      // this wave group's ring
 
   // weights: float4 e = tid + 256u of the chunk's [NIT*2 rows][BM] slab out of [rows][Mld4]
   constexpr int WU = KSP ? SCF_DMA_WU_KSP : SCF_DMA_WU;
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(256, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel
       bdma_slot<true>(wrs, woff[u], wl0 + u * 4096, wrem - u * 256);
   };
   CTRACE(1);
-  if (p.nchunk > 0) stage_w(0, 0);
+  if (grp < p.nchunk) stage_w(grp, 0);
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- gather table: LDS patch float e = tid + 256u <-> (group g, half h, py, px, s) ----
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(256, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel
   // the epilogue -- a launch of one round of blocks has all its epilogues at the same moment, and
   // every byte they read or write there is unoverlapped HBM time at the end of the kernel.
   if (p.res && (p.mode == SCF_CONV_GRU_ZR || p.mode == SCF_CONV_GRU_Q) && p.out_div == 1.0f && !p.out_tile) {
-    if (!KSP || wave == 0) {
+    if (!KSP || (wave == 0 && grp == 0)) {
       const float* rn = p.res + (long long)n * p.res_ns;
       const int HWo = p.Ho * p.Wo;
 #pragma unroll
@@ -301,14 +308,19 @@ __global__ __launch_bounds__(256, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel
   // DMA instructions this wave issues per chunk (the same for every chunk): vmcnt bookkeeping
   const int cnt = __builtin_amdgcn_readfirstlane(max(0, (prem0 + 255) >> 8) + max(0, (wrem0 + 255) >> 8));
 
-  if (p.nchunk > 0) stage_p(0, 0);     // (its weights went out before the table)
+  if (grp < p.nchunk) stage_p(grp, 0);   // (its weights went out before the table)
 #pragma unroll
   for (int c = 1; c < NST - 1; ++c)
     if (c < p.nchunk) stage(c, c);
   CTRACE(2);
 
   int buf = 0;                         // ring slot of the current chunk
-  for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+  // wave group g walks chunks g, g + NG, ...; every group runs the same number of iterations (the barriers are the
+  // block's), an iteration past the group's last chunk does nothing between them
+  const int niter = (p.nchunk + NG - 1) / NG;
+  for (int iter = 0; iter < niter; ++iter) {
+    const int chunk = iter * NG + grp;
+    const bool live = NG == 1 || chunk < p.nchunk;
     __builtin_amdgcn_s_setprio(3);
     // this wave's DMA of THIS chunk has landed; up to NST-2 later chunks stay in flight
     if (NST == 2) {
@@ -320,9 +332,10 @@ __global__ __launch_bounds__(256, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel
     CTRACE(4 + chunk * 4);
     __syncthreads();                                   // everyone's has; previous MFMA phase done
     CTRACE(5 + chunk * 4);
-    if (!CLAB(0) && chunk + NST - 1 < p.nchunk) stage(chunk + NST - 1, buf == 0 ? NST - 1 : buf - 1);
+    if (!CLAB(0) && chunk + NG * (NST - 1) < p.nchunk) stage(chunk + NG * (NST - 1), buf == 0 ? NST - 1 : buf - 1);
     CTRACE(6 + chunk * 4);
     __builtin_amdgcn_s_setprio(0);                     // the MFMA stream yields to the other waves
+    if (!live) continue;
 
     const f32x4* wl = reinterpret_cast<const f32x4*>(lds + buf * bufsz) + half * BM + l32;
     const f32x4* pl = reinterpret_cast<const f32x4*>(lds + buf * bufsz + WF4 * 4);
@@ -426,16 +439,19 @@ __global__ __launch_bounds__(256, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel
     // ---- cross-wave reduction (fixed order) + epilogue: wave w finalises accumulator rows 4w..4w+3 ----
     __builtin_amdgcn_s_setprio(3);
     __syncthreads();                          // every wave is done reading the ring
-    float* red = lds;                         // [4 waves][16 regs][64 lanes] = 16 KB
+    float* red = lds_all;                     // [4 NG waves][16 regs][64 lanes] = 16 KB per wave group
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[0][0][r] + acc2[r];
+    for (int r = 0; r < 16; ++r) red[((grp * 4 + wave) * 16 + r) * 64 + lane] = acc[0][0][r] + acc2[r];
     __syncthreads();
+    if (grp != 0) return;                     // group 0 adds the partial tiles in wave order and finishes them
     float v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = 4 * wave + q;
-      v[q] = ((red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) +
-              red[(2 * 16 + r) * 64 + lane]) + red[(3 * 16 + r) * 64 + lane];
+      float sum = red[r * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < 4 * NG; ++w) sum += red[(w * 16 + r) * 64 + lane];
+      v[q] = sum;
     }
     const int oy = ty0 + fr, ox = tx0 + fc;
     if (oy < p.Ho && ox < p.Wo) {
@@ -469,7 +485,7 @@ __global__ __launch_bounds__(256, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel
 
 #define SCF_DMA_LDS_DEEP (144 * 1024)  // tiny grids (one block per CU): 32-channel chunks of 3x3 layers
 
-template <int WM, int WN, int NST = 2, bool KSP = false, bool PX4 = false>
+template <int WM, int WN, int NST = 2, bool KSP = false, bool PX4 = false, int NG = 1>
 static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
   if (lds_bytes > 64 * 1024) {       // opt in to > 64 KiB of dynamic LDS: once per instantiation AND device
     static std::atomic<unsigned long long> raised{0};      // bit d: done on device d
@@ -477,14 +493,14 @@ static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st
     if (hipGetDevice(&dev) != hipSuccess) return SCF_ELAUNCH;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(raised.load(std::memory_order_relaxed) & bit)) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WM, WN, NST, KSP, PX4>),
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WM, WN, NST, KSP, PX4, NG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (NST == 2 && !KSP) ? SCF_DMA_LDS_MAX : SCF_DMA_LDS_DEEP) != hipSuccess)
         return SCF_ELAUNCH;
       raised.fetch_or(bit, std::memory_order_relaxed);
     }
   }
-  scf_launch((conv_dma_kernel<WM, WN, NST, KSP, PX4>), dim3(nblk), dim3(256), lds_bytes, st, k);
+  scf_launch((conv_dma_kernel<WM, WN, NST, KSP, PX4, NG>), dim3(nblk), dim3(256 * NG), lds_bytes, st, k);
   return scf_launch_status();
 }
 
@@ -497,6 +513,9 @@ static int launch_dma(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st
 // pixels per block: each block stages the full weight slab of its 32 output channels for 32 pixels)
 static std::atomic<int> g_force_ksp{0};
 int scf_dma_force_ksplit_set(int v) { return g_force_ksp.exchange(v); }
+// scf_tune(SCF_TUNE_DMA_KSPLIT_GROUPS, 1): K-split blocks keep ONE wave group (the r3 kernel) on every grid
+static std::atomic<int> g_ksp_groups{0};
+int scf_dma_ksplit_groups_set(int v) { return g_ksp_groups.exchange(v); }
 
 int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st) {
   if ((!k.wp4 && !k.wp4s) || (k.stride != 1 && k.stride != 2) || k.w_ns != 0) return SCF_EUNSUPPORTED;
@@ -578,7 +597,7 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
     if (blk11 >= 256) return SCF_EUNSUPPORTED;
   }
   if (KC) k.nchunk = (k.Cin + KC - 1) / KC;
-  int WM = 1, WN = 1;
+  int WM = 1, WN = 1, ngroups = 1;
   bool ksp = false, px4 = false;
   long long nblk = 0;
   size_t ldsb = 0;
@@ -614,10 +633,14 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
     const int PW = pitch(PWin, px4);
     const long long PE = (long long)KC * PH * PW, WF4 = (long long)k.T * G * 2 * 32;
     const size_t stage_b = (size_t)(WF4 * 4 + PE) * sizeof(float);
-    ldsb = stage_b * 2;
-    if (ldsb < 16 * 1024) ldsb = 16 * 1024;            // cross-wave reduction area
+    // at most one block per CU and a chain of >= 4 chunks: two wave groups per block walk alternate chunks
+    // (conv_dma_kernel NG = 2: half the serial chain, the partial sums meet in LDS as before)
+    ngroups = (ksp_blk <= scf_cu_count() && k.nchunk >= 4 && stage_b * 4 <= SCF_DMA_LDS_DEEP &&
+               g_ksp_groups.load(std::memory_order_relaxed) != 1) ? 2 : 1;
+    ldsb = stage_b * 2 * ngroups;
+    if (ldsb < (size_t)ngroups * 16 * 1024) ldsb = (size_t)ngroups * 16 * 1024;      // cross-wave reduction area
     if (PE > (px4 ? 1024 * SCF_DMA_PU_X4 : 256 * SCF_DMA_PU_KSP) || WF4 > 256 * SCF_DMA_WU_KSP ||
-        ldsb > (tiny ? SCF_DMA_LDS_DEEP : SCF_DMA_LDS_MAX)) {
+        ldsb > ((tiny || ngroups > 1) ? SCF_DMA_LDS_DEEP : SCF_DMA_LDS_MAX)) {
       use_ksp = false;
     } else {
       ksp = true;
@@ -650,6 +673,9 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   if (dry_run) return SCF_OK;
 #define SCF_GO(...) return px4 ? launch_dma<__VA_ARGS__, true>(k, (int)nblk, ldsb, st)            \
                                : launch_dma<__VA_ARGS__, false>(k, (int)nblk, ldsb, st)
+  if (ksp && ngroups == 2) {
+    return px4 ? launch_dma<1, 1, 2, true, true, 2>(k, (int)nblk, ldsb, st) : launch_dma<1, 1, 2, true, false, 2>(k, (int)nblk, ldsb, st);
+  }
   if (ksp) SCF_GO(1, 1, 2, true);
 #define SCF_CASE(M, Nn) if (WM == M && WN == Nn) SCF_GO(M, Nn, 2, false);
   SCF_CASE(2, 2) SCF_CASE(3, 1) SCF_CASE(2, 1) SCF_CASE(1, 1)

@@ -295,6 +295,39 @@ def test_conv2d_dma_kernel(case):
     close(got, ref.cpu(), atol=3e-5, what='dma vs register-staged ' + str(case))
 
 
+@pytest.mark.parametrize('case', [(1, 256, 256, (1, 5), (0, 2), 32, 32, 1, 128), (1, 128, 256, (3, 3), (1, 1), 32, 32, 1, 0),
+                                  (2, 256, 128, (5, 1), (2, 0), 32, 32, 1, 128), (1, 324, 256, (1, 1), (0, 0), 32, 32, 1, 0),
+                                  (1, 224, 128, (3, 3), (1, 1), 32, 32, 2, 128), (1, 104, 64, (3, 3), (1, 1), 20, 24, 1, 0),
+                                  (1, 128, 128, (3, 3), (1, 1), 8, 8, 2, 0)])
+def test_conv2d_ksplit_wave_groups(case):
+    """grids with at most one K-split block per CU (batch 1): two wave groups per block walk alternate channel chunks
+    (conv_dma_kernel NG = 2) -- against torch and against the one-group kernel (scf_tune dma_ksplit_groups = 1): same
+    products, another fixed summation order"""
+    n, cin, cout, k, p, H, W, st, c0 = case
+    x = rnd((n, cin, H, W), 230)
+    wt = rnd((cout, cin, *k), 231, (1.0 / (cin * k[0] * k[1])) ** 0.5)
+    b = rnd((cout,), 232, 0.1)
+    want = torch.relu(F.conv2d(x.double(), wt.double(), b.double(), stride=st, padding=p)).float()
+    pc = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), stride=st, padding=p)
+    xd = x.to(DEV)
+    x0, x1 = (xd[:, :c0], xd[:, c0:]) if c0 else (xd, None)
+    prev = ops.set_conv_winograd(False)
+    try:
+        got2 = ops.conv2d(pc, x0, x1, act=ops.ACT_RELU)
+        ops.tune('dma_ksplit_groups', 1)
+        got1 = ops.conv2d(pc, x0, x1, act=ops.ACT_RELU)
+    finally:
+        ops.tune('dma_ksplit_groups', 0)
+        ops.set_conv_winograd(prev)
+    close(got2, want, atol=1e-5, what=f'two wave groups {case}')
+    close(got1, want, atol=1e-5, what=f'one wave group {case}')
+    assert float((got1 - got2).abs().max()) > 0.0, 'identical bits: the two-group kernel did not run'
+    prev2 = ops.set_conv_winograd(False)
+    again = ops.conv2d(pc, x0, x1, act=ops.ACT_RELU)
+    ops.set_conv_winograd(prev2)
+    assert torch.equal(again, got2)                  # deterministic
+
+
 WINO_CASES = [
     # n, cin, cout, H, W, (c0 split or 0), BN, residual, relu -- every case is >= 128 blocks (the dispatch keeps
     # smaller grids on the direct kernels)

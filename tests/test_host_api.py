@@ -197,7 +197,7 @@ def test_pack_conv_weight_thin_layout_and_eligibility():
     assert ops.choose_a4_groups(64, 3, 3, 1) == 1 and ops.choose_a4_groups(384, 1, 5, 1) == 2
     assert ops.choose_a4_groups(224, 3, 3, 2) == 1
     assert ops.choose_a4_groups(324, 1, 1, 1) == 4 and ops.choose_a4_groups(3, 7, 7, 2) == 0
-    assert ops.choose_a4_groups(64, 1, 1, 2) == 0 and ops.choose_a4_groups(32, 1, 1, 1) == 0    # 1x1: stride 1, >= 64 channels
+    assert ops.choose_a4_groups(64, 1, 1, 2) == 4 and ops.choose_a4_groups(32, 1, 1, 1) == 0    # 1x1: >= 64 channels (stride 2: dilated gather)
     # ... and the small-grid variant with bigger chunks (dense 1x1 layers join in)
     assert ops.choose_a4s_groups(324, 1, 1, 1) == 4 and ops.choose_a4s_groups(384, 5, 1, 1) == 4
     assert ops.choose_a4s_groups(128, 3, 3, 2) == 2 and ops.choose_a4s_groups(8, 3, 3, 1) == 0
