@@ -615,28 +615,50 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   // packing -- half the chunks, half the chain (batch 1: 256 -> 192 29.8 -> 21.5 us, pose-head convs
   // 17 -> 13.7 us).  With more blocks than CUs the 100 KB stages would cost the co-residency that
   // small grids live on (128 -> 512 at batch 1: 19.4 -> 23.5 us): those keep 16-channel chunks.
-  const bool tiny = ksp_blk <= scf_cu_count() && k.wp4t && k.G4t == 4 && !(k.in1 && (k.C0 % 32) != 0);
+  // r4: on such a grid a block may also run TWO wave groups that walk alternate chunks (conv_dma_kernel NG = 2) if
+  // four stages fit its LDS -- so the choice is by the length of the serial chain, chunks / groups, over the packings
+  // the caller provides (ties: the bigger chunks, fewer barriers).
+  const bool one_per_cu = ksp_blk <= scf_cu_count();
+  const bool tiny = one_per_cu && k.wp4t && k.G4t == 4 && !(k.in1 && (k.C0 % 32) != 0);
+  const int PHk = (FR - 1) * k.stride + k.KH, PWink = (FC - 1) * k.stride + k.KW;
+  const int PWk = pitch(PWink, px4_small);
+  auto stage_bytes = [&](int g) { return (size_t)((long long)k.T * g * 2 * 32 * 4 + (long long)8 * g * PHk * PWk) * sizeof(float); };
+  auto fits_ksp = [&](int g, int ng) {
+    const long long PE = (long long)8 * g * PHk * PWk, WF4 = (long long)k.T * g * 2 * 32;
+    const size_t l = stage_bytes(g) * 2 * ng;
+    return PE <= (px4_small ? 1024 * SCF_DMA_PU_X4 : 256 * SCF_DMA_PU_KSP) && WF4 <= 256 * SCF_DMA_WU_KSP &&
+           l <= ((one_per_cu && (ng > 1 || tiny)) ? SCF_DMA_LDS_DEEP : SCF_DMA_LDS_MAX);
+  };
   if (use_ksp) {
-    if (tiny) {
-      k.wp4 = k.wp4t; k.G4 = k.G4t;
-    } else if (k.wp4s && (k.G4s == 1 || k.G4s == 2 || k.G4s == 4) && !(k.in1 && (k.C0 % (8 * k.G4s)) != 0)) {
-      k.wp4 = k.wp4s; k.G4 = k.G4s;                    // the small-grid packing: bigger chunks
-    } else if (!pix_ok) {
+    const bool groups_ok = one_per_cu && g_ksp_groups.load(std::memory_order_relaxed) != 1;
+    const float* cand_w[3] = {tiny ? k.wp4t : nullptr, k.wp4s, pix_ok ? k.wp4 : nullptr};
+    const int cand_g[3] = {k.G4t, k.G4s, k.G4};
+    int best_c = -1, best_chain = 1 << 30, best_ng = 1;
+    for (int c = 0; c < 3; ++c) {
+      const int g = cand_g[c];
+      if (!cand_w[c] || !(g == 1 || g == 2 || g == 4) || (k.in1 && (k.C0 % (8 * g)) != 0)) continue;
+      const int nch = (k.Cin + 8 * g - 1) / (8 * g);
+      const int ng = (groups_ok && nch >= 4 && fits_ksp(g, 2)) ? 2 : 1;
+      if (!fits_ksp(g, ng)) continue;
+      const int chain = (nch + ng - 1) / ng;
+      // without wave groups the order of preference is the r3 one (tiny-grid packing, small-grid packing, the
+      // full-grid one): a later candidate must be strictly shorter
+      if (best_c < 0 || chain < best_chain) { best_c = c; best_chain = chain; best_ng = ng; }
+    }
+    if (best_c < 0) {
       use_ksp = false;
+    } else {
+      k.wp4 = cand_w[best_c]; k.G4 = cand_g[best_c];
+      ngroups = best_ng;
     }
   }
   if (use_ksp) {
     G = k.G4; KC = 8 * G;
     k.nchunk = (k.Cin + KC - 1) / KC;
-    const int PH = (FR - 1) * k.stride + k.KH, PWin = (FC - 1) * k.stride + k.KW;
+    const int PH = PHk;
     px4 = px4_small;
-    const int PW = pitch(PWin, px4);
-    const long long PE = (long long)KC * PH * PW, WF4 = (long long)k.T * G * 2 * 32;
-    const size_t stage_b = (size_t)(WF4 * 4 + PE) * sizeof(float);
-    // at most one block per CU and a chain of >= 4 chunks: two wave groups per block walk alternate chunks
-    // (conv_dma_kernel NG = 2: half the serial chain, the partial sums meet in LDS as before)
-    ngroups = (ksp_blk <= scf_cu_count() && k.nchunk >= 4 && stage_b * 4 <= SCF_DMA_LDS_DEEP &&
-               g_ksp_groups.load(std::memory_order_relaxed) != 1) ? 2 : 1;
+    const long long PE = (long long)KC * PH * PWk, WF4 = (long long)k.T * G * 2 * 32;
+    const size_t stage_b = stage_bytes(G);
     ldsb = stage_b * 2 * ngroups;
     if (ldsb < (size_t)ngroups * 16 * 1024) ldsb = (size_t)ngroups * 16 * 1024;      // cross-wave reduction area
     if (PE > (px4 ? 1024 * SCF_DMA_PU_X4 : 256 * SCF_DMA_PU_KSP) || WF4 > 256 * SCF_DMA_WU_KSP ||
@@ -669,7 +691,7 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
 
   k.tiles_x = (k.Wo + FC - 1) / FC;
   k.mblocks = (frags_m + WM - 1) / WM;
-  if (info) { info[0] = WM; info[1] = WN; info[2] = (int)nblk; info[3] = k.T * G * 4 * WM * WN / (ksp ? 4 : 1); }
+  if (info) { info[0] = WM; info[1] = ksp ? ngroups : WN; info[2] = (int)nblk; info[3] = k.T * G * 4 * WM * WN / (ksp ? 4 : 1); }
   if (dry_run) return SCF_OK;
 #define SCF_GO(...) return px4 ? launch_dma<__VA_ARGS__, true>(k, (int)nblk, ldsb, st)            \
                                : launch_dma<__VA_ARGS__, false>(k, (int)nblk, ldsb, st)

@@ -321,7 +321,9 @@ def test_conv2d_ksplit_wave_groups(case):
         ops.set_conv_winograd(prev)
     close(got2, want, atol=1e-5, what=f'two wave groups {case}')
     close(got1, want, atol=1e-5, what=f'one wave group {case}')
-    assert float((got1 - got2).abs().max()) > 0.0, 'identical bits: the two-group kernel did not run'
+    if k in ((1, 5), (1, 1)) and n * ((H // st + 0) * (W // st) // 32) * ((cout + 31) // 32) <= 256:
+        # small stages (four fit the LDS): these run two wave groups; 3x3 / 5x1 stages are too big and keep one
+        assert float((got1 - got2).abs().max()) > 0.0, 'identical bits: the two-group kernel did not run'
     prev2 = ops.set_conv_winograd(False)
     again = ops.conv2d(pc, x0, x1, act=ops.ACT_RELU)
     ops.set_conv_winograd(prev2)
