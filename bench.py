@@ -599,17 +599,19 @@ def main():
             w_fl = sum(e[1] for e in conv_launches if e[2].endswith('[winograd]'))
             v_us = sum(e[0] for e in conv_launches if e[2].endswith('[winograd F(2,5)]'))
             v_fl = sum(e[1] for e in conv_launches if e[2].endswith('[winograd F(2,5)]'))
-            x_fl = c_fl - w_fl - v_fl + w_fl / 2.25 + v_fl * 0.6       # flops the matrix cores actually execute
+            u_us = sum(e[0] for e in conv_launches if e[2].endswith('[winograd F(4,5)]'))
+            u_fl = sum(e[1] for e in conv_launches if e[2].endswith('[winograd F(4,5)]'))
+            x_fl = c_fl - w_fl - v_fl - u_fl + w_fl / 2.25 + v_fl * 0.6 + u_fl * 0.4     # flops the matrix cores actually execute
             by_shape = {}
             for us, fl, tag in conv_launches:
                 a = by_shape.setdefault(tag, [0, 0.0, 0.0])
                 a[0] += 1; a[1] += us; a[2] += fl
             top = sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:args.top_layers]
             x_tf = x_fl / (c_us * 1e-6) / 1e12
-            w_x, v_x = w_fl / 2.25, v_fl * 0.6
-            d_us, d_fl = c_us - w_us - v_us, c_fl - w_fl - v_fl
+            w_x, v_x, u_x = w_fl / 2.25, v_fl * 0.6, u_fl * 0.4
+            d_us, d_fl = c_us - w_us - v_us - u_us, c_fl - w_fl - v_fl - u_fl
             result['roofline_conv'] = {
-                'kernel': 'conv_wino_kernel / conv_wino1d_kernel / conv_dma_kernel / conv_mfma_kernel / conv_taps_kernel (all convolution '
+                'kernel': 'conv_wino_kernel / conv_wino1d4_kernel / conv_wino1d_kernel / conv_dma_kernel / conv_mfma_kernel / conv_taps_kernel (all convolution '
                           'launches of one step)',
                 # the roofline fraction of THIS line: MFMA flops the kernels actually issue / time / dense fp32 peak
                 'bound': 'mfma', 'achieved': round(x_tf, 1),
@@ -625,26 +627,31 @@ def main():
                     'winograd_f2_5': {'us_per_step': round(v_us, 1),
                                       'tflops': round(v_x / max(v_us, 1e-9) / 1e6, 1),
                                       'frac': round(v_x / max(v_us, 1e-9) / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)},
+                    'winograd_f4_5': {'us_per_step': round(u_us, 1),
+                                      'tflops': round(u_x / max(u_us, 1e-9) / 1e6, 1),
+                                      'frac': round(u_x / max(u_us, 1e-9) / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)},
                     'direct': {'us_per_step': round(d_us, 1),
                                'tflops': round(d_fl / max(d_us, 1e-9) / 1e6, 1),
                                'frac': round(d_fl / max(d_us, 1e-9) / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)}},
                 # side figure, NOT a roofline fraction: the same time priced at the flops a direct convolution
-                # of these layers would execute (Winograd issues 1 / 2.25 resp. 0.6 of them)
+                # of these layers would execute (Winograd issues 1 / 2.25 resp. 0.6 resp. 0.4 of them)
                 'algorithmic': {'flops_per_step': c_fl, 'tflops': round(c_fl / (c_us * 1e-6) / 1e12, 1),
                                 'winograd_f2x2_3x3_tflops': round(w_fl / max(w_us, 1e-9) / 1e6, 1),
                                 'winograd_f2_5_tflops': round(v_fl / max(v_us, 1e-9) / 1e6, 1),
+                                'winograd_f4_5_tflops': round(u_fl / max(u_us, 1e-9) / 1e6, 1),
                                 'note': 'direct-convolution flops 2*Cin*KH*KW*Cout*Ho*Wo*N of every launch / time: what '
                                         'the layers cost in the formulation of the reference; can exceed the MFMA peak '
                                         'because the Winograd kernels do not execute these flops'},
                 'top_layers': [{'layer': k, 'launches': v[0], 'us': round(v[1], 1),
                                 'tflops_algorithmic': round(v[2] / v[1] / 1e6, 1),
                                 'tflops': round(v[2] / v[1] / 1e6 / (2.25 if k.endswith('[winograd]') else
-                                                                     (1 / 0.6) if k.endswith('[winograd F(2,5)]') else 1.0), 1)}
+                                                                     (1 / 0.6) if k.endswith('[winograd F(2,5)]') else
+                                                                     2.5 if k.endswith('[winograd F(4,5)]') else 1.0), 1)}
                                for k, v in top],
                 'note': 'v_mfma_f32_32x32x2_f32 (fp32 throughout), dense peak 256 CU x 256 flop/clk x 2.4 GHz; achieved = '
                         'EXECUTED MFMA flops of all convolution launches of one step (direct launches 2*Cin*KH*KW*Cout*Ho*Wo*N; '
                         'F(2x2,3x3) launches 1 / 2.25 of that: 16 multiplies per 2x2 outputs instead of 36; F(2,5) launches '
-                        '0.6: 6 per 2 outputs instead of 10) / sum of the launch durations (HIP start/stop events bound to '
+                        '0.6: 6 per 2 outputs instead of 10; F(4,5) launches 0.4: 8 per 4 outputs instead of 20) / sum of the launch durations (HIP start/stop events bound to '
                         'each launch)'}
             mp = _latest_mfma_pmc()
             if mp and args.batch == 32:       # SQ counter pass of this command (own rocprofv3 run), committed under profiles/

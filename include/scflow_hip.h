@@ -187,6 +187,9 @@ typedef struct scf_conv_desc {
                                            kernels by a few ulp of sum |w||x|.  Kernel selection therefore depends on
                                            N and on the device: leave both Winograd packings NULL for results that
                                            do not */
+  const float* wp_wino1d4;              /* optional: the F(4, 5) packing of the same 1x5 / 5x1 layer (scf_pack_conv_weight_wino1d4):
+                                           four outputs per 8 multiplies; taken before wp_wino1d on grids of more than CUs / 2 of its
+                                           blocks (64 channels x 256 pixels); same contract as wp_wino */
 } scf_conv_desc;
 
 int scf_conv2d(const scf_conv_desc* desc, scf_stream_t stream);
@@ -214,6 +217,10 @@ int64_t scf_pack_conv_weight_wino1d_size(int32_t Cout, int32_t Cin);
 int scf_pack_conv_weight_wino1d(const float* w, int32_t Cout, int32_t Cin, float* out);   /* w: (Cout, Cin, 5) taps;
      out[((chunk*F + co/32)*6 + i)*256 + (cl & 1)*128 + (co % 32)*4 + (cl >> 1)] = (G g)[i], ci = 8*chunk + cl,
      G = the 6 x 5 matrix of the points 0, 1, -1, 2, -2, infinity */
+int64_t scf_pack_conv_weight_wino1d4_size(int32_t Cout, int32_t Cin);
+int scf_pack_conv_weight_wino1d4(const float* w, int32_t Cout, int32_t Cin, float* out);  /* w: (Cout, Cin, 5) taps;
+     out[((chunk*F + co/32)*8 + i)*128 + (cl & 1)*64 + (co % 32)*2 + (cl >> 1)] = (G g)[i], ci = 4*chunk + cl,
+     G = the 8 x 5 matrix of the points 0, 1, -1, 2, -2, 1/2, -1/2, infinity, row 0 negated */
 int64_t scf_pack_conv_weight_wino_size(int32_t Cout, int32_t Cin);
 int scf_pack_conv_weight_wino(const float* w, int32_t Cout, int32_t Cin, float* out);
 
@@ -247,6 +254,7 @@ typedef struct scf_gru_pass {
   const float* wp_zr_a4s; const float* wp_q_a4s; int32_t a4s_groups;
   const float* wp_zr_a4t; const float* wp_q_a4t; int32_t a4t_groups;   /* 3x3 passes: tiny-grid packings (scf_conv_desc.wp_a4t), optional */
   const float* wp_zr_wino1d; const float* wp_q_wino1d;   /* 1x5 / 5x1 passes: F(2, 5) packings (scf_conv_desc.wp_wino1d), optional */
+  const float* wp_zr_wino1d4; const float* wp_q_wino1d4; /* 1x5 / 5x1 passes: F(4, 5) packings (scf_conv_desc.wp_wino1d4), optional */
 } scf_gru_pass;
 
 int scf_sepconv_gru(float* hx, int64_t hx_nstride, int N, int Ch, int Cx, int H, int W,

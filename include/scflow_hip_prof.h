@@ -46,8 +46,9 @@ enum {
   SCF_KERNEL_DMA = 6,         /* conv_dma_kernel: direct, LDS-DMA staged (pixel-split or K-split)  */
   SCF_KERNEL_MFMA = 7,        /* conv_mfma_kernel: direct, register staged                         */
   SCF_KERNEL_MFMA_KSPLIT = 8, /* conv_mfma_ksplit_kernel                                           */
-  SCF_KERNEL_WINO_Q = 9       /* conv_wino_q_kernel: Winograd F(2x2, 3x3), one transform row x two channel
+  SCF_KERNEL_WINO_Q = 9,      /* conv_wino_q_kernel: Winograd F(2x2, 3x3), one transform row x two channel
                                  fragments per wave (even fragment counts)                           */
+  SCF_KERNEL_WINO1D4 = 10     /* conv_wino1d4_kernel: Winograd F(4, 5)                             */
 };
 typedef struct scf_conv_log_entry {
   int32_t kernel;             /* SCF_KERNEL_*                                                      */
@@ -60,7 +61,9 @@ int scf_conv_log_enable(int capacity);
 enum {
   SCF_TUNE_WINO_VARIANT = 1,  /* F(2x2,3x3): 1 = pair kernel, 2 / 3 = quarter-domain kernel with 4 / 8 waves */
   SCF_TUNE_DMA_FORCE_KSPLIT = 2, /* 1: the LDS-DMA kernel takes its K-split tile (32 channels x 32 pixels per block) on every grid */
-  SCF_TUNE_DMA_KSPLIT_GROUPS = 3 /* 1: K-split blocks keep one wave group (no intra-block split of the chunk chain) */
+  SCF_TUNE_DMA_KSPLIT_GROUPS = 3, /* 1: K-split blocks keep one wave group (no intra-block split of the chunk chain) */
+  SCF_TUNE_WINO1D4 = 4        /* 1 (default): 1x5 / 5x1 layers that carry an F(4, 5) packing use it on large grids; 0: F(2, 5);
+                                 2: F(4, 5) on every grid it supports (tests of small ragged shapes) */
 };
 int scf_tune(int key, int value);
 int scf_conv_log_read(scf_conv_log_entry* out, int max_entries);

@@ -53,6 +53,7 @@ class ConvDesc(C.Structure):
         ('a4t_groups', C.c_int32),
         ('wp_wino1d', _fp),
         ('wp_wino', _fp),
+        ('wp_wino1d4', _fp),
     ]
 
 
@@ -67,6 +68,7 @@ class GruPass(C.Structure):
         ('wp_zr_a4s', _fp), ('wp_q_a4s', _fp), ('a4s_groups', C.c_int32),
         ('wp_zr_a4t', _fp), ('wp_q_a4t', _fp), ('a4t_groups', C.c_int32),
         ('wp_zr_wino1d', _fp), ('wp_q_wino1d', _fp),
+        ('wp_zr_wino1d4', _fp), ('wp_q_wino1d4', _fp),
     ]
 
 
@@ -76,7 +78,7 @@ class ConvLogEntry(C.Structure):
 
 
 KERNEL_NAMES = {1: 'thin', 2: 'taps', 3: 'winograd', 4: 'winograd F(2,5)', 5: 'f16x3', 6: 'direct-dma',
-                7: 'direct-mfma', 8: 'direct-mfma-ksplit', 9: 'winograd-q'}
+                7: 'direct-mfma', 8: 'direct-mfma-ksplit', 9: 'winograd-q', 10: 'winograd F(4,5)'}
 
 
 class FcDesc(C.Structure):
@@ -165,6 +167,8 @@ SIGNATURES = {
     'scf_pack_conv_weight_taps': (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'scf_pack_conv_weight_wino1d_size': (C.c_int64, [C.c_int32, C.c_int32]),
     'scf_pack_conv_weight_wino1d': (C.c_int, [_fp, C.c_int32, C.c_int32, _fp]),
+    'scf_pack_conv_weight_wino1d4_size': (C.c_int64, [C.c_int32, C.c_int32]),
+    'scf_pack_conv_weight_wino1d4': (C.c_int, [_fp, C.c_int32, C.c_int32, _fp]),
     'scf_pack_conv_weight_wino_size': (C.c_int64, [C.c_int32, C.c_int32]),
     'scf_pack_conv_weight_wino': (C.c_int, [_fp, C.c_int32, C.c_int32, _fp]),
     'scf_sepconv_gru': (C.c_int, [_fp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -5,13 +5,13 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['capi.hip', 'corr_lookup.hip', 'corr_gemm.hip', 'conv_mfma.hip', 'conv_f16x3.hip', 'conv_dma.hip', 'conv_thin.hip', 'conv_taps.hip', 'conv_wino.hip', 'conv_wino1d.hip', 'resample.hip', 'pose.hip', 'scflow_iter.hip',
+SOURCES = ['capi.hip', 'corr_lookup.hip', 'corr_gemm.hip', 'conv_mfma.hip', 'conv_f16x3.hip', 'conv_dma.hip', 'conv_thin.hip', 'conv_taps.hip', 'conv_wino.hip', 'conv_wino1d.hip', 'conv_wino1d4.hip', 'resample.hip', 'pose.hip', 'scflow_iter.hip',
            'norm.hip', 'metrics.hip', 'fc.hip']
 OUT = os.path.join(HERE, 'libscflow_hip.so')
 # conv_wino.hip: the SLP vectoriser turns the input transform's 32 adds into packed adds PLUS as many register
 # moves to pair their operands up; vector-ALU instructions cost matrix-pipe time there (see the file), so the
 # scalar form (no moves) is the faster one
-FILE_FLAGS = {'conv_wino.hip': ['-fno-slp-vectorize'], 'conv_wino1d.hip': ['-fno-slp-vectorize']}
+FILE_FLAGS = {'conv_wino.hip': ['-fno-slp-vectorize'], 'conv_wino1d.hip': ['-fno-slp-vectorize'], 'conv_wino1d4.hip': ['-fno-slp-vectorize']}
 
 
 def needs_build() -> bool:

@@ -364,6 +364,8 @@ int scf_conv_taps_dispatch(ConvK k, const float* wt, int N, bool dry_run, int* i
 int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* info, hipStream_t st, int* which = nullptr);
 // conv_wino1d.hip: 1x5 / 5x1 stride-1 'same' layers, any epilogue kind, in the Winograd F(2, 5) form (wu = the G g packing).
 int scf_conv_wino1d_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* info, hipStream_t st);
+// conv_wino1d4.hip: the same layers in the F(4, 5) form (wu = its own G g packing), grids of more than CUs / 2 blocks only.
+int scf_conv_wino1d4_dispatch(ConvK k, const float* wu, int N, bool any_grid, bool dry_run, int* info, hipStream_t st);
 // conv_thin.hip: Cout <= 4 layers on the vector ALUs.
 int scf_conv_thin_dispatch(ConvK k, int N, bool dry_run, hipStream_t st);
 // conv_dma.hip: same contract for the stride-1 LDS-DMA fp32 kernel.

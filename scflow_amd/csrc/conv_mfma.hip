@@ -538,6 +538,8 @@ static bool want_f16x3(const scf_conv_desc* d) {
   return d->wp_f16 != nullptr && !d->out_tile8x4 && d->w_nstride == 0 && d->KH * d->KW > 1 && d->C0 + d->C1 >= 16;
 }
 
+static std::atomic<int> g_wino1d4{1};    // SCF_TUNE_WINO1D4: 0 = F(2, 5) also where an F(4, 5) packing is given (A/B measurements), 2 = F(4, 5) on every grid
+
 static bool want_dma(const scf_conv_desc* d) {      // a layer opts in by carrying the LDS-DMA packing
   return (d->wp_a4 != nullptr || d->wp_a4s != nullptr) && (d->stride == 1 || d->stride == 2) &&
          d->w_nstride == 0 && d->a4_mld >= d->Cout;
@@ -562,6 +564,11 @@ static int conv2d_launch(const scf_conv_desc* d, scf_stream_t stream, int* which
     int quarter = 0;
     const int rw = scf_conv_wino_dispatch(pl.k, d->wp_wino, d->N, false, nullptr, scf_stream(stream), &quarter);
     *which = quarter ? SCF_KERNEL_WINO_Q : SCF_KERNEL_WINO;
+    if (rw != SCF_EUNSUPPORTED) return rw;
+  }
+  if (d->wp_wino1d4 && g_wino1d4.load(std::memory_order_relaxed)) {
+    *which = SCF_KERNEL_WINO1D4;
+    const int rw = scf_conv_wino1d4_dispatch(pl.k, d->wp_wino1d4, d->N, g_wino1d4.load(std::memory_order_relaxed) == 2, false, nullptr, scf_stream(stream));
     if (rw != SCF_EUNSUPPORTED) return rw;
   }
   if (d->wp_wino1d) {
@@ -614,6 +621,10 @@ extern "C" int scf_tune(int key, int value) {
   if (key == SCF_TUNE_WINO_VARIANT) return scf_wino_variant_set(value);
   if (key == SCF_TUNE_DMA_FORCE_KSPLIT) return scf_dma_force_ksplit_set(value);
   if (key == SCF_TUNE_DMA_KSPLIT_GROUPS) return scf_dma_ksplit_groups_set(value);
+  if (key == SCF_TUNE_WINO1D4) {
+    if (value < 0 || value > 2) return SCF_EINVAL;
+    return g_wino1d4.exchange(value);
+  }
   return SCF_EINVAL;
 }
 
@@ -701,7 +712,7 @@ static int sepconv_gru_impl(float* hx, int64_t hx_nstride, int N, int Ch, int Cs
     d.wp_a4 = g.wp_zr_a4; d.a4_groups = g.a4_groups; d.a4_mld = d.Mld; d.wp_f16 = g.wp_zr_f16;
     d.wp_a4s = g.wp_zr_a4s; d.a4s_groups = g.a4s_groups;
     d.wp_a4t = g.wp_zr_a4t; d.a4t_groups = g.a4t_groups;
-    d.wp_wino1d = g.wp_zr_wino1d;
+    d.wp_wino1d = g.wp_zr_wino1d; d.wp_wino1d4 = g.wp_zr_wino1d4;
     d.out = z; d.out_nstride = Ch * hw;
     d.mode = SCF_CONV_GRU_ZR; d.gru_h = hx; d.gru_h_nstride = hx_nstride;
     d.gru_aux = rh; d.gru_aux_nstride = Ch * hw;
@@ -716,7 +727,7 @@ static int sepconv_gru_impl(float* hx, int64_t hx_nstride, int N, int Ch, int Cs
     d.wp_a4 = g.wp_q_a4; d.a4_mld = d.Mld; d.wp_f16 = g.wp_q_f16;
     d.wp_a4s = g.wp_q_a4s;
     d.wp_a4t = g.wp_q_a4t;
-    d.wp_wino1d = g.wp_q_wino1d;
+    d.wp_wino1d = g.wp_q_wino1d; d.wp_wino1d4 = g.wp_q_wino1d4;
     d.out = hx; d.out_nstride = hx_nstride;
     d.mode = SCF_CONV_GRU_Q; d.gru_h = hx; d.gru_h_nstride = hx_nstride;
     d.gru_aux = nullptr; d.gru_aux_nstride = 0;
@@ -771,6 +782,11 @@ extern "C" int scf_conv2d_query(const scf_conv_desc* d, int32_t* info) {
   }
   if (d->wp_wino && scf_conv_wino_dispatch(pl.k, d->wp_wino, d->N, true, info, nullptr) == SCF_OK) {
     info[3] = -info[3];      // negative: the Winograd kernel will run (info = 16 positions, fragments per block, blocks, -LDS bytes)
+    return SCF_OK;
+  }
+  if (d->wp_wino1d4 && g_wino1d4.load(std::memory_order_relaxed) &&
+      scf_conv_wino1d4_dispatch(pl.k, d->wp_wino1d4, d->N, g_wino1d4.load(std::memory_order_relaxed) == 2, true, info, nullptr) == SCF_OK) {
+    info[3] = -info[3];      // negative: the F(4, 5) kernel will run (info = 8 positions, 4 fragments per block, blocks, -LDS bytes)
     return SCF_OK;
   }
   if (d->wp_wino1d && scf_conv_wino1d_dispatch(pl.k, d->wp_wino1d, d->N, true, info, nullptr) == SCF_OK) {

@@ -1,0 +1,385 @@
+// 1 x 5 / 5 x 1 stride-1 convolutions (the SepConvGRU gates, raft_decoder.py:198-253) in the one-dimensional
+// Winograd form F(4, 5), fp32 throughout: FOUR outputs along the filter axis from a window of eight inputs with 8
+// multiplies per channel pair instead of 20 (points 0, +-1, +-2, +-1/2, infinity):
+//     y = A^T [ (G g) . (B^T d) ],   A^T 4 x 8, G 8 x 5, B^T 8 x 8
+// -- 1.5x fewer matrix-core flops than F(2, 5) (conv_wino1d.hip: 6 per 2 outputs), 2.5x fewer than the direct kernels.
+// Read conv_wino.hip / conv_wino1d.hip first: copy streams through buffer descriptors, three-deep rings, operands of
+// the next chunk read / computed under the MFMAs of the current one.  What differs:
+//   * a wave holds ONE 32 x 32 fragment (32 output channels x 32 tiles of FOUR outputs = 128 pixels) for all 8 transform
+//     positions = 128 accumulator registers; the output transform is lane-local; after it a lane holds 16 channel rows
+//     of four pixels = four accumulator fragments of the direct kernels, finished by the shared fused epilogue
+//     (conv_kernels.h: bias, BN, residual, activations, both GRU gates);
+//   * a block = 2 channel fragments x 2 tile groups (64 channels x 256 pixels); 4 channels per chunk: one ds_read_b64 per
+//     position feeds both k-steps, 16 MFMAs per barrier (the 128 accumulators leave no room for deeper operand buffers);
+//   * the input transform is 26 fmas per window (2 windows per lane and chunk):
+//         r0 = (d0 - d6) + 21/4 (d4 - d2)                       r7 = (d7 - d1) + 21/4 (d3 - d5)
+//         r1 | r2 = (d2 + d6 - 17/4 d4) +- (d1 + d5 - 17/4 d3)
+//         r3 | r4 = (d6 + 1/4 d2 - 5/4 d4) +- (1/2 d1 - 5/2 d3 + 2 d5)
+//         r5 | r6 = (d6 + 4 d2 - 5 d4) +- (2 d1 - 5/2 d3 + 1/2 d5)
+//     and the output transform  y0 = M0 + ... + M6,  y1 = (M1 - M2) + 2 (M3 - M4) + 1/2 (M5 - M6),
+//         y2 = (M1 + M2) + 4 (M3 + M4) + 1/4 (M5 + M6),  y3 = (M1 - M2) + 8 (M3 - M4) + 1/8 (M5 - M6) + M7;
+//   * a GRU launch's pre-activation term (the hoisted context part, one value per output) goes INTO the accumulators at
+//     kernel start: positions 0, 1, 2, 7 take res0 - res2, (res1 + res2) / 2, (res2 - res1) / 2, res3 - res1 -- A^T maps
+//     exactly these back onto (res0, res1, res2, res3) -- so it costs no registers over the loop.
+// Error vs fp64: ~2.5x F(2, 5)'s on unit-scale operands, the same on the stress operands of tests/test_gpu_ops.py
+// (measured there in units of eps sum|w||x|).
+#include <stdlib.h>
+#include <string.h>
+#include "scf_common.h"
+#include "conv_kernels.h"
+#include "scf_dma.h"
+
+typedef float w4_f32x16 __attribute__((ext_vector_type(16)));
+typedef float w4_f32x2 __attribute__((ext_vector_type(2)));
+
+#define W4_KC 4             // channels per chunk
+#define W4_UF 1024          // floats of one fragment's U chunk: [8 positions][2 k-halves][32 channels][2 k-steps]
+// patch copy instructions per wave per chunk (256 cells per block-instruction) = template parameter NPI: 16-byte cells 2
+// (vertical 16-column blocks: 3), dword cells 5
+
+struct Wino4K {
+  const float* wu;          // [nchunk][F][8][2][32][2]
+  int F;                    // channel fragments in the packing
+  int txl;                  // log2(tile columns of a wave's 32-tile group)
+  int PH, PWp, PPL;         // patch rows, row pitch, plane stride (floats)
+  int nchunk;
+  int sx, sy;               // block strips per image
+  int mblocks;
+};
+
+__device__ __forceinline__ int w4_div(int e, int d, float rd) {       // floor(e / d), 0 <= e < 2^20, 0 < d < 2^12
+  int q = (int)((float)e * rd);
+  const int r = e - q * d;
+  q += (r >= d) ? 1 : 0;
+  q -= (r < 0) ? 1 : 0;
+  return q;
+}
+
+template <bool VERT, bool PX4, int NPI>
+__global__ __launch_bounds__(256, 2)
+void conv_wino1d4_kernel(ConvK p, Wino4K q) {
+  static_assert(!VERT || PX4, "the vertical kernel copies 16-byte cells only");
+  extern __shared__ __attribute__((aligned(16))) float w4_lds[];
+  constexpr int CW = 2, TW = 2;
+  constexpr int USLOT = CW * W4_UF;                             // floats per ring slot
+  constexpr int NUI = 2;                                        // U copy instructions (16 B per lane) per wave per chunk
+  constexpr int PSLOT = NPI * (PX4 ? 1024 : 256);
+  constexpr int GRP = NUI + NPI;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cw = wave >> 1, tw = wave & 1;
+  const int half = lane >> 5, l32 = lane & 31;
+
+  int lb = scf_xcd_remap(blockIdx.x, gridDim.x);
+  const int mb = __builtin_amdgcn_readfirstlane(lb % q.mblocks);
+  lb /= q.mblocks;
+  const int xs = __builtin_amdgcn_readfirstlane(lb % q.sx);
+  lb /= q.sx;
+  const int ys = __builtin_amdgcn_readfirstlane(lb % q.sy);
+  const int n = __builtin_amdgcn_readfirstlane(lb / q.sy);
+  const int TXW = 1 << q.txl, TYW = 32 >> q.txl;
+  // first output pixel of the block; a tile = 4 pixels along the filter axis
+  const int y0 = ys * (VERT ? 4 * TW * TYW : TW * TYW), x0 = xs * (VERT ? TXW : 4 * TXW);
+  const int f0 = mb * CW;
+  const int HW = p.H * p.W;
+
+  float* Us = w4_lds;
+  float* Ps = Us + 3 * USLOT;
+  const unsigned u_lds = scf_lds_addr(Us), p_lds = scf_lds_addr(Ps);
+
+  // ---- chunk-invariant copy offsets ----
+  // patch = 4 channel planes of PH rows x PWp floats: horizontal: the block's rows, columns from x0 - 2 (x0 - 4 with
+  // 16-byte cells: windows then start at column 4 tx + 2); vertical: rows from y0 - 2, the block's columns (pitch 32)
+  unsigned pvo[NPI];
+  {
+    const int NC = PX4 ? q.PWp >> 2 : q.PWp, PPC = q.PH * NC;
+    const float rPPC = 1.0f / (float)PPC, rNC = 1.0f / (float)NC;
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+      const int e = i * 256 + tid;
+      const int c = w4_div(e, PPC, rPPC), r = e - c * PPC;
+      const int py = w4_div(r, NC, rNC), px = r - py * NC;
+      const int iy = VERT ? y0 - 2 + py : y0 + py;
+      const int ix = VERT ? x0 + 4 * px : (PX4 ? x0 - 4 + 4 * px : x0 - 2 + px);
+      const bool ok = c < W4_KC && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      pvo[i] = ok ? (unsigned)((c * HW + iy * p.W + ix) * 4) : SCF_BUF_OOB;
+    }
+  }
+  unsigned uvo[NUI], uld[NUI];
+#pragma unroll
+  for (int i = 0; i < NUI; ++i) {               // a fragment's chunk is 4 KB contiguous: 4 instructions of 1 KB
+    const int j = wave + 4 * i;
+    const int f = j >> 2, part = j & 3;
+    uvo[i] = (unsigned)((f0 + f) * (W4_UF * 4) + part * 1024 + lane * 16);
+    uld[i] = (unsigned)(f * (W4_UF * 4) + part * 1024);
+  }
+  const unsigned u_chunk_bytes = (unsigned)(q.F * W4_UF * 4);
+  const unsigned u_total = (unsigned)q.nchunk * u_chunk_bytes;
+  scf_rsrc4 urs = scf_make_rsrc(q.wu, u_total);
+  int u_left = (int)u_total;
+  auto issue_u = [&](int slot) {                   // the next U chunk -> ring slot (past the end: zeros)
+    const unsigned dst = u_lds + (unsigned)(slot * USLOT * 4);
+#pragma unroll
+    for (int i = 0; i < NUI; ++i) scf_bdma_b128(urs, uvo[i], dst + uld[i]);
+    const unsigned lo = (unsigned)urs[0] + u_chunk_bytes;
+    urs[1] += lo < u_chunk_bytes ? 1 : 0;
+    urs[0] = (int)lo;
+    u_left -= (int)u_chunk_bytes;
+    urs[2] = u_left > 0 ? u_left : 0;
+  };
+  const unsigned p_chunk_bytes = (unsigned)(W4_KC * HW * 4);
+  int p_left = p.C0;                                 // channels of the current input segment still to copy
+  bool p_second = p.in1 == nullptr;
+  scf_rsrc4 prs = scf_make_rsrc(p.in0 + (long long)n * p.in0_ns, (unsigned)((p_left < W4_KC ? p_left : W4_KC) * HW * 4));
+  auto issue_p = [&](int slot) {                   // the next patch chunk -> ring slot
+    const unsigned dst = p_lds + (unsigned)((slot * PSLOT + wave * (PX4 ? 256 : 64)) * 4);
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+      if (PX4) scf_bdma_b128(prs, pvo[i], dst + (unsigned)(i * 4096));
+      else scf_bdma_b32(prs, pvo[i], dst + (unsigned)(i * 1024));
+    }
+    p_left -= W4_KC;
+    if (p_left <= 0 && !p_second) {                  // on to the second input segment (C0 % 4 == 0 there)
+      p_second = true;
+      p_left = p.Cin - p.C0;
+      prs = scf_make_rsrc(p.in1 + (long long)n * p.in1_ns, 0u);
+    } else {
+      const unsigned lo = (unsigned)prs[0] + p_chunk_bytes;
+      prs[1] += lo < p_chunk_bytes ? 1 : 0;
+      prs[0] = (int)lo;
+    }
+    const int cl = p_left < W4_KC ? p_left : W4_KC;
+    prs[2] = cl > 0 ? cl * HW * 4 : 0;
+  };
+
+  // ---- input transform in registers: lane (tile l32, k-half) turns the 8-windows of channels half and 2 + half into
+  //      its B operands ----
+  const int ty = tw * TYW + (l32 >> q.txl), tx = l32 & (TXW - 1);
+  unsigned prow[2];                                  // absolute LDS byte address of the window of channel 2 s + half, slot 0
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int off = VERT ? 4 * ty * q.PWp + tx : ty * q.PWp + 4 * tx + (PX4 ? 2 : 0);
+    prow[s] = p_lds + (unsigned)(((2 * s + half) * q.PPL + off) * 4);
+  }
+  float dw[2][8];
+  auto win_load = [&](unsigned slot_bytes, int s) {
+    const __attribute__((address_space(3))) float* r =
+        (const __attribute__((address_space(3))) float*)(uintptr_t)(prow[s] + slot_bytes);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dw[s][i] = VERT ? r[i * 32] : r[i];       // vertical: pitch 32 floats
+  };
+  auto win_transform = [&](w4_f32x2 (&bo)[8], int s) {                    // -> bo[position][s]
+    const float (&d)[8] = dw[s];
+    const float t1 = __builtin_fmaf(-4.25f, d[4], d[2] + d[6]), t2 = __builtin_fmaf(-4.25f, d[3], d[1] + d[5]);
+    const float t3 = __builtin_fmaf(-1.25f, d[4], __builtin_fmaf(0.25f, d[2], d[6]));
+    const float t4 = __builtin_fmaf(2.f, d[5], __builtin_fmaf(-2.5f, d[3], 0.5f * d[1]));
+    const float t5 = __builtin_fmaf(-5.f, d[4], __builtin_fmaf(4.f, d[2], d[6]));
+    const float t6 = __builtin_fmaf(0.5f, d[5], __builtin_fmaf(-2.5f, d[3], 2.f * d[1]));
+    bo[0][s] = __builtin_fmaf(5.25f, d[4] - d[2], d[0] - d[6]);
+    bo[1][s] = t1 + t2;
+    bo[2][s] = t1 - t2;
+    bo[3][s] = t3 + t4;
+    bo[4][s] = t3 - t4;
+    bo[5][s] = t5 + t6;
+    bo[6][s] = t5 - t6;
+    bo[7][s] = __builtin_fmaf(5.25f, d[3] - d[5], d[7] - d[1]);
+  };
+
+  // ---- output pixels of this lane (four along the filter axis) ----
+  const ConvEpi e = scf_conv_epi(p, n);
+  int pix[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int oy = VERT ? y0 + 4 * ty + j : y0 + ty, ox = VERT ? x0 + tx : x0 + 4 * tx + j;
+    pix[j] = (oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
+  }
+
+  w4_f32x16 acc[8];
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+  // GRU launches: the pre-activation term enters through the accumulators (see the header), requested in front of the
+  // first copies: vector loads return in order, so the counted waits below still cover exactly the copies
+  const bool pre_res = e.res && (p.mode == SCF_CONV_GRU_ZR || p.mode == SCF_CONV_GRU_Q) && p.out_div == 1.0f;
+  if (pre_res) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = (f0 + cw) * 32 + 8 * (r >> 2) + (r & 3) + 4 * half;
+      float rv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rv[j] = (pix[j] >= 0 && co < p.Cout) ? e.res[co * e.HWo + pix[j]] : 0.f;
+      acc[0][r] = rv[0] - rv[2];
+      acc[1][r] = 0.5f * (rv[1] + rv[2]);
+      acc[2][r] = 0.5f * (rv[2] - rv[1]);
+      acc[7][r] = rv[3] - rv[1];
+    }
+  }
+
+  // ---- prologue: three chunks requested, two awaited ----
+  issue_p(0); issue_u(0);
+  issue_u(1); issue_p(1);
+  issue_u(2); issue_p(2);
+  scf_wait_vmcnt_imm<GRP>();
+  __syncthreads();
+  const float* ua = Us + cw * W4_UF + lane * 2;                        // + position * 128
+  w4_f32x2 a0[8], b0[8], a1[8], b1[8];
+#pragma unroll
+  for (int x = 0; x < 8; ++x) a0[x] = *reinterpret_cast<const w4_f32x2*>(ua + x * 128);
+  win_load(0u, 0); win_transform(b0, 0);
+  win_load(0u, 1); win_transform(b0, 1);
+  __syncthreads();                     // slot 0 of both rings is free again
+
+  int s1 = 1;                          // ring slot of the next chunk
+  auto chunk = [&](const w4_f32x2 (&a)[8], const w4_f32x2 (&b)[8], w4_f32x2 (&an)[8], w4_f32x2 (&bn)[8]) {
+    const float* uc = ua + s1 * USLOT;
+    const unsigned pcb = (unsigned)(s1 * PSLOT * 4);
+    int s3 = s1 + 2;                   // ring slot of the chunk three ahead
+    s3 = s3 >= 3 ? s3 - 3 : s3;
+#define W4_M(X, S)                                                                              \
+    acc[X] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[X][S], b[X][S], acc[X], 0, 0, 0);           \
+    __builtin_amdgcn_sched_barrier(0);
+    W4_M(0, 0) win_load(pcb, 0); __builtin_amdgcn_sched_barrier(0);
+    W4_M(1, 0) win_load(pcb, 1); __builtin_amdgcn_sched_barrier(0);
+    W4_M(2, 0) issue_u(s3); __builtin_amdgcn_sched_barrier(0);
+    W4_M(3, 0) issue_p(s3); __builtin_amdgcn_sched_barrier(0);
+    W4_M(4, 0)
+#pragma unroll
+    for (int x = 0; x < 8; ++x) an[x] = *reinterpret_cast<const w4_f32x2*>(uc + x * 128);
+    __builtin_amdgcn_sched_barrier(0);
+    W4_M(5, 0) W4_M(6, 0) win_transform(bn, 0); __builtin_amdgcn_sched_barrier(0);
+    W4_M(7, 0) W4_M(0, 1) W4_M(1, 1) win_transform(bn, 1); __builtin_amdgcn_sched_barrier(0);
+    W4_M(2, 1) W4_M(3, 1) W4_M(4, 1) W4_M(5, 1) W4_M(6, 1) W4_M(7, 1)
+#undef W4_M
+    scf_wait_vmcnt_imm<GRP>();
+    __syncthreads();
+    s1 = s1 == 2 ? 0 : s1 + 1;
+  };
+  int c = 0;
+  for (; c + 1 < q.nchunk; c += 2) {
+    chunk(a0, b0, a1, b1);
+    chunk(a1, b1, a0, b0);
+  }
+  if (c < q.nchunk) chunk(a0, b0, a1, b1);
+  scf_wait_vmcnt_imm<0>();             // the zero-filled groups past the end
+
+  // ---- output transform, then the shared fused epilogue on the four pixels' 16-row fragments ----
+  w4_f32x16 o[1][4];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float s12 = acc[1][r] + acc[2][r], d12 = acc[1][r] - acc[2][r];
+    const float s34 = acc[3][r] + acc[4][r], d34 = acc[3][r] - acc[4][r];
+    const float s56 = acc[5][r] + acc[6][r], d56 = acc[5][r] - acc[6][r];
+    o[0][0][r] = ((acc[0][r] + s12) + s34) + s56;
+    o[0][1][r] = __builtin_fmaf(0.5f, d56, __builtin_fmaf(2.f, d34, d12));
+    o[0][2][r] = __builtin_fmaf(0.25f, s56, __builtin_fmaf(4.f, s34, s12));
+    o[0][3][r] = __builtin_fmaf(0.125f, d56, __builtin_fmaf(8.f, d34, d12)) + acc[7][r];
+  }
+  ConvEpi e2 = e;
+  if (pre_res) e2.res = nullptr;       // consumed through the accumulators
+  scf_conv_epilogue_tile<1, 4>(p, e2, o, (f0 + cw) * 32, half, pix, p.out_div != 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Host side: packing and launch
+// ---------------------------------------------------------------------------------------------------
+extern "C" int64_t scf_pack_conv_weight_wino1d4_size(int32_t cout, int32_t cin) {
+  if (cout <= 0 || cin <= 0) return 0;
+  const int64_t F = (cout + 31) / 32, nchunk = (cin + W4_KC - 1) / W4_KC;
+  return nchunk * F * W4_UF;
+}
+
+// w: (Cout, Cin, 5) = a 1 x 5 or 5 x 1 kernel's taps in filter order
+extern "C" int scf_pack_conv_weight_wino1d4(const float* w, int32_t cout, int32_t cin, float* out) {
+  if (!w || !out || cout <= 0 || cin <= 0) return SCF_EINVAL;
+  const int F = (cout + 31) / 32;
+  memset(out, 0, sizeof(float) * (size_t)scf_pack_conv_weight_wino1d4_size(cout, cin));
+  // G (8 x 5) for the points 0, 1, -1, 2, -2, 1/2, -1/2, infinity: row i = (1, a_i, ..., a_i^4) / prod_{k != i} (a_i - a_k),
+  // row 0 with the sign that goes with B^T row 0 = (d0 - d6) + 21/4 (d4 - d2)
+  static const double pts[7] = {0.0, 1.0, -1.0, 2.0, -2.0, 0.5, -0.5};
+  double G[8][5];
+  for (int i = 0; i < 7; ++i) {
+    double nrm = 1.0;
+    for (int k = 0; k < 7; ++k)
+      if (k != i) nrm *= pts[i] - pts[k];
+    if (i == 0) nrm = -nrm;
+    double pw = 1.0;
+    for (int k = 0; k < 5; ++k) { G[i][k] = pw / nrm; pw *= pts[i]; }
+  }
+  for (int k = 0; k < 5; ++k) G[7][k] = k == 4 ? 1.0 : 0.0;
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci) {
+      const float* g = w + ((size_t)co * cin + ci) * 5;
+      const int chunk = ci / W4_KC, cl = ci % W4_KC, s = cl >> 1, kh = cl & 1;
+      const int frag = co / 32, m = co % 32;
+      for (int i = 0; i < 8; ++i) {
+        double u = 0.0;
+        for (int k = 0; k < 5; ++k) u += G[i][k] * g[k];
+        out[(((size_t)chunk * F + frag) * 8 + i) * 128 + kh * 64 + m * 2 + s] = (float)u;
+      }
+    }
+  return SCF_OK;
+}
+
+// Tile selection + launch; SCF_EUNSUPPORTED -> the caller goes on to the F(2, 5) / direct kernels.
+// info: {8 transform positions, 4 fragments per block, blocks, LDS bytes}.  any_grid: also on grids the F(2, 5) kernel fills
+// better (tests of ragged shapes).
+int scf_conv_wino1d4_dispatch(ConvK k, const float* wu, int N, bool any_grid, bool dry_run, int* info, hipStream_t st) {
+  const bool vert = k.KH == 5 && k.KW == 1 && k.pad_h == 2 && k.pad_w == 0;
+  const bool horz = k.KH == 1 && k.KW == 5 && k.pad_h == 0 && k.pad_w == 2;
+  if (!wu || !(vert || horz) || k.stride != 1 || k.w_ns != 0 || k.out_tile) return SCF_EUNSUPPORTED;
+  if (k.in1 && (k.C0 % W4_KC) != 0) return SCF_EUNSUPPORTED;
+  if (((uintptr_t)wu & 15) || (long long)W4_KC * k.H * k.W * 4 >= 0x7fffffffLL) return SCF_EUNSUPPORTED;
+  const int F = (k.Cout + 31) / 32;
+  if (F % 2) return SCF_EUNSUPPORTED;                   // blocks take pairs of channel fragments
+  const bool px4 = (k.W % 4) == 0 && (((uintptr_t)k.in0 | (uintptr_t)k.in1) & 15) == 0 && (k.in0_ns % 4) == 0 && (k.in1_ns % 4) == 0;
+  if (vert && !px4) return SCF_EUNSUPPORTED;
+  const int TW = 2;
+  int txl;
+  Wino4K q;
+  q.wu = wu; q.F = F;
+  if (vert) {
+    txl = k.Wo > 16 ? 5 : 4;                            // 32 columns x 1 tile row, or 16 x 2
+    const int TXW = 1 << txl, TYW = 32 >> txl;
+    q.PH = 4 * TW * TYW + 4; q.PWp = 32;
+    q.sx = (k.Wo + TXW - 1) / TXW;
+    q.sy = (k.Ho + 4 * TW * TYW - 1) / (4 * TW * TYW);
+  } else {
+    const int tcols = (k.Wo + 3) / 4;
+    txl = 3;                                            // 8 tiles = 32 pixels per group row unless narrower wastes less
+    if (tcols < 8) { txl = 1; while ((1 << txl) < tcols) ++txl; }
+    else {
+      int best = (tcols + 15) / 16 * 16;                // 16 tiles per row (64 pixels) as the widest candidate
+      txl = 4;
+      for (int l = 3; l >= 2; --l) {
+        const int wpad = (tcols + (1 << l) - 1) >> l << l;
+        if (wpad * 10 <= best * 9) { best = wpad; txl = l; }
+      }
+    }
+    const int TXW = 1 << txl, TYW = 32 >> txl;
+    q.PH = TW * TYW; q.PWp = px4 ? 4 * TXW + 8 : 4 * TXW + 4;
+    q.sx = (k.Wo + 4 * TXW - 1) / (4 * TXW);
+    q.sy = (k.Ho + TW * TYW - 1) / (TW * TYW);
+  }
+  q.txl = txl;
+  q.PPL = q.PH * q.PWp;
+  const int cells = W4_KC * q.PPL / (px4 ? 4 : 1);
+  const int npi = px4 ? (cells <= 512 ? 2 : 3) : 5;
+  if (cells > npi * 256 || (!vert && px4 && npi != 2)) return SCF_EUNSUPPORTED;
+  q.nchunk = (k.Cin + W4_KC - 1) / W4_KC;
+  q.mblocks = F / 2;
+  const long long nblk = (long long)N * q.sx * q.sy * q.mblocks;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
+  // a block is twice the pixels of an F(2, 5) block: up to CUs / 2 blocks the F(2, 5) kernel, one block per CU too, is the
+  // faster one (1152 vs 1536 MFMAs per wave at Cin 384); above that its blocks share SIMDs and this kernel wins even with
+  // one wave per SIMD (MI355X, GRU q launch at batch 32 = 256 blocks: 73 ... 85 us vs 95 ... 105 us)
+  if (!any_grid && nblk * 2 <= (long long)scf_cu_count()) return SCF_EUNSUPPORTED;
+  const size_t ldsb = (size_t)(3 * 2 * W4_UF + 3 * npi * (px4 ? 1024 : 256)) * sizeof(float);
+  if (info) { info[0] = 8; info[1] = 4; info[2] = (int)nblk; info[3] = (int)ldsb; }      // positions, fragments per block
+  if (dry_run) return SCF_OK;
+  if (vert && npi == 2) scf_launch((conv_wino1d4_kernel<true, true, 2>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
+  else if (vert) scf_launch((conv_wino1d4_kernel<true, true, 3>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
+  else if (px4) scf_launch((conv_wino1d4_kernel<false, true, 2>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
+  else scf_launch((conv_wino1d4_kernel<false, false, 5>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
+  return scf_launch_status();
+}

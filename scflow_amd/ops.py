@@ -25,7 +25,7 @@ from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_GRU_Q, CONV_G
 
 Tensor = torch.Tensor
 
-__all__ = ['record_conv_kernels', 'PackedConv', 'conv_desc', 'gru_passes', 'scflow_iteration', 'side_stream_handle', 'pyramid_layout', 'untile_level', 'level_storage_shape', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision', 'set_conv_winograd', 'get_conv_winograd', 'pack_conv_weight_wino', 'pack_conv_weight_wino1d',
+__all__ = ['record_conv_kernels', 'PackedConv', 'conv_desc', 'gru_passes', 'scflow_iteration', 'side_stream_handle', 'pyramid_layout', 'untile_level', 'level_storage_shape', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision', 'set_conv_winograd', 'get_conv_winograd', 'pack_conv_weight_wino', 'pack_conv_weight_wino1d', 'pack_conv_weight_wino1d4',
            'get_conv_precision', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
            'instance_norm', 'group_norm_relu', 'linear', 'fc_splitk', 'fc_slices', 'pose_update', 'reproject_flow',
            'unproject_depth', 'linear_pair', 'resize_bilinear', 'convex_upsample', 'avgpool2x2', 'copy_channels',
@@ -291,6 +291,20 @@ def pack_conv_weight_wino1d(weight: Tensor) -> Tensor:
     return out.to(weight.device)
 
 
+def pack_conv_weight_wino1d4(weight: Tensor) -> Tensor:
+    """(Cout, Cin, 1, 5) or (Cout, Cin, 5, 1) -> U = G g in conv_wino1d4.hip's layout, on the weight's device
+    (``scf_pack_conv_weight_wino1d4``: G = the 8 x 5 matrix of the points 0, 1, -1, 2, -2, 1/2, -1/2, infinity;
+    computed in double, rounded once)."""
+    cout, cin, kh, kw = weight.shape
+    if (kh, kw) not in ((1, 5), (5, 1)):
+        raise ValueError('F(4, 5) packing: 1x5 / 5x1 kernels')
+    lib = _lib.load()
+    host_w = weight.detach().to('cpu', torch.float32).reshape(cout, cin, 5).contiguous()
+    out = torch.empty((int(lib.scf_pack_conv_weight_wino1d4_size(cout, cin)),), dtype=torch.float32)
+    _lib.check(lib.scf_pack_conv_weight_wino1d4(host_w.data_ptr(), cout, cin, out.data_ptr()), 'scf_pack_conv_weight_wino1d4')
+    return out.to(weight.device)
+
+
 _CONV_PRECISION = 'f32'
 _CONV_WINOGRAD = True
 
@@ -363,6 +377,7 @@ class PackedConv:
     g4t: int = 0
     wwino: Optional[Tensor] = None    # G g G^T packing (3x3, stride 1, pad 1, Cin >= 8)
     wwino1d: Optional[Tensor] = None  # G g packing (1x5 / 5x1, stride 1, 'same', Cin >= 16, Cout % 64 == 0)
+    wwino1d4: Optional[Tensor] = None  # the F(4, 5) packing of the same layers
 
     @staticmethod
     def from_weight(weight: Tensor, bias: Optional[Tensor], stride: int = 1,
@@ -395,7 +410,9 @@ class PackedConv:
                           pack_conv_weight_wino(weight) if (dma_packing and (kh, kw, stride, ph, pw) == (3, 3, 1, 1, 1)
                                                             and cin >= 8) else None,
                           pack_conv_weight_wino1d(weight) if (dma_packing and stride == 1 and cin >= 16 and cout % 64 == 0
-                                                              and (kh, kw, ph, pw) in ((1, 5, 0, 2), (5, 1, 2, 0))) else None)
+                                                              and (kh, kw, ph, pw) in ((1, 5, 0, 2), (5, 1, 2, 0))) else None,
+                          pack_conv_weight_wino1d4(weight) if (dma_packing and stride == 1 and cin >= 16 and cout % 64 == 0
+                                                               and (kh, kw, ph, pw) in ((1, 5, 0, 2), (5, 1, 2, 0))) else None)
 
     @staticmethod
     def _tiny(weight, kh, kw, stride, dma_packing):
@@ -492,6 +509,7 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
         d.wp_wino = pc.wwino.data_ptr()
     elif _CONV_WINOGRAD and pc.wwino1d is not None:
         d.wp_wino1d = pc.wwino1d.data_ptr()
+        d.wp_wino1d4 = pc.wwino1d4.data_ptr() if pc.wwino1d4 is not None else None
     if x1 is not None:
         d.wp_taps = None                # the thin-input kernel takes one input segment
     if pc.wp_alt is not None and (c1 == 0 or c0 % 32 == 0):
@@ -503,13 +521,13 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
             use_alt = False
             # the KC decision describes the DIRECT register-staged kernel: asked with the Winograd packings
             # cleared, so that the cached plan does not depend on whether Winograd was on at the first call
-            ww, ww1, d.wp_wino, d.wp_wino1d = d.wp_wino, d.wp_wino1d, None, None
+            ww, ww1, ww4, d.wp_wino, d.wp_wino1d, d.wp_wino1d4 = d.wp_wino, d.wp_wino1d, d.wp_wino1d4, None, None, None
             if (lib.scf_conv2d_query(C.byref(d), info) == 0 and info[0] * info[1] == 1
                     and 0 <= info[3] * 64 < 6000):
                 d.wp, d.KC = pc.wp_alt.data_ptr(), 32
                 use_alt = lib.scf_conv2d_query(C.byref(d), info) == 0
                 d.wp, d.KC = pc.wp.data_ptr(), pc.kc
-            d.wp_wino, d.wp_wino1d = ww, ww1
+            d.wp_wino, d.wp_wino1d, d.wp_wino1d4 = ww, ww1, ww4
             pc.plans[key] = use_alt
         if use_alt:
             d.wp, d.KC = pc.wp_alt.data_ptr(), 32
@@ -527,8 +545,8 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
         tag = ''
         if d.wp_wino or d.wp_wino1d:    # does a Winograd kernel take this launch (grid-size policy)?
             info = (C.c_int32 * 4)()
-            if lib.scf_conv2d_query(C.byref(d), info) == 0 and info[3] < 0 and info[0] in (16, 6):
-                tag = ' [winograd]' if info[0] == 16 else ' [winograd F(2,5)]'
+            if lib.scf_conv2d_query(C.byref(d), info) == 0 and info[3] < 0 and info[0] in (16, 6, 8):
+                tag = {16: ' [winograd]', 6: ' [winograd F(2,5)]', 8: ' [winograd F(4,5)]'}[info[0]]
         _CONV_EVENTS.append((tm, 2.0 * pc.cin * pc.kh * pc.kw * pc.cout * ho * wo * n,
                              f'{pc.cin}->{pc.cout} {pc.kh}x{pc.kw}/s{pc.stride} @{ho}x{wo} N{n}' + tag))
         return out
@@ -558,6 +576,8 @@ def _gru_passes(packs):
             g.wp_zr_a4t, g.wp_q_a4t, g.a4t_groups = pzr.wp4t.data_ptr(), pq.wp4t.data_ptr(), pzr.g4t
         if _CONV_WINOGRAD and not f16 and pzr.wwino1d is not None and pq.wwino1d is not None:
             g.wp_zr_wino1d, g.wp_q_wino1d = pzr.wwino1d.data_ptr(), pq.wwino1d.data_ptr()
+            if pzr.wwino1d4 is not None and pq.wwino1d4 is not None:
+                g.wp_zr_wino1d4, g.wp_q_wino1d4 = pzr.wwino1d4.data_ptr(), pq.wwino1d4.data_ptr()
     return arr
 
 
@@ -638,7 +658,7 @@ def conv_timing(enable: bool):
     """like ``lookup_timing`` for the convolution launches: enable=False returns a list of
     (microseconds, algorithmic flops = 2*Cin*KH*KW*Cout*Ho*Wo*N, shape tag) per launch; the tag ends in
     ' [winograd]' when the F(2x2, 3x3) kernel ran the launch (it executes 1 / 2.25 of those flops), in
-    ' [winograd F(2,5)]' for the 1x5 / 5x1 kernel (1 / 1.667)."""
+    ' [winograd F(2,5)]' / ' [winograd F(4,5)]' for the 1x5 / 5x1 kernels (1 / 1.667, 1 / 2.5)."""
     global _CONV_EVENTS
     if enable:
         _CONV_EVENTS = []
@@ -648,12 +668,13 @@ def conv_timing(enable: bool):
     return list(zip(_read_timers([e[0] for e in evs]), [e[1] for e in evs], [e[2] for e in evs]))
 
 
-TUNE_KEYS = {'wino_variant': 1, 'dma_force_ksplit': 2, 'dma_ksplit_groups': 3}
+TUNE_KEYS = {'wino_variant': 1, 'dma_force_ksplit': 2, 'dma_ksplit_groups': 3, 'wino1d4': 4}
 
 
 def tune(key: str, value: int) -> int:
     """measurement knob of the library (``scf_tune``, scflow_hip_prof.h): returns the previous value.
-    ``'wino_variant'``: 0 = the dispatch's choice, 1 = pair kernel, 2 / 3 = quarter-domain kernel (4 / 8 waves)."""
+    ``'wino_variant'``: 0 = the dispatch's choice, 1 = pair kernel, 2 / 3 = quarter-domain kernel (4 / 8 waves);
+    ``'wino1d4'``: 1 = F(4, 5) where the dispatch prefers it (default), 0 = never, 2 = on every grid it supports."""
     return int(_lib.load().scf_tune(TUNE_KEYS[key], int(value)))
 
 

@@ -426,12 +426,15 @@ WINO1D_CASES = [
 ]
 
 
+@pytest.mark.parametrize('form', ['F(2,5)', 'F(4,5)'])
 @pytest.mark.parametrize('case', WINO1D_CASES)
-def test_conv2d_winograd_1d(case):
-    """F(2, 5) kernel (conv_wino1d.hip) vs torch fp64 and vs the direct kernel, plain epilogue with residual
-    + ReLU; the GRU epilogues on it are covered by test_sepconv_gru_winograd."""
+def test_conv2d_winograd_1d(case, form):
+    """F(2, 5) kernel (conv_wino1d.hip) and F(4, 5) kernel (conv_wino1d4.hip; on every grid here: the ragged
+    cases are below its dispatch threshold) vs torch fp64 and vs the direct kernel, plain epilogue with residual
+    + ReLU; the GRU epilogues on them are covered by test_sepconv_gru_winograd."""
     import ctypes as C
     n, cin, cout, k, H, W, c0 = case
+    f4 = form == 'F(4,5)'
     pad = (0, 2) if k == (1, 5) else (2, 0)
     x = rnd((n, cin, H, W), 50)
     wt = rnd((cout, cin, *k), 51, (1.0 / (cin * 5)) ** 0.5)
@@ -446,6 +449,9 @@ def test_conv2d_winograd_1d(case):
     wc = wt.reshape(cout, cin, 5).contiguous()
     assert lib.scf_pack_conv_weight_wino1d(wc.data_ptr(), cout, cin, host.data_ptr()) == 0
     assert torch.equal(host, pc.wwino1d.cpu())
+    host4 = torch.empty(lib.scf_pack_conv_weight_wino1d4_size(cout, cin))
+    assert lib.scf_pack_conv_weight_wino1d4(wc.data_ptr(), cout, cin, host4.data_ptr()) == 0
+    assert torch.equal(host4, pc.wwino1d4.cpu())
     xd = x.to(DEV)
     x0, x1 = (xd[:, :c0], xd[:, c0:]) if c0 else (xd, None)
     kw = dict(res=res.to(DEV), act=ops.ACT_RELU)
@@ -453,17 +459,21 @@ def test_conv2d_winograd_1d(case):
     try:
         direct = ops.conv2d(pc, x0, x1, **kw)
         ops.set_conv_winograd(True)
+        ops.tune('wino1d4', 2 if f4 else 0)
         d, _ = ops.conv_desc(pc, x0, x1, **kw)
         info = (C.c_int32 * 4)()
         assert lib.scf_conv2d_query(C.byref(d), info) == 0
-        assert info[3] < 0 and info[0] == 6 and info[2] >= 128, list(info)
-        got = ops.conv2d(pc, x0, x1, **kw)
+        assert info[3] < 0 and info[0] == (8 if f4 else 6) and info[2] >= (64 if f4 else 128), list(info)
+        with ops.record_conv_kernels() as ran:
+            got = ops.conv2d(pc, x0, x1, **kw)
+        assert [kk for _, kk in ran] == ['winograd ' + form], ran
     finally:
+        ops.tune('wino1d4', 1)
         ops.set_conv_winograd(prev)
     e_dir = float((direct.cpu() - want).abs().max())
     e_win = float((got.cpu() - want).abs().max())
-    print(f'winograd F(2,5) {case}: max err {e_win:.2e} (direct kernel {e_dir:.2e})')
-    close(got, want, atol=2e-5, what='winograd 1d ' + str(case))
+    print(f'winograd {form} {case}: max err {e_win:.2e} (direct kernel {e_dir:.2e})')
+    close(got, want, atol=2e-5, what=f'winograd {form} ' + str(case))
 
 
 @pytest.mark.parametrize('seed', range(12))
@@ -474,7 +484,10 @@ def test_winograd_kernels_random_shapes(seed):
     import random
     rng = random.Random(1000 + seed)
     lib = ops._lib.load()
-    for kind in ('2d', '1dh', '1dv'):
+    for kind in ('2d', '1dh', '1dv', '1dh4', '1dv4'):
+        f4 = kind.endswith('4')          # F(4, 5) on every grid (2), else F(2, 5) only (0)
+        ops.tune('wino1d4', 2 if f4 else 0)
+        kind = kind[:3]
         cin = rng.choice([16, 20, 36, 64, 72, 130])
         cout = rng.choice([64, 128, 192]) if kind != '2d' else rng.choice([32, 40, 64, 96, 126, 160])
         H, W = rng.choice([(16, 16), (20, 28), (23, 30), (32, 32), (33, 40), (48, 36), (12, 64)])
@@ -491,11 +504,12 @@ def test_winograd_kernels_random_shapes(seed):
             xd = rnd((n, cin, H, W), 63 + seed).to(DEV)
             d, _ = ops.conv_desc(pc, xd)
             assert lib.scf_conv2d_query(C.byref(d), info) == 0
-            if info[0] in (16, 6) or n >= 256:
+            if info[0] in (16, 6, 8) or n >= 256:
                 break
             n *= 2
-        if info[0] not in (16, 6):
+        if info[0] not in (16, 6, 8):
             continue                     # e.g. a vertical pass on rows that are not 16-byte aligned: direct kernels
+        assert (info[0] == 8) == f4, (kind, f4, list(info))
         c0 = rng.choice([0, 0, 8, 16]) if cin > 16 and (kind == '2d' or cin % 8 == 0) else 0
         res = rnd((n, cout, H, W), 64 + seed).to(DEV) if rng.random() < 0.5 else None
         act = ops.ACT_RELU if rng.random() < 0.5 else ops.ACT_NONE
@@ -507,8 +521,9 @@ def test_winograd_kernels_random_shapes(seed):
         finally:
             ops.set_conv_winograd(True)
         err = float((got - want).abs().max())
-        assert err <= 3e-5, (kind, n, cin, cout, H, W, c0, err)
+        assert err <= 3e-5, (kind, f4, n, cin, cout, H, W, c0, err)
         assert err > 0.0, 'the two paths gave identical bits: the Winograd kernel did not run'
+    ops.tune('wino1d4', 1)
 
 
 # Winograd error scales with |input| and |weight|, not with |output|: the transforms add and subtract the RAW
@@ -540,7 +555,7 @@ def _stress_operands(kind, shape_x, shape_w, seed):
     return x, wt
 
 
-def _winograd_stress(kind, k, pad, n, cin, cout, H, W, budget, info0, seed):
+def _winograd_stress(kind, k, pad, n, cin, cout, H, W, budget, info0, seed, wino1d4=0):
     import ctypes as C
     x, wt = _stress_operands(kind, (n, cin, H, W), (cout, cin, *k), seed)
     b = rnd((cout,), seed + 3, 0.1)
@@ -556,9 +571,11 @@ def _winograd_stress(kind, k, pad, n, cin, cout, H, W, budget, info0, seed):
         with ops.record_conv_kernels() as ran_d:
             direct = ops.conv2d(pc, xd)
         ops.set_conv_winograd(True)
+        ops.tune('wino1d4', wino1d4)
         with ops.record_conv_kernels() as ran_w:
             got = ops.conv2d(pc, xd)
     finally:
+        ops.tune('wino1d4', 1)
         ops.set_conv_winograd(prev)
     assert [kk for _, kk in ran_d] == ['direct-dma'], ran_d
     assert len(ran_w) == 1 and ran_w[0][1].startswith(info0), ran_w       # the Winograd kernel really ran
@@ -592,8 +609,18 @@ def test_conv2d_winograd_1d_stress_operands(kind, shape):
     _winograd_stress(kind, k, pad, n, cin, cout, H, W, budget=60.0, info0='winograd F(2,5)', seed=800 + cout)
 
 
-def test_sepconv_gru_winograd_drift_12_iterations():
-    """configs[4]'s recurrence: 12 iterations of the SepConvGRU at (8, 60, 80) on the F(2, 5) kernel vs the direct
+@pytest.mark.parametrize('kind', WINO_STRESS_OPERANDS)
+@pytest.mark.parametrize('shape', [(8, 256, 256, (1, 5), 32, 32), (8, 256, 128, (5, 1), 32, 32), (2, 256, 256, (5, 1), 60, 80)])
+def test_conv2d_winograd_1d4_stress_operands(kind, shape):
+    """F(4, 5) (points 0, +-1, +-2, +-1/2, inf) on the same stress operands and shapes, same budget as F(2, 5)."""
+    n, cin, cout, k, H, W = shape
+    pad = (0, 2) if k == (1, 5) else (2, 0)
+    _winograd_stress(kind, k, pad, n, cin, cout, H, W, budget=60.0, info0='winograd F(4,5)', seed=800 + cout, wino1d4=2)
+
+
+@pytest.mark.parametrize('form', ['F(2,5)', 'F(4,5)'])
+def test_sepconv_gru_winograd_drift_12_iterations(form):
+    """configs[4]'s recurrence: 12 iterations of the SepConvGRU at (8, 60, 80) on the F(2, 5) / the F(4, 5) kernel vs the direct
     kernels from the same state, fresh motion features every iteration, post-ReLU (one-signed) context and motion
     channels like the real network's.  The gates contract (|dh'| <= max(z, 1 - z) |dh| + ...), so the difference
     must stay at round-off level instead of growing with the iteration count."""
@@ -610,6 +637,7 @@ def test_sepconv_gru_winograd_drift_12_iterations():
     hist = {}
     for wino in (True, False):
         prev = ops.set_conv_winograd(wino)
+        ops.tune('wino1d4', 1 if form == 'F(4,5)' else 0)     # 1: the dispatch's own choice -- F(4, 5) on all 4 launches here
         try:
             gru.invalidate_packed()
             a = hx.to(DEV)
@@ -620,13 +648,14 @@ def test_sepconv_gru_winograd_drift_12_iterations():
                     a[:, hc + cc:] = torch.relu(rnd((n, xc, h, w), 196 + it) + 0.5).to(DEV)
                     gru.forward_inplace(a, ctx, cc)
                     states.append(a[:, :hc].clone())
-            want_kind = 'winograd F(2,5)' if wino else 'direct-dma'
+            want_kind = 'winograd ' + form if wino else 'direct-dma'
             assert len(ran) == 48 and all(k == want_kind for _, k in ran), ran[:4]
             hist[wino] = states
         finally:
+            ops.tune('wino1d4', 1)
             ops.set_conv_winograd(prev)
     errs = [float((a_ - b_).abs().max()) for a_, b_ in zip(hist[True], hist[False])]
-    print('[measured] SepConvGRU F(2,5) vs direct, (8, 60, 80), max |dh| per iteration: ' + ' '.join(f'{e:.1e}' for e in errs))
+    print(f'[measured] SepConvGRU {form} vs direct, (8, 60, 80), max |dh| per iteration: ' + ' '.join(f'{e:.1e}' for e in errs))
     assert errs[0] > 0.0
     assert max(errs) <= 1.2e-5, errs          # measured 3.0e-6 ... 3.8e-6 in every one of the 12 iterations
     assert errs[-1] <= 4.0 * max(errs[:3]) + 1e-6, f'the difference grows with the iteration count: {errs}'
@@ -768,10 +797,13 @@ def test_convgru_context_hoisting(n, h, w, kind):
         close(b[:, hc:], a[:, hc:].cpu(), atol=0, what='x untouched')
 
 
+@pytest.mark.parametrize('form', ['F(2,5)', 'F(4,5)'])
 @pytest.mark.parametrize('n,h,w', [(32, 32, 32), (8, 60, 80)])
-def test_sepconv_gru_winograd(n, h, w):
+def test_sepconv_gru_winograd(n, h, w, form):
     """SepConvGRU with its 1x5 / 5x1 gates on the F(2, 5) kernel (conv_wino1d.hip: both GRU epilogues, two input
-    segments, hoisted context term) vs the direct kernels, two iterations: the state differs by fp32 round-off."""
+    segments, hoisted context term) or, as the dispatch chooses at these sizes, the F(4, 5) kernel (conv_wino1d4.hip:
+    the context term enters through the accumulators) vs the direct kernels, two iterations: the state differs by
+    fp32 round-off."""
     from scflow_amd.modules import ConvGRU
     torch.manual_seed(12)
     hc, cc, xc = 128, 128, 128
@@ -783,18 +815,22 @@ def test_sepconv_gru_winograd(n, h, w):
     outs = {}
     for wino in (True, False):
         prev = ops.set_conv_winograd(wino)
+        ops.tune('wino1d4', 1 if form == 'F(4,5)' else 0)
         try:
             gru.invalidate_packed() if hasattr(gru, 'invalidate_packed') else None
             a = hx.to(DEV)
             ctx = gru.context_terms(a[:, hc:hc + cc])
-            for it in range(2):
-                a[:, hc + cc:] = rnd((n, xc, h, w), 96 + it).to(DEV)
-                gru.forward_inplace(a, ctx, cc)
+            with ops.record_conv_kernels() as ran:
+                for it in range(2):
+                    a[:, hc + cc:] = rnd((n, xc, h, w), 96 + it).to(DEV)
+                    gru.forward_inplace(a, ctx, cc)
+            assert len(ran) == 8 and all(k == ('winograd ' + form if wino else 'direct-dma') for _, k in ran), ran
             outs[wino] = a[:, :hc].clone()
         finally:
+            ops.tune('wino1d4', 1)
             ops.set_conv_winograd(prev)
     err = float((outs[True] - outs[False]).abs().max())
-    print(f'[measured] SepConvGRU F(2,5) vs direct kernels, {n}x{h}x{w}: max |dh| after 2 iterations {err:.2e}')
+    print(f'[measured] SepConvGRU {form} vs direct kernels, {n}x{h}x{w}: max |dh| after 2 iterations {err:.2e}')
     assert 0.0 < err <= 2e-5, err
 
 
@@ -1099,6 +1135,15 @@ def test_sepconv_gru_c_entry(n, h, w, kind):
                 w1.append(u.to(DEV))
             g.wp_zr_wino1d, g.wp_q_wino1d = w1[0].data_ptr(), w1[1].data_ptr()
             bufs += w1
+            w4 = []                                   # and the F(4, 5) ones
+            for wt in (wzr, wq.contiguous()):
+                co, ci = wt.shape[:2]
+                u = torch.empty(lib.scf_pack_conv_weight_wino1d4_size(co, ci))
+                taps = wt.reshape(co, ci, 5).contiguous()
+                assert lib.scf_pack_conv_weight_wino1d4(taps.data_ptr(), co, ci, u.data_ptr()) == 0
+                w4.append(u.to(DEV))
+            g.wp_zr_wino1d4, g.wp_q_wino1d4 = w4[0].data_ptr(), w4[1].data_ptr()
+            bufs += w4
         keep += bufs
         g.KH, g.KW, g.pad_h, g.pad_w = k[0], k[1], pad[0], pad[1]
         g.wp_zr, g.wp_zr_a4, g.wp_q, g.wp_q_a4 = (t.data_ptr() for t in bufs[:4])

@@ -172,12 +172,12 @@ def test_config4_full_size_480x640_12iters_batch8(dispatch_check):
         f8, o8 = m.get_flow(rend.to(DEV), real.to(DEV))
     assert len(f8) == 12 and f8[-1].shape == (8, 2, 480, 640) and o8[-1].shape == (8, 1, 480, 640)
     assert bool(torch.isfinite(f8[-1]).all()) and bool(torch.isfinite(o8[-1]).all())
-    # batch 8 at 60x80: the 3x3 stride-1 layers of the loop run the F(2x2,3x3) kernel, the GRU gates F(2,5)
+    # batch 8 at 60x80: the 3x3 stride-1 layers of the loop run the F(2x2,3x3) kernel, the GRU gates F(4,5)
     dispatch_check('config4_batch8', ran)
     kinds = {(tag, k) for tag, k in ran}
     assert ('256->192 3x3/s1 @60x80 N8', 'winograd-q') in kinds, sorted(kinds)
-    assert any(k == 'winograd F(2,5)' and '1x5' in tag for tag, k in kinds), sorted(kinds)
-    assert any(k == 'winograd F(2,5)' and '5x1' in tag for tag, k in kinds), sorted(kinds)
+    assert any(k == 'winograd F(4,5)' and '1x5' in tag for tag, k in kinds), sorted(kinds)
+    assert any(k == 'winograd F(4,5)' and '5x1' in tag for tag, k in kinds), sorted(kinds)
     with torch.no_grad():
         fr, fl, hf, cf = oracle.extract_feat(rend, real, sd)
         wf, wo = oracle.raft_decoder_mask(fr, fl, torch.zeros((8, 2, 60, 80)), hf, cf, sd, iters=12)

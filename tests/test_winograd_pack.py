@@ -134,8 +134,47 @@ def test_wino1d_packing_reproduces_the_convolution(lib):
     assert np.abs(y - want).max() < 1e-5
 
 
+def test_wino1d4_packing_reproduces_the_convolution(lib):
+    """F(4, 5): the C packer's U through conv_wino1d4.hip's input / output transforms, written out the way the
+    kernel evaluates them, gives four outputs of the 5-tap convolution; so does its accumulator seeding of a
+    pre-activation term."""
+    rng = np.random.default_rng(14)
+    cout, cin = 64, 18
+    w = torch.from_numpy(rng.standard_normal((cout, cin, 1, 5)).astype(np.float32))
+    n = lib.scf_pack_conv_weight_wino1d4_size(cout, cin)
+    assert n == ((cin + 3) // 4) * 2 * 1024
+    host = torch.empty(n)
+    taps = w.reshape(cout, cin, 5).contiguous()
+    assert lib.scf_pack_conv_weight_wino1d4(taps.data_ptr(), cout, cin, host.data_ptr()) == 0
+    assert torch.equal(host, ops.pack_conv_weight_wino1d4(w))
+    assert torch.equal(host, ops.pack_conv_weight_wino1d4(w.reshape(cout, cin, 5, 1)))
+    u, full = _unpack(host.numpy().astype(np.float64), 8, cout, cin, 4)
+    assert np.all(full[:, :, cin:] == 0)
+    d = rng.standard_normal((cin, 8))
+    d0, d1, d2, d3, d4, d5, d6, d7 = d.T
+    t1, t2 = d2 + d6 - 4.25 * d4, d1 + d5 - 4.25 * d3
+    t3, t4 = d6 + 0.25 * d2 - 1.25 * d4, 0.5 * d1 - 2.5 * d3 + 2 * d5
+    t5, t6 = d6 + 4 * d2 - 5 * d4, 2 * d1 - 2.5 * d3 + 0.5 * d5
+    V = np.stack([(d0 - d6) + 5.25 * (d4 - d2), t1 + t2, t1 - t2, t3 + t4, t3 - t4, t5 + t6, t5 - t6,
+                  (d7 - d1) + 5.25 * (d3 - d5)])                      # (8, cin)
+    M = np.einsum('ioc,ic->io', u, V)
+    res = rng.standard_normal((4, cout))
+    M[0] += res[0] - res[2]
+    M[1] += 0.5 * (res[1] + res[2])
+    M[2] += 0.5 * (res[2] - res[1])
+    M[7] += res[3] - res[1]
+    s12, d12, s34, d34, s56, d56 = M[1] + M[2], M[1] - M[2], M[3] + M[4], M[3] - M[4], M[5] + M[6], M[5] - M[6]
+    y = np.stack([M[0] + s12 + s34 + s56, d12 + 2 * d34 + 0.5 * d56, s12 + 4 * s34 + 0.25 * s56,
+                  d12 + 8 * d34 + 0.125 * d56 + M[7]])
+    wd = taps.numpy().astype(np.float64)
+    want = np.stack([np.einsum('ock,ck->o', wd, d[:, o:o + 5]) for o in range(4)]) + res
+    assert np.abs(y - want).max() < 2e-5
+
+
 def test_wino_packers_reject_bad_arguments(lib):
     buf = torch.empty(16)
     assert lib.scf_pack_conv_weight_wino(None, 4, 4, buf.data_ptr()) != 0
     assert lib.scf_pack_conv_weight_wino1d(buf.data_ptr(), 0, 4, buf.data_ptr()) != 0
+    assert lib.scf_pack_conv_weight_wino1d4(buf.data_ptr(), 4, 0, buf.data_ptr()) != 0
     assert lib.scf_pack_conv_weight_wino_size(0, 4) == 0 and lib.scf_pack_conv_weight_wino1d_size(4, 0) == 0
+    assert lib.scf_pack_conv_weight_wino1d4_size(0, 4) == 0
