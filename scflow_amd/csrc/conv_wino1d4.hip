@@ -18,13 +18,17 @@
 //         r5 | r6 = (d6 + 4 d2 - 5 d4) +- (2 d1 - 5/2 d3 + 1/2 d5)
 //     and the output transform  y0 = M0 + ... + M6,  y1 = (M1 - M2) + 2 (M3 - M4) + 1/2 (M5 - M6),
 //         y2 = (M1 + M2) + 4 (M3 + M4) + 1/4 (M5 + M6),  y3 = (M1 - M2) + 8 (M3 - M4) + 1/8 (M5 - M6) + M7;
-//   * a GRU launch's pre-activation term (the hoisted context part, one value per output) goes INTO the accumulators at
-//     kernel start: positions 0, 1, 2, 7 take res0 - res2, (res1 + res2) / 2, (res2 - res1) / 2, res3 - res1 -- A^T maps
-//     exactly these back onto (res0, res1, res2, res3) -- so it costs no registers over the loop.
+//   * a GRU launch's pre-activation term (the hoisted context part, one value per output) goes INTO the accumulators:
+//     positions 0, 1, 2, 7 take res0 - res2, (res1 + res2) / 2, (res2 - res1) / 2, res3 - res1 -- A^T maps exactly these
+//     back onto (res0, res1, res2, res3) -- so it costs no registers over the loop.  It arrives during the first
+//     chunks, one output column per chunk, as a fourth copy stream (memory -> 4 KB of LDS per wave -> 16 reads): read
+//     at kernel start (r4m) it was a memory round trip of every block of the launch at the same time with the matrix
+//     cores idle, read in the epilogue it is the same at the end.
 // Error vs fp64: ~2.5x F(2, 5)'s on unit-scale operands, the same on the stress operands of tests/test_gpu_ops.py
 // (measured there in units of eps sum|w||x|).
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include "scf_common.h"
 #include "conv_kernels.h"
 #include "scf_dma.h"
@@ -53,6 +57,72 @@ __device__ __forceinline__ int w4_div(int e, int d, float rd) {       // floor(e
   q += (r >= d) ? 1 : 0;
   q -= (r < 0) ? 1 : 0;
   return q;
+}
+
+// The two GRU gate epilogues on a lane's 16 channel rows x 4 pixels, same arithmetic as the shared ones
+// (scf_epi_general_frag: + bias, sigmoid -> z | r h;  tanh -> (1 - z) h + z q), different memory schedule: the shared
+// code handles one pixel's fragment at a time = four dependent round trips for h (and z) at the end of every block of
+// the launch at the same time.  Here the operands of 8 rows x 4 pixels are requested together, twice; VEC (horizontal
+// passes, rows of 16-byte aligned pixel quadruples): one 16-byte access per row instead of four 4-byte ones 16 bytes
+// apart.  Needs whole channel fragments, Ch % 32 == 0 (a wave is all z rows or all r rows) and a 16-byte aligned bias.
+template <int KIND, bool VEC>
+__device__ __forceinline__ void w4_gru_epilogue(const ConvK& p, const ConvEpi& e, const w4_f32x16 (&o)[1][4], int cb,
+                                                const int (&pix)[4]) {
+  const int hc = p.Cout >> 1;
+  const bool upper = KIND == SCF_EPI_GRU_ZR && cb >= hc;              // wave-uniform
+  const float* hsrc = KIND == SCF_EPI_GRU_ZR ? e.gru_h - hc * e.HWo : e.gru_h;      // row co -> hsrc + co * HWo
+  float* dst = upper ? e.gru_aux - hc * e.HWo : e.out;
+  const scf_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  scf_f32x4 bv[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bv[g] = p.bias ? *reinterpret_cast<const scf_f32x4*>(p.bias + cb + 8 * g) : zero4;
+  auto load4 = [&](const float* row) __attribute__((always_inline)) {
+    scf_f32x4 v = zero4;
+    if (VEC) {
+      if (pix[0] >= 0) v = *reinterpret_cast<const scf_f32x4*>(row + pix[0]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (pix[j] >= 0) v[j] = row[pix[j]];
+    }
+    return v;
+  };
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) {
+    scf_f32x4 hv[8], zv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = hb * 8 + q;
+      const int off = (cb + 8 * (r >> 2) + (r & 3)) * e.HWo;
+      hv[q] = (KIND == SCF_EPI_GRU_Q || upper) ? load4(hsrc + off) : zero4;
+      zv[q] = KIND == SCF_EPI_GRU_Q ? load4(e.gru_z + off) : zero4;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = hb * 8 + q;
+      const int off = (cb + 8 * (r >> 2) + (r & 3)) * e.HWo;
+      scf_f32x4 w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = o[0][j][r] + bv[r >> 2][r & 3];
+        if (KIND == SCF_EPI_GRU_ZR) {
+          const float sg = scf_fast_sigmoid(v);
+          w[j] = upper ? sg * hv[q][j] : sg;
+        } else {
+          w[j] = (1.f - zv[q][j]) * hv[q][j] + zv[q][j] * scf_fast_tanh(v);
+        }
+      }
+      if (VEC) {
+        if (pix[0] >= 0) *reinterpret_cast<scf_f32x4*>(dst + off + pix[0]) = w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (pix[j] >= 0) dst[off + pix[j]] = w[j];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 template <bool VERT, bool PX4, int NPI>
@@ -85,7 +155,8 @@ void conv_wino1d4_kernel(ConvK p, Wino4K q) {
 
   float* Us = w4_lds;
   float* Ps = Us + 3 * USLOT;
-  const unsigned u_lds = scf_lds_addr(Us), p_lds = scf_lds_addr(Ps);
+  float* Rs = Ps + 3 * PSLOT + wave * 1024;                     // GRU launches: [16 rows][64 lanes] of the pre-activation term
+  const unsigned u_lds = scf_lds_addr(Us), p_lds = scf_lds_addr(Ps), r_lds = scf_lds_addr(Rs);
 
   // ---- chunk-invariant copy offsets ----
   // patch = 4 channel planes of PH rows x PWp floats: horizontal: the block's rows, columns from x0 - 2 (x0 - 4 with
@@ -199,23 +270,35 @@ void conv_wino1d4_kernel(ConvK p, Wino4K q) {
   for (int x = 0; x < 8; ++x)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
-  // GRU launches: the pre-activation term enters through the accumulators (see the header), requested in front of the
-  // first copies: vector loads return in order, so the counted waits below still cover exactly the copies
+  // GRU launches: the pre-activation term enters through the accumulators (see the header).  Chunk k = 0 ... 3 requests
+  // output column k of the wave's fragment (16 copies of one row x 64 lanes, issued IN FRONT of the chunk's U / patch
+  // copies, so the counted wait at its end covers them), chunk k + 1 adds it in.  Rows past Cout: the descriptor range.
+  // Straight-line code in the first five chunks of EVERY launch (a branch around accumulator updates costs register
+  // copies): without a term the descriptor's range is empty, the copies deliver zeros and the adds add them.
   const bool pre_res = e.res && (p.mode == SCF_CONV_GRU_ZR || p.mode == SCF_CONV_GRU_Q) && p.out_div == 1.0f;
-  if (pre_res) {
+  const scf_rsrc4 rrs = scf_make_rsrc(pre_res ? e.res : p.out, pre_res ? (unsigned)(p.Cout * e.HWo * 4) : 0u);
+  const unsigned r_row0 = (unsigned)((((f0 + cw) * 32 + 4 * half) * e.HWo) * 4);
+  float rt[16];
+  auto res_issue = [&](int j) __attribute__((always_inline)) {
+    const unsigned vo = pix[j] >= 0 ? r_row0 + (unsigned)(pix[j] * 4) : SCF_BUF_OOB;
+    const unsigned dst = r_lds;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      scf_bdma_b32(rrs, vo + (unsigned)((8 * (r >> 2) + (r & 3)) * e.HWo * 4), dst + (unsigned)(r * 256));
+  };
+  auto res_read = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rt[r] = Rs[r * 64 + lane];
+  };
+  auto res_add = [&](int j) __attribute__((always_inline)) {            // column j of the term -> the positions A^T maps back onto it
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int co = (f0 + cw) * 32 + 8 * (r >> 2) + (r & 3) + 4 * half;
-      float rv[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) rv[j] = (pix[j] >= 0 && co < p.Cout) ? e.res[co * e.HWo + pix[j]] : 0.f;
-      acc[0][r] = rv[0] - rv[2];
-      acc[1][r] = 0.5f * (rv[1] + rv[2]);
-      acc[2][r] = 0.5f * (rv[2] - rv[1]);
-      acc[7][r] = rv[3] - rv[1];
+      if (j == 0) acc[0][r] += rt[r];
+      if (j == 1) { acc[1][r] = __builtin_fmaf(0.5f, rt[r], acc[1][r]); acc[2][r] = __builtin_fmaf(-0.5f, rt[r], acc[2][r]); acc[7][r] -= rt[r]; }
+      if (j == 2) { acc[0][r] -= rt[r]; acc[1][r] = __builtin_fmaf(0.5f, rt[r], acc[1][r]); acc[2][r] = __builtin_fmaf(0.5f, rt[r], acc[2][r]); }
+      if (j == 3) acc[7][r] += rt[r];
     }
-  }
-
+  };
   // ---- prologue: three chunks requested, two awaited ----
   issue_p(0); issue_u(0);
   issue_u(1); issue_p(1);
@@ -231,13 +314,20 @@ void conv_wino1d4_kernel(ConvK p, Wino4K q) {
   __syncthreads();                     // slot 0 of both rings is free again
 
   int s1 = 1;                          // ring slot of the next chunk
-  auto chunk = [&](const w4_f32x2 (&a)[8], const w4_f32x2 (&b)[8], w4_f32x2 (&an)[8], w4_f32x2 (&bn)[8]) {
+  auto chunk = [&](auto kc, const w4_f32x2 (&a)[8], const w4_f32x2 (&b)[8], w4_f32x2 (&an)[8], w4_f32x2 (&bn)[8]) {
+    constexpr int K = decltype(kc)::value;        // 0 ... 4: the chunk's number (the pre-activation term's stream), 5: any later one
     const float* uc = ua + s1 * USLOT;
     const unsigned pcb = (unsigned)(s1 * PSLOT * 4);
     int s3 = s1 + 2;                   // ring slot of the chunk three ahead
     s3 = s3 >= 3 ? s3 - 3 : s3;
 #define W4_M(X, S)                                                                              \
     acc[X] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[X][S], b[X][S], acc[X], 0, 0, 0);           \
+    __builtin_amdgcn_sched_barrier(0);
+    if (K >= 1 && K <= 4) {              // read back the column the last chunk requested, then request the next one
+      res_read();
+      __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the reads are done before the next copies can land there
+    }
+    if (K <= 3) res_issue(K);
     __builtin_amdgcn_sched_barrier(0);
     W4_M(0, 0) win_load(pcb, 0); __builtin_amdgcn_sched_barrier(0);
     W4_M(1, 0) win_load(pcb, 1); __builtin_amdgcn_sched_barrier(0);
@@ -251,16 +341,25 @@ void conv_wino1d4_kernel(ConvK p, Wino4K q) {
     W4_M(7, 0) W4_M(0, 1) W4_M(1, 1) win_transform(bn, 1); __builtin_amdgcn_sched_barrier(0);
     W4_M(2, 1) W4_M(3, 1) W4_M(4, 1) W4_M(5, 1) W4_M(6, 1) W4_M(7, 1)
 #undef W4_M
+    if (K >= 1 && K <= 4) res_add(K - 1);
+    __builtin_amdgcn_sched_barrier(0);
     scf_wait_vmcnt_imm<GRP>();
     __syncthreads();
     s1 = s1 == 2 ? 0 : s1 + 1;
   };
-  int c = 0;
+#define W4_K(k) std::integral_constant<int, k>()
+  chunk(W4_K(0), a0, b0, a1, b1);      // (the dispatch takes layers of at least five chunks)
+  chunk(W4_K(1), a1, b1, a0, b0);
+  chunk(W4_K(2), a0, b0, a1, b1);
+  chunk(W4_K(3), a1, b1, a0, b0);
+  chunk(W4_K(4), a0, b0, a1, b1);
+  int c = 5;
   for (; c + 1 < q.nchunk; c += 2) {
-    chunk(a0, b0, a1, b1);
-    chunk(a1, b1, a0, b0);
+    chunk(W4_K(5), a1, b1, a0, b0);
+    chunk(W4_K(5), a0, b0, a1, b1);
   }
-  if (c < q.nchunk) chunk(a0, b0, a1, b1);
+  if (c < q.nchunk) chunk(W4_K(5), a1, b1, a0, b0);
+#undef W4_K
   scf_wait_vmcnt_imm<0>();             // the zero-filled groups past the end
 
   // ---- output transform, then the shared fused epilogue on the four pixels' 16-row fragments ----
@@ -277,6 +376,22 @@ void conv_wino1d4_kernel(ConvK p, Wino4K q) {
   }
   ConvEpi e2 = e;
   if (pre_res) e2.res = nullptr;       // consumed through the accumulators
+  const int kind = scf_conv_epi_kind(p);
+  if ((kind == SCF_EPI_GRU_ZR || kind == SCF_EPI_GRU_Q) && !e2.res && p.out_div == 1.0f && (p.Cout & 63) == 0 &&
+      ((uintptr_t)p.bias & 15) == 0) {
+    const int cb = (f0 + cw) * 32 + 4 * half;
+    // pixel quadruples: a row's four outputs are one aligned 16-byte cell (x0 and Wo are multiples of 4: all in or all out)
+    const bool vec = !VERT && (p.Wo & 3) == 0 &&
+                     ((((uintptr_t)e.out | (uintptr_t)e.gru_h | (uintptr_t)e.gru_aux | (uintptr_t)e.gru_z) & 15) == 0);
+    if (kind == SCF_EPI_GRU_ZR) {
+      if (!VERT && vec) w4_gru_epilogue<SCF_EPI_GRU_ZR, true>(p, e2, o, cb, pix);
+      else w4_gru_epilogue<SCF_EPI_GRU_ZR, false>(p, e2, o, cb, pix);
+    } else {
+      if (!VERT && vec) w4_gru_epilogue<SCF_EPI_GRU_Q, true>(p, e2, o, cb, pix);
+      else w4_gru_epilogue<SCF_EPI_GRU_Q, false>(p, e2, o, cb, pix);
+    }
+    return;
+  }
   scf_conv_epilogue_tile<1, 4>(p, e2, o, (f0 + cw) * 32, half, pix, p.out_div != 1.0f);
 }
 
@@ -367,6 +482,7 @@ int scf_conv_wino1d4_dispatch(ConvK k, const float* wu, int N, bool any_grid, bo
   const int npi = px4 ? (cells <= 512 ? 2 : 3) : 5;
   if (cells > npi * 256 || (!vert && px4 && npi != 2)) return SCF_EUNSUPPORTED;
   q.nchunk = (k.Cin + W4_KC - 1) / W4_KC;
+  if (q.nchunk < 5) return SCF_EUNSUPPORTED;           // the kernel's first five chunks are peeled
   q.mblocks = F / 2;
   const long long nblk = (long long)N * q.sx * q.sy * q.mblocks;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
@@ -374,9 +490,17 @@ int scf_conv_wino1d4_dispatch(ConvK k, const float* wu, int N, bool any_grid, bo
   // faster one (1152 vs 1536 MFMAs per wave at Cin 384); above that its blocks share SIMDs and this kernel wins even with
   // one wave per SIMD (MI355X, GRU q launch at batch 32 = 256 blocks: 73 ... 85 us vs 95 ... 105 us)
   if (!any_grid && nblk * 2 <= (long long)scf_cu_count()) return SCF_EUNSUPPORTED;
-  const size_t ldsb = (size_t)(3 * 2 * W4_UF + 3 * npi * (px4 ? 1024 : 256)) * sizeof(float);
+  const size_t ldsb = (size_t)(3 * 2 * W4_UF + 3 * npi * (px4 ? 1024 : 256) + 4 * 1024) * sizeof(float);    // rings + the term's 4 KB per wave
   if (info) { info[0] = 8; info[1] = 4; info[2] = (int)nblk; info[3] = (int)ldsb; }      // positions, fragments per block
   if (dry_run) return SCF_OK;
+  const int cfg = vert ? (npi == 2 ? 0 : 1) : (px4 ? 2 : 3);
+  if (ldsb > 64 * 1024) {
+    static std::atomic<unsigned long long> raised[4];
+    const void* fn = cfg == 0 ? (const void*)conv_wino1d4_kernel<true, true, 2> : cfg == 1 ? (const void*)conv_wino1d4_kernel<true, true, 3>
+                   : cfg == 2 ? (const void*)conv_wino1d4_kernel<false, true, 2> : (const void*)conv_wino1d4_kernel<false, false, 5>;
+    const int rc = scf_raise_dynamic_lds(raised[cfg], fn, 80 * 1024);
+    if (rc != SCF_OK) return rc;
+  }
   if (vert && npi == 2) scf_launch((conv_wino1d4_kernel<true, true, 2>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
   else if (vert) scf_launch((conv_wino1d4_kernel<true, true, 3>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
   else if (px4) scf_launch((conv_wino1d4_kernel<false, true, 2>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);

@@ -509,6 +509,9 @@ def test_winograd_kernels_random_shapes(seed):
             n *= 2
         if info[0] not in (16, 6, 8):
             continue                     # e.g. a vertical pass on rows that are not 16-byte aligned: direct kernels
+        if f4 and info[0] == 6:
+            assert cin <= 16, (kind, cin, list(info))     # fewer than the five chunks the F(4, 5) kernel peels: F(2, 5)
+            continue
         assert (info[0] == 8) == f4, (kind, f4, list(info))
         c0 = rng.choice([0, 0, 8, 16]) if cin > 16 and (kind == '2d' or cin % 8 == 0) else 0
         res = rnd((n, cout, H, W), 64 + seed).to(DEV) if rng.random() < 0.5 else None

@@ -12,7 +12,7 @@ def bench(fn, reps=20):
     ts.sort()
     return ts[len(ts) // 2]
 for (k, pad) in (((1, 5), (0, 2)), ((5, 1), (2, 0))):
-    for cin in (256, 384):
+    for cin in (128, 256, 384):        # three chain lengths: the intercept is the launch's fixed cost
         hx = torch.randn((n, 384, H, W), device=DEV)
         w = torch.randn((256, cin, *k), device=DEV) * 0.05
         b = torch.randn((256,), device=DEV)
@@ -24,6 +24,8 @@ for (k, pad) in (((1, 5), (0, 2)), ((5, 1), (2, 0))):
         hv = hx[:, :128]
         if cin == 384:
             x0, x1 = hx, None
+        elif cin == 128:
+            x0, x1 = hx[:, :128], None
         else:
             x0, x1 = hx[:, :128], hx[:, 256:]
         fl = 2.0 * n * 256 * cin * 5 * H * W
