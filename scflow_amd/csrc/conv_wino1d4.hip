@@ -62,7 +62,8 @@ __device__ __forceinline__ int w4_div(int e, int d, float rd) {       // floor(e
 // The two GRU gate epilogues on a lane's 16 channel rows x 4 pixels, same arithmetic as the shared ones
 // (scf_epi_general_frag: + bias, sigmoid -> z | r h;  tanh -> (1 - z) h + z q), different memory schedule: the shared
 // code handles one pixel's fragment at a time = four dependent round trips for h (and z) at the end of every block of
-// the launch at the same time.  Here the operands of 8 rows x 4 pixels are requested together, twice; VEC (horizontal
+// the launch at the same time.  Here the operands of 16 rows x 4 pixels (z | r: h) or 8 rows x 4 pixels (q: h and z) are
+// requested together -- 64 registers, free by then; VEC (horizontal
 // passes, rows of 16-byte aligned pixel quadruples): one 16-byte access per row instead of four 4-byte ones 16 bytes
 // apart.  Needs whole channel fragments, Ch % 32 == 0 (a wave is all z rows or all r rows) and a 16-byte aligned bias.
 template <int KIND, bool VEC>
@@ -87,20 +88,21 @@ __device__ __forceinline__ void w4_gru_epilogue(const ConvK& p, const ConvEpi& e
     }
     return v;
   };
+  constexpr int RB = KIND == SCF_EPI_GRU_Q ? 8 : 16;      // rows per batch of operand requests: 64 registers of them
 #pragma unroll
-  for (int hb = 0; hb < 2; ++hb) {
-    scf_f32x4 hv[8], zv[8];
+  for (int hb = 0; hb < 16 / RB; ++hb) {
+    scf_f32x4 hv[RB], zv[RB];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int r = hb * 8 + q;
+    for (int q = 0; q < RB; ++q) {
+      const int r = hb * RB + q;
       const int off = (cb + 8 * (r >> 2) + (r & 3)) * e.HWo;
       hv[q] = (KIND == SCF_EPI_GRU_Q || upper) ? load4(hsrc + off) : zero4;
       zv[q] = KIND == SCF_EPI_GRU_Q ? load4(e.gru_z + off) : zero4;
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int r = hb * 8 + q;
+    for (int q = 0; q < RB; ++q) {
+      const int r = hb * RB + q;
       const int off = (cb + 8 * (r >> 2) + (r & 3)) * e.HWo;
       scf_f32x4 w;
 #pragma unroll

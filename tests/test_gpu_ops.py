@@ -423,6 +423,8 @@ WINO1D_CASES = [
     (24, 48, 64, (5, 1), 21, 28, 0),        # vertical, odd height
     (2, 64, 128, (1, 5), 60, 80, 0),        # 60 x 80 maps
     (2, 64, 128, (5, 1), 60, 80, 0),
+    (24, 44, 64, (5, 1), 24, 32, 0),        # 11 chunks of 4 (F(4, 5)), 5.5 of 8 (F(2, 5))
+    (20, 172, 128, (1, 5), 24, 32, 128),    # two input segments, a short last chunk in the second
 ]
 
 
