@@ -77,14 +77,18 @@ __device__ __forceinline__ void w4_gru_epilogue(const ConvK& p, const ConvEpi& e
   scf_f32x4 bv[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) bv[g] = p.bias ? *reinterpret_cast<const scf_f32x4*>(p.bias + cb + 8 * g) : zero4;
+  // operand loads are unconditional (a pixel outside the image reads pixel 0 of its row instead: one branch and one
+  // wait per element otherwise), stores are masked once per pixel column
+  int pl[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pl[j] = pix[j] >= 0 ? pix[j] : 0;
   auto load4 = [&](const float* row) __attribute__((always_inline)) {
-    scf_f32x4 v = zero4;
+    scf_f32x4 v;
     if (VEC) {
-      if (pix[0] >= 0) v = *reinterpret_cast<const scf_f32x4*>(row + pix[0]);
+      v = *reinterpret_cast<const scf_f32x4*>(row + pl[0]);
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (pix[j] >= 0) v[j] = row[pix[j]];
+      for (int j = 0; j < 4; ++j) v[j] = row[pl[j]];
     }
     return v;
   };
@@ -100,27 +104,39 @@ __device__ __forceinline__ void w4_gru_epilogue(const ConvK& p, const ConvEpi& e
       zv[q] = KIND == SCF_EPI_GRU_Q ? load4(e.gru_z + off) : zero4;
     }
     __builtin_amdgcn_sched_barrier(0);
+    scf_f32x4 w[RB];
 #pragma unroll
     for (int q = 0; q < RB; ++q) {
       const int r = hb * RB + q;
-      const int off = (cb + 8 * (r >> 2) + (r & 3)) * e.HWo;
-      scf_f32x4 w;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float v = o[0][j][r] + bv[r >> 2][r & 3];
         if (KIND == SCF_EPI_GRU_ZR) {
           const float sg = scf_fast_sigmoid(v);
-          w[j] = upper ? sg * hv[q][j] : sg;
+          w[q][j] = upper ? sg * hv[q][j] : sg;
         } else {
-          w[j] = (1.f - zv[q][j]) * hv[q][j] + zv[q][j] * scf_fast_tanh(v);
+          w[q][j] = (1.f - zv[q][j]) * hv[q][j] + zv[q][j] * scf_fast_tanh(v);
         }
       }
-      if (VEC) {
-        if (pix[0] >= 0) *reinterpret_cast<scf_f32x4*>(dst + off + pix[0]) = w;
-      } else {
+    }
+    if (VEC) {
+      if (pix[0] >= 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (pix[j] >= 0) dst[off + pix[j]] = w[j];
+        for (int q = 0; q < RB; ++q) {
+          const int r = hb * RB + q;
+          *reinterpret_cast<scf_f32x4*>(dst + (cb + 8 * (r >> 2) + (r & 3)) * e.HWo + pix[0]) = w[q];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (pix[j] >= 0) {
+#pragma unroll
+          for (int q = 0; q < RB; ++q) {
+            const int r = hb * RB + q;
+            dst[(cb + 8 * (r >> 2) + (r & 3)) * e.HWo + pix[j]] = w[q][j];
+          }
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
