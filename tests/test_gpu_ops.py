@@ -1000,7 +1000,8 @@ def test_reproject_full_size_matches_oracle():
 
 
 @pytest.mark.parametrize('shape,out', [((2, 2, 256, 256), (32, 32)), ((2, 2, 32, 32), (256, 256)),
-                                       ((1, 1, 32, 32), (256, 256)), ((1, 3, 12, 20), (5, 9))])
+                                       ((1, 1, 32, 32), (256, 256)), ((1, 3, 12, 20), (5, 9)), ((3, 2, 60, 80), (480, 640)),
+                                       ((2, 1, 9, 7), (30, 301)), ((1, 2, 8, 8), (1, 1))])
 def test_resize_bilinear(shape, out):
     a, b = rnd(shape, 70, 4.0), rnd(shape, 71)
     want = 0.125 * F.interpolate(a + b, size=out, mode='bilinear', align_corners=True)
