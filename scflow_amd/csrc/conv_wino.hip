@@ -609,6 +609,19 @@ void conv_wino_q_kernel(ConvK p, WinoK q) {
   //      Combination q = 16 f + r is finished by wave q >> 3 of the tile group; the others' pairs go through LDS:
   //      outbox[source wave][slot of the owner: 3][pair of combinations: 4][lane][4 floats] ----
   float* box = wn_lds + tw * (4 * 3072);
+  // the per-channel constants of the epilogue are requested HERE: their round trip runs under the output transform
+  // and the exchange instead of after them
+  const int cb = (f0 + (row >> 1)) * 32 + 16 * (row & 1) + 4 * half;
+  float bv[8], sc[8], sh[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int co = cb + 8 * (k >> 2) + (k & 3);
+    const int cc = co < p.Cout ? co : 0;
+    bv[k] = p.bias ? p.bias[cc] : 0.f;
+    sc[k] = p.scale ? p.scale[cc] : 1.f;
+    sh[k] = p.scale ? p.shift[cc] : 0.f;
+  }
+  __builtin_amdgcn_sched_barrier(0);
   wn_f32x4 own[4];
 #pragma unroll
   for (int qq = 0; qq < 32; qq += 2) {
@@ -640,16 +653,11 @@ void conv_wino_q_kernel(ConvK p, WinoK q) {
       if (sw == row) in[sw][kp] = own[kp];
       else in[sw][kp] = *reinterpret_cast<const wn_f32x4*>(box + (((sw * 3 + (row < sw ? row : row - 1)) * 4 + kp) * 64 + lane) * 4);
     }
-  const int cb = (f0 + (row >> 1)) * 32 + 16 * (row & 1) + 4 * half;
-  float bv[8], sc[8], sh[8];
   wn_f32x2 rr[8][2];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int co = cb + 8 * (k >> 2) + (k & 3);
     const int cc = co < p.Cout ? co : 0;
-    bv[k] = p.bias ? p.bias[cc] : 0.f;
-    sc[k] = p.scale ? p.scale[cc] : 1.f;
-    sh[k] = p.scale ? p.shift[cc] : 0.f;
     const int off = cc * e.HWo + oy * p.Wo + ox;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
