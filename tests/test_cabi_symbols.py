@@ -52,6 +52,19 @@ def test_version_and_error_strings():
     assert b'invalid' in lib.scf_error_string(-1)
 
 
+def test_tune_knobs_validate_their_values():
+    """scf_tune (scflow_hip_prof.h): returns the previous value, rejects unknown keys and out-of-range values, and
+    leaves the defaults in place (no GPU involved: the knobs are host-side dispatch state)."""
+    lib = _lib.load()
+    from scflow_amd import ops
+    assert lib.scf_tune(999, 0) < 0
+    assert lib.scf_tune(ops.TUNE_KEYS['wino1d4'], 3) < 0 and lib.scf_tune(ops.TUNE_KEYS['wino1d4'], -1) < 0
+    assert ops.tune('wino1d4', 0) == 1            # default: F(4, 5) where the dispatch prefers it
+    assert ops.tune('wino1d4', 2) == 0
+    assert ops.tune('wino1d4', 1) == 2
+    assert ops.tune('wino_variant', 0) == 0
+
+
 def test_conv_desc_layout_matches_c():
     """sizeof(scf_conv_desc) from a C compile must equal the ctypes mirror."""
     import ctypes, subprocess, tempfile
