@@ -62,8 +62,12 @@ enum {
   SCF_TUNE_WINO_VARIANT = 1,  /* F(2x2,3x3): 1 = pair kernel, 2 / 3 = quarter-domain kernel with 4 / 8 waves */
   SCF_TUNE_DMA_FORCE_KSPLIT = 2, /* 1: the LDS-DMA kernel takes its K-split tile (32 channels x 32 pixels per block) on every grid */
   SCF_TUNE_DMA_KSPLIT_GROUPS = 3, /* 1: K-split blocks keep one wave group (no intra-block split of the chunk chain) */
-  SCF_TUNE_WINO1D4 = 4        /* 1 (default): 1x5 / 5x1 layers that carry an F(4, 5) packing use it on large grids; 0: F(2, 5);
+  SCF_TUNE_WINO1D4 = 4,       /* 1 (default): 1x5 / 5x1 layers that carry an F(4, 5) packing use it on large grids; 0: F(2, 5);
                                  2: F(4, 5) on every grid it supports (tests of small ragged shapes) */
+  SCF_TUNE_LOOKUP_STORE = 6,  /* correlation lookup (r = 4, one group per block): cache policy of the output stores, 0 = the build's,
+                                 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt, 5 plain */
+  SCF_TUNE_LOOKUP_PIPE = 5    /* correlation lookup: 0 = the dispatch's own choice, 1 = one group per block (the r3 kernel),
+                                 2 / 3 = the pipelined kernel with two / three groups per block wherever it fits */
 };
 int scf_tune(int key, int value);
 int scf_conv_log_read(scf_conv_log_entry* out, int max_entries);

@@ -616,11 +616,15 @@ std::atomic<int> g_log_cap{0};
 int scf_wino_variant_set(int v);      // conv_wino.hip
 int scf_dma_force_ksplit_set(int v);  // conv_dma.hip
 int scf_dma_ksplit_groups_set(int v);
+int scf_lookup_pipe_set(int v);       // corr_lookup.hip
+int scf_lookup_store_set(int v);
 
 extern "C" int scf_tune(int key, int value) {
   if (key == SCF_TUNE_WINO_VARIANT) return scf_wino_variant_set(value);
   if (key == SCF_TUNE_DMA_FORCE_KSPLIT) return scf_dma_force_ksplit_set(value);
   if (key == SCF_TUNE_DMA_KSPLIT_GROUPS) return scf_dma_ksplit_groups_set(value);
+  if (key == SCF_TUNE_LOOKUP_PIPE) return scf_lookup_pipe_set(value);
+  if (key == SCF_TUNE_LOOKUP_STORE) return scf_lookup_store_set(value);
   if (key == SCF_TUNE_WINO1D4) {
     if (value < 0 || value > 2) return SCF_EINVAL;
     return g_wino1d4.exchange(value);

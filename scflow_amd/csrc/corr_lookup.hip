@@ -44,6 +44,13 @@
 #ifndef SCF_LOOKUP_STORE_MODE
 #define SCF_LOOKUP_STORE_MODE 2      // sc1 = write-through, see lk_store
 #endif
+// cache policy of the gather instructions (A/B builds of tools/lab/lookup_lab.hip): footprint taps / whole maps
+#ifndef SCF_LOOKUP_TAP_POL
+#define SCF_LOOKUP_TAP_POL " nt"
+#endif
+#ifndef SCF_LOOKUP_MAP_POL
+#define SCF_LOOKUP_MAP_POL " nt"
+#endif
 
 // tools/lab/lookup_lab.hip compiles this file with per-wave timeline stamps and ablation switches;
 // their code lives in tools/lab/lookup_lab_hooks.h.  The product build sees empty hooks.
@@ -53,11 +60,18 @@
 #define LK_LAB_PARAMS
 #define LK_TRACE(slot) do { } while (0)
 #define LK_TRACE_END(lvl) do { } while (0)
+#define LK_TRACE_U(g, lvl, slot) do { } while (0)
+#define LK_TRACE_END_U(g, lvl) do { } while (0)
+#define LK_LAB_PIPE_MODE(v) (v)
 #define LK_SKIP_DMA false
 #define LK_SKIP_STORE false
 #define LK_LAB_LAUNCH(p, nblk) do { } while (0)
+#define LK_LAB_SETUP(p, nblk) do { } while (0)
+#define LK_LAB_STAGGER do { } while (0)
+#define LK_EARLY_MAPS true
 #endif
 
+#define LK_MAXU 3        // units per wave of the pipelined kernel
 struct LookupParams {
   const float* lvl[SCF_MAX_LEVELS];
   int lh[SCF_MAX_LEVELS];
@@ -70,6 +84,11 @@ struct LookupParams {
   int woff[4];            // LDS offset (floats) of each wave slot's staging region
   int ngroups;            // ceil(total_q / 32)
   long long total_q;
+  // pipelined kernel (corr_lookup_pipe_kernel): a block owns `gpb` consecutive groups; its gpb * L
+  // (group, level) units are dealt to the four waves by cost, each wave runs its units cheapest first
+  int gpb, nsg;                     // groups per block, ceil(ngroups / gpb)
+  unsigned char unit[4][4];         // wave slot, position: (group within the block << 4) | level; 0xff = none
+  int uoff[4][LK_MAXU];             // LDS offset (floats) of that unit's staging region
   LK_LAB_PARAMS
 };
 
@@ -114,7 +133,7 @@ __device__ __forceinline__ lk_rsrc_t lk_make_rsrc(const void* base, unsigned byt
 __device__ __forceinline__ void lk_dma_tap(lk_rsrc_t rsrc, unsigned voff, unsigned lds) {
   asm volatile("s_mov_b32 m0, %2\n\t"
                "s_nop 0\n\t"
-               "buffer_load_dword %1, %0, 0 offen lds"
+               "buffer_load_dword %1, %0, 0 offen" SCF_LOOKUP_TAP_POL " lds"
                : : "s"(rsrc), "v"(voff), "s"(lds) : "memory");
 }
 // contiguous variant with an explicit lane mask (whole small maps)
@@ -123,7 +142,7 @@ __device__ __forceinline__ void lk_dma_mask(const void* sbase, unsigned voff, un
   asm volatile("s_mov_b64 exec, %3\n\t"
                "s_mov_b32 m0, %2\n\t"
                "s_nop 0\n\t"
-               "global_load_lds_dword %1, %0 nt\n\t"
+               "global_load_lds_dword %1, %0" SCF_LOOKUP_MAP_POL "\n\t"
                "s_mov_b64 exec, -1"
                : : "s"(sbase), "v"(voff), "s"(lds), "s"(mask) : "memory");
 }
@@ -287,6 +306,7 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
   };
   int g = blockIdx.x;
   float fx = 0.f, fy = 0.f;
+  LK_LAB_STAGGER;
   if (g < p.ngroups) flow_of(g, fx, fy);       // issued before any setup
 
   for (; g < p.ngroups; g += gridDim.x) {
@@ -326,18 +346,13 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
       const bool small = !tiled && (lh <= FW && lw <= FW);
       if (small && lane < lw) (myfp + QB * (msz | 1))[lane] = 0.f;       // the shared zero row
       const float inv = 1.0f / (float)(1 << lvl);
-      const LkCentre c = lk_centre<R>(xf + fx, yf + fy, inv, flat_x, flat_y);   // first use of the flow
-      const int x0 = c.x0, y0 = c.y0;
       const char* lbase = (const char*)lk_sgpr_ptr(p.lvl[lvl] + (size_t)gq0 * msz);
-      const int i0 = (half * D + 1) / 2;                // first x-offset of this half-wave
-      lds_cfp_t rowp[FW];
       unsigned st0 = (unsigned)(uintptr_t)myfp;
       asm volatile("" : "+s"(st0));                     // row / query LDS addresses: s_add from here
-
-      if (small) {
-        // ---- whole map per query, stride S (odd), + ONE shared zero row behind them ----
+      // A level that is staged whole does not need the flow to be fetched: its DMAs leave before the flow
+      // load is waited for (~0.8 us earlier; the memory system has work while the other waves build tables)
+      if (small && LK_EARLY_MAPS) {
         const int S = msz | 1;
-        const lds_fp_t zrow = myfp + QB * S;
         const unsigned long long m0mask = msz >= 64 ? ~0ull : ((1ull << msz) - 1ull);
         const unsigned long long m1mask = msz > 64 ? ((1ull << (msz - 64)) - 1ull) : 0ull;
         const unsigned vlane4 = (unsigned)lane * 4u;
@@ -347,6 +362,30 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
             const char* mb = lbase + (size_t)qq * msz * 4;
             lk_dma_mask(mb, vlane4, st0 + (unsigned)(qq * S) * 4u, m0mask);
             if (msz > 64) lk_dma_mask(mb + 256, vlane4, st0 + (unsigned)(qq * S + 64) * 4u, m1mask);
+          }
+        }
+        asm volatile("" : "+v"(fx), "+v"(fy));          // the first use of the flow stays behind the DMAs
+      }
+      const LkCentre c = lk_centre<R>(xf + fx, yf + fy, inv, flat_x, flat_y);   // first use of the flow
+      const int x0 = c.x0, y0 = c.y0;
+      const int i0 = (half * D + 1) / 2;                // first x-offset of this half-wave
+      lds_cfp_t rowp[FW];
+
+      if (small) {
+        // ---- whole map per query, stride S (odd), + ONE shared zero row behind them ----
+        const int S = msz | 1;
+        const lds_fp_t zrow = myfp + QB * S;
+        const unsigned long long m0mask = msz >= 64 ? ~0ull : ((1ull << msz) - 1ull);
+        const unsigned long long m1mask = msz > 64 ? ((1ull << (msz - 64)) - 1ull) : 0ull;
+        const unsigned vlane4 = (unsigned)lane * 4u;
+        if (!LK_EARLY_MAPS) {
+          LK_TRACE(2);
+          if (!skip_dma) {
+            for (int qq = 0; qq < nq; ++qq) {
+              const char* mb = lbase + (size_t)qq * msz * 4;
+              lk_dma_mask(mb, vlane4, st0 + (unsigned)(qq * S) * 4u, m0mask);
+              if (msz > 64) lk_dma_mask(mb + 256, vlane4, st0 + (unsigned)(qq * S + 64) * 4u, m1mask);
+            }
           }
         }
         const lds_cfp_t f = myfp + l32 * S;
@@ -435,6 +474,244 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
 }
 
 // ---------------------------------------------------------------------------------
+// v9 (round 5): the same gather / emit code, de-phased.  v8's 1024 blocks all run tables -> gather ->
+// emit in step: the chip reads for the first half of the kernel and writes for the second.  Here a
+// block owns G consecutive groups; its G * L (group, level) units are dealt to the four waves so that
+// every wave carries the same number of DMA instructions (a big level of one group + a small level
+// of another), and a wave runs its units as a software pipeline:
+//   flows of all G groups (plain loads, waited for before the first DMA)
+//   issue  : every unit, cheapest first (a level that is staged whole, then the footprint level)
+//   emit   : in the same order, each behind a COUNTED wait -- s_waitcnt vmcnt(n), n = the DMA
+//            instructions of the units behind it (loads return in order; stores in flight only add
+//            to the counter, so the wait is conservative, never early).  The first unit's stores
+//            leave while the later units' gathers are still in flight: every CU reads and writes
+//            at the same time for most of the kernel.
+// Half as many waves as v8 for the same LDS bytes in flight: the launch ramp halves as well.
+// ---------------------------------------------------------------------------------
+// counted wait on the vector-memory counter.  Every DMA and store of this kernel is inline asm the compiler does
+// not count; the only loads it knows of (the flows) are consumed before the first DMA is issued.
+#define LK_WAITVM(N) asm volatile("s_waitcnt vmcnt(" #N ")" : : : "memory")
+
+template <int R, int SM, int G, int NU>
+__global__ __launch_bounds__(256, 2) void corr_lookup_pipe_kernel(LookupParams p) {
+  constexpr int FW = 2 * R + 2, FS = FW * FW, FSP = FS | 1, D = 2 * R + 1, QB = 32;
+  constexpr int NSET = (FS + 63) / 64, LPS = FS / NSET, TQ = 2 * FW;
+  static_assert(LPS * NSET == FS && LPS <= 64, "the footprint splits into equal lane shares");
+  static_assert(G == 2 || G == 3, "two or three groups per block");
+  extern __shared__ __attribute__((aligned(16))) float lds_fp[];
+
+  const bool skip_dma = LK_SKIP_DMA, skip_store = LK_SKIP_STORE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, half = lane >> 5;
+  const int hw = p.h * p.w;
+  const int ktot = p.L * D * D;
+  const size_t cs = (size_t)hw * 4;
+  const unsigned total_q = (unsigned)p.total_q;
+
+  // geometry of group g as this lane sees it (maps of >= 32 pixels: a group spans at most two samples)
+  struct Geom { unsigned gq0; int n0, nq, x, y; unsigned lane_off; bool qvalid; };
+  auto geom = [&](int g) {
+    Geom m;
+    m.gq0 = (unsigned)g * QB;
+    m.n0 = (int)(m.gq0 / (unsigned)hw);
+    const unsigned gq = m.gq0 + l32;
+    m.qvalid = gq < total_q;
+    unsigned q0 = gq - (unsigned)m.n0 * (unsigned)hw;
+    int n = m.n0;
+    if (hw >= QB) {
+      if (q0 >= (unsigned)hw) { q0 -= (unsigned)hw; ++n; }
+    } else {
+      const unsigned dn = q0 / (unsigned)hw;
+      n += (int)dn;
+      q0 -= dn * (unsigned)hw;
+    }
+    const int q = m.qvalid ? (int)q0 : 0;
+    m.y = (int)((unsigned)q / (unsigned)p.w);
+    m.x = q - m.y * p.w;
+    m.lane_off = ((unsigned)(n - m.n0) * (unsigned)(ktot * hw) + (unsigned)q) * 4u;
+    m.nq = (int)((total_q - m.gq0) < (unsigned)QB ? (total_q - m.gq0) : (unsigned)QB);
+    return m;
+  };
+
+  for (int sg = blockIdx.x; sg < p.nsg; sg += gridDim.x) {
+    // ---- flows of the block's groups: plain loads, consumed (centres of the first footprint unit, or the
+    //      opaque use below) BEFORE the first DMA leaves -- the compiler's own wait for them must not sit
+    //      behind DMAs it does not know of ----
+    float fx[G], fy[G];
+#pragma unroll
+    for (int gs = 0; gs < G; ++gs) {
+      const int g = sg * G + gs;
+      const unsigned gq = (unsigned)g * QB + l32;
+      fx[gs] = 0.f; fy[gs] = 0.f;
+      if (g < p.ngroups && gq < total_q) {
+        const unsigned n_ = gq / (unsigned)hw;
+        const float* fl = p.flow + (size_t)n_ * 2 * hw + (gq - n_ * (unsigned)hw);
+        fx[gs] = fl[0];
+        fy[gs] = fl[hw];
+      }
+    }
+#pragma unroll
+    for (int gs = 0; gs < G; ++gs) asm volatile("" : "+v"(fx[gs]), "+v"(fy[gs]));   // used: the loads are waited for here
+    auto wait_vm = [&](int n) {      // at most n (wave-uniform) vector-memory operations stay in flight
+      if (n >= 63) LK_WAITVM(63);
+      else if (n >= 32) LK_WAITVM(32);
+      else LK_WAITVM(0);
+    };
+    auto flow_of = [&](int gs, float& ax, float& ay) {
+      ax = fx[0]; ay = fy[0];
+#pragma unroll
+      for (int k = 1; k < G; ++k)
+        if (gs == k) { ax = fx[k]; ay = fy[k]; }
+    };
+
+    int cnt[NU];
+    int issued = 0;
+    // ================= issue: every unit of this wave, cheapest first =================
+#pragma unroll
+    for (int s = 0; s < NU; ++s) {
+      cnt[s] = 0;
+      const int uc = p.unit[wave][s];
+      const int gs = uc >> 4, lvl = uc & 15;
+      const int g = sg * G + gs;
+      if (uc == 0xff || g >= p.ngroups) continue;
+      LK_TRACE_U(g, lvl, 0);
+      const Geom m = geom(g);
+      const int lh = p.lh[lvl], lw = p.lw[lvl], msz = p.msz[lvl], pw4 = p.pw4[lvl];
+      const bool tiled = pw4 != 0;
+      const bool flat_x = lw == 1, flat_y = lh == 1;
+      const bool small = !tiled && (lh <= FW && lw <= FW);
+      const lds_fp_t myfp = (lds_fp_t)lds_fp + p.uoff[wave][s];
+      const char* lbase = (const char*)lk_sgpr_ptr(p.lvl[lvl] + (size_t)m.gq0 * msz);
+      unsigned st0 = (unsigned)(uintptr_t)myfp;
+      asm volatile("" : "+s"(st0));
+      if (small) {
+        const int S = msz | 1;
+        if (lane < lw) (myfp + QB * S)[lane] = 0.f;       // the shared zero row
+        const unsigned long long m0mask = msz >= 64 ? ~0ull : ((1ull << msz) - 1ull);
+        const unsigned long long m1mask = msz > 64 ? ((1ull << (msz - 64)) - 1ull) : 0ull;
+        const unsigned vlane4 = (unsigned)lane * 4u;
+        LK_TRACE_U(g, lvl, 2);
+        if (!skip_dma) {
+          for (int qq = 0; qq < m.nq; ++qq) {
+            const char* mb = lbase + (size_t)qq * msz * 4;
+            lk_dma_mask(mb, vlane4, st0 + (unsigned)(qq * S) * 4u, m0mask);
+            if (msz > 64) lk_dma_mask(mb + 256, vlane4, st0 + (unsigned)(qq * S + 64) * 4u, m1mask);
+          }
+          cnt[s] = m.nq * (msz > 64 ? 2 : 1);
+        }
+      } else {
+        float qx, qy;
+        flow_of(gs, qx, qy);
+        const float inv = 1.0f / (float)(1 << lvl);
+        const LkCentre c = lk_centre<R>((float)m.x + qx, (float)m.y + qy, inv, flat_x, flat_y);
+        const lds_u16p_t tbl = (lds_u16p_t)(myfp + QB * FSP);
+        {
+          const int c0 = half ? c.x0 : c.y0, lim = half ? lw : lh;
+          const bool flat = half ? flat_x : flat_y;
+          const int sh = half ? 3 : 2, msk = half ? 7 : 3;
+          const int mula = tiled ? (half ? 32 : pw4) : 0, mulb = tiled ? (half ? 1 : 8) : (half ? 1 : lw);
+          const lds_u16p_t tq = tbl + l32 * TQ + half * FW;
+#pragma unroll
+          for (int j = 0; j < FW; j += 2) {
+            unsigned pr = 0;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+              const int v = flat ? 0 : c0 + j + jj;
+              const bool ok = m.qvalid && (unsigned)v < (unsigned)lim;
+              const int val = tiled ? __mul24(v >> sh, mula) + __mul24(v & msk, mulb) : __mul24(v, mulb);
+              pr |= (ok ? (unsigned)val : LK_OOB) << (16 * jj);
+            }
+            *(__attribute__((address_space(3))) unsigned*)(tq + j) = pr;
+          }
+        }
+        const unsigned mbytes = (unsigned)msz * 4u;
+        __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): the tables are in LDS
+        __builtin_amdgcn_wave_barrier();
+        LK_TRACE_U(g, lvl, 2);
+        if (!skip_dma && (LPS == 64 || lane < LPS)) {
+          lds_cu16p_t trow[NSET];
+          lds_cu16p_t tcol[NSET];
+#pragma unroll
+          for (int e_ = 0; e_ < NSET; ++e_) {
+            const int e = lane + LPS * e_;
+            trow[e_] = tbl + e / FW;
+            tcol[e_] = tbl + FW + (e - (e / FW) * FW);
+          }
+          constexpr int QBATCH = 4;
+#pragma unroll
+          for (int qb = 0; qb < QB; qb += QBATCH) {
+            unsigned tr_[QBATCH][NSET], tc_[QBATCH][NSET];
+#pragma unroll
+            for (int qi = 0; qi < QBATCH; ++qi)
+#pragma unroll
+              for (int e_ = 0; e_ < NSET; ++e_) {
+                tr_[qi][e_] = trow[e_][(qb + qi) * TQ];
+                tc_[qi][e_] = tcol[e_][(qb + qi) * TQ];
+              }
+#pragma unroll
+            for (int qi = 0; qi < QBATCH; ++qi) {
+              const int qq = qb + qi;
+              const lk_rsrc_t rsrc = lk_make_rsrc(lbase + (size_t)qq * mbytes, mbytes);
+#pragma unroll
+              for (int e_ = 0; e_ < NSET; ++e_)
+                lk_dma_tap(rsrc, (tr_[qi][e_] + tc_[qi][e_]) << 2, st0 + (unsigned)(qq * FSP + LPS * e_) * 4u);
+            }
+          }
+        }
+        if (!skip_dma) cnt[s] = QB * NSET;
+      }
+      issued += cnt[s];
+      LK_TRACE_U(g, lvl, 3);
+    }
+
+    // ================= emit: same order, each behind a counted wait =================
+#pragma unroll
+    for (int s = 0; s < NU; ++s) {
+      const int uc = p.unit[wave][s];
+      const int gs = uc >> 4, lvl = uc & 15;
+      const int g = sg * G + gs;
+      if (uc == 0xff || g >= p.ngroups) continue;
+      issued -= cnt[s];                                   // what is left behind this unit
+      wait_vm(issued);
+      __builtin_amdgcn_wave_barrier();
+      LK_TRACE_U(g, lvl, 4);
+      const Geom m = geom(g);
+      const int lh = p.lh[lvl], lw = p.lw[lvl], msz = p.msz[lvl], pw4 = p.pw4[lvl];
+      const bool tiled = pw4 != 0;
+      const bool flat_x = lw == 1, flat_y = lh == 1;
+      const bool small = !tiled && (lh <= FW && lw <= FW);
+      const lds_fp_t myfp = (lds_fp_t)lds_fp + p.uoff[wave][s];
+      float qx, qy;
+      flow_of(gs, qx, qy);
+      const float inv = 1.0f / (float)(1 << lvl);
+      const LkCentre c = lk_centre<R>((float)m.x + qx, (float)m.y + qy, inv, flat_x, flat_y);
+      const int i0 = (half * D + 1) / 2;
+      char* obase = (char*)p.out + ((size_t)m.n0 * ktot + (size_t)lvl * D * D) * cs;
+      lds_cfp_t rowp[FW];
+      if (small) {
+        const int S = msz | 1;
+        const lds_fp_t zrow = myfp + QB * S;
+        const lds_cfp_t f = myfp + l32 * S;
+#pragma unroll
+        for (int r = 0; r < FW; ++r) {
+          const int yy = flat_y ? 0 : c.y0 + r;
+          rowp[r] = (unsigned)yy < (unsigned)lh ? f + yy * lw : (lds_cfp_t)zrow;
+        }
+        lookup_emit<R, true, SM>(rowp, lw, c.x0 + i0, flat_x, c.nw, c.ne, c.sw, c.se, half, obase, m.lane_off, cs, m.qvalid && !skip_store);
+      } else {
+        const lds_cfp_t f = myfp + l32 * FSP + i0;
+#pragma unroll
+        for (int r = 0; r < FW; ++r) rowp[r] = f + r * FW;
+        lookup_emit<R, false, SM>(rowp, lw, 0, flat_x, c.nw, c.ne, c.sw, c.se, half, obase, m.lane_off, cs, m.qvalid && !skip_store);
+      }
+      __builtin_amdgcn_wave_barrier();
+      LK_TRACE_END_U(g, lvl);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // Generic lookup: any radius, level count, map size and layout -- one thread per output element,
 // four cached loads per tap.  It exists so that the operator seam (CorrLookup(radius, ...) on any
 // pyramid, corr_lookup.py:91-102) never answers "unsupported"; every configuration the reference
@@ -498,6 +775,21 @@ extern "C" unsigned scf_corr_preferred_layout(int h, int w, int r, int L) {
   return mask;
 }
 
+// scf_tune(SCF_TUNE_LOOKUP_PIPE, v): 0 = the dispatch's own choice (pipelined kernel with two groups per
+// block where two such blocks fit a CU), 1 = v8 (one group per block), 2 / 3 = pipelined with that many groups
+static std::atomic<int> g_lookup_pipe{0};
+int scf_lookup_pipe_set(int v) {
+  if (v < 0 || v > 3) return SCF_EINVAL;
+  return g_lookup_pipe.exchange(v);
+}
+
+// scf_tune(SCF_TUNE_LOOKUP_STORE, v): 0 = the build's policy, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt, 5 plain (r = 4, one group per block)
+static std::atomic<int> g_lookup_store{0};
+int scf_lookup_store_set(int v) {
+  if (v < 0 || v > 5) return SCF_EINVAL;
+  return g_lookup_store.exchange(v);
+}
+
 static int lookup_launch(const float* const* levels, const float* flow, float* out, int N, int h, int w,
                          int r, int L, unsigned tiled_levels, scf_stream_t stream) {
   if (!levels || !flow || !out || N <= 0 || h <= 0 || w <= 0 || L <= 0 || r < 1) return SCF_EINVAL;
@@ -557,11 +849,87 @@ static int lookup_launch(const float* const* levels, const float* flow, float* o
   per_cu = per_cu > 4 ? 4 : per_cu < 1 ? 1 : per_cu;    // launch bounds: 4 blocks (16 waves) per CU
   long long nblk = (long long)scf_cu_count() * per_cu;
   if (nblk > ngroups) nblk = ngroups;
+
+  // ---- pipelined kernel: G groups per block, their G * L units dealt to the four waves by cost ----
+  // (r = 4 and three or four levels -- every configuration the reference ships; anything else keeps v8)
+  const int pipe_mode = LK_LAB_PIPE_MODE(g_lookup_pipe.load(std::memory_order_relaxed));
+  int G = pipe_mode == 0 ? 2 : pipe_mode >= 2 ? pipe_mode : 0;
+  if (G && r == 4 && (L == 3 || L == 4) && ngroups >= 2 * G) {
+    struct Unit { int gs, lvl, cost, fl; };
+    Unit u[3 * 4];
+    int nu = 0;
+    for (int l = 0; l < L; ++l)                            // levels are in descending cost order already
+      for (int gs = 0; gs < G; ++gs) {
+        const bool small = !p.pw4[l] && p.lh[l] <= FW && p.lw[l] <= FW;
+        u[nu++] = {gs, l, small ? qb * (p.msz[l] > 64 ? 2 : 1) : qb * ((FW * FW + 63) / 64),
+                   small ? qb * (p.msz[l] | 1) + p.lw[l] : qb * FSP + qb * FW};
+      }
+    for (int i = 1; i < nu; ++i)                            // stable insertion sort, most expensive first
+      for (int j = i; j > 0 && u[j].cost > u[j - 1].cost; --j) { const Unit t = u[j]; u[j] = u[j - 1]; u[j - 1] = t; }
+    int perwave[4] = {0, 0, 0, 0};
+    Unit mine[4][LK_MAXU];
+    bool fits = true;
+    for (int i = 0; i < nu && fits; ++i) {                  // snake: 0 1 2 3 3 2 1 0 0 1 ...
+      const int c = i & 3, wv = ((i >> 2) & 1) ? 3 - c : c;
+      if (perwave[wv] >= LK_MAXU) { fits = false; break; }
+      mine[wv][perwave[wv]++] = u[i];
+    }
+    int poff = 0, numax = 0;
+    if (fits) {
+      for (int wv = 0; wv < 4; ++wv) {
+        numax = numax > perwave[wv] ? numax : perwave[wv];
+        for (int k = 0; k < 4; ++k) p.unit[wv][k] = 0xff;
+        for (int k = 0; k < perwave[wv]; ++k) {             // run order: cheapest first
+          const Unit& t = mine[wv][perwave[wv] - 1 - k];
+          p.unit[wv][k] = (unsigned char)((t.gs << 4) | t.lvl);
+          p.uoff[wv][k] = poff;
+          poff += (t.fl + 3) & ~3;
+        }
+      }
+    }
+    const size_t plds = (size_t)poff * sizeof(float);
+    const int nu_k = G == 2 ? 2 : 3;                        // instantiated (G, NU) pairs: (2, 2), (3, 3)
+    int pper = fits ? (int)((160 * 1024) / (plds + 512)) : 0;
+    pper = pper > 2 ? 2 : pper;
+    // worth it only with at least two blocks (8 waves) per CU issuing gathers
+    if (fits && numax <= nu_k && pper >= (pipe_mode == 0 ? 2 : 1)) {
+      p.gpb = G;
+      p.nsg = (int)scf_cdiv(ngroups, G);
+      long long pblk = (long long)scf_cu_count() * pper;
+      if (pblk > p.nsg) pblk = p.nsg;
+      int rc = SCF_OK;
+      if (G == 2) {
+        static std::atomic<unsigned long long> done{0};
+        if (plds > 64 * 1024) rc = scf_raise_dynamic_lds(done, (const void*)corr_lookup_pipe_kernel<4, SCF_LOOKUP_STORE_MODE, 2, 2>, (int)plds);
+        if (rc != SCF_OK) return rc;
+        LK_LAB_SETUP(p, pblk);
+        scf_launch((corr_lookup_pipe_kernel<4, SCF_LOOKUP_STORE_MODE, 2, 2>), dim3((unsigned)pblk), dim3(256), plds, scf_stream(stream), p);
+      } else {
+        static std::atomic<unsigned long long> done{0};
+        if (plds > 64 * 1024) rc = scf_raise_dynamic_lds(done, (const void*)corr_lookup_pipe_kernel<4, SCF_LOOKUP_STORE_MODE, 3, 3>, (int)plds);
+        if (rc != SCF_OK) return rc;
+        LK_LAB_SETUP(p, pblk);
+        scf_launch((corr_lookup_pipe_kernel<4, SCF_LOOKUP_STORE_MODE, 3, 3>), dim3((unsigned)pblk), dim3(256), plds, scf_stream(stream), p);
+      }
+      return scf_launch_status();
+    }
+  }
+  p.gpb = 1; p.nsg = p.ngroups;
   LK_LAB_LAUNCH(p, nblk);
 #define SCF_LK(R_)                                                                                 \
   case R_:                                                                                         \
     scf_launch((corr_lookup_kernel<R_, SCF_LOOKUP_STORE_MODE>), dim3((unsigned)nblk), dim3(256), lds, scf_stream(stream), p); \
     break;
+#define SCF_LK4(SM_)                                                                               \
+  case SM_:                                                                                        \
+    scf_launch((corr_lookup_kernel<4, SM_ == 5 ? 0 : SM_>), dim3((unsigned)nblk), dim3(256), lds, scf_stream(stream), p); \
+    return scf_launch_status();
+  if (r == 4)
+    switch (g_lookup_store.load(std::memory_order_relaxed)) {   // A/B knob: store policy of the r = 4 kernel
+      SCF_LK4(1) SCF_LK4(2) SCF_LK4(3) SCF_LK4(4) SCF_LK4(5)
+      default: break;
+    }
+#undef SCF_LK4
   switch (r) {
     SCF_LK(4) SCF_LK(3) SCF_LK(2) SCF_LK(1)
     default: return SCF_EUNSUPPORTED;

@@ -668,14 +668,22 @@ def conv_timing(enable: bool):
     return list(zip(_read_timers([e[0] for e in evs]), [e[1] for e in evs], [e[2] for e in evs]))
 
 
-TUNE_KEYS = {'wino_variant': 1, 'dma_force_ksplit': 2, 'dma_ksplit_groups': 3, 'wino1d4': 4}
+TUNE_KEYS = {'wino_variant': 1, 'dma_force_ksplit': 2, 'dma_ksplit_groups': 3, 'wino1d4': 4, 'lookup_pipe': 5, 'lookup_store': 6}
 
 
 def tune(key: str, value: int) -> int:
     """measurement knob of the library (``scf_tune``, scflow_hip_prof.h): returns the previous value.
     ``'wino_variant'``: 0 = the dispatch's choice, 1 = pair kernel, 2 / 3 = quarter-domain kernel (4 / 8 waves);
-    ``'wino1d4'``: 1 = F(4, 5) where the dispatch prefers it (default), 0 = never, 2 = on every grid it supports."""
-    return int(_lib.load().scf_tune(TUNE_KEYS[key], int(value)))
+    ``'wino1d4'``: 1 = F(4, 5) where the dispatch prefers it (default), 0 = never, 2 = on every grid it supports;
+    ``'lookup_pipe'``: 0 = the dispatch's choice, 1 = one group per block (r3 kernel), 2 / 3 = pipelined kernel with
+    that many groups per block.  Unknown keys raise ``ValueError``; a value the library refuses raises
+    ``RuntimeError`` (the return value is always a previous setting, never an error code)."""
+    if key not in TUNE_KEYS:
+        raise ValueError(f'unknown tune key {key!r}; known: {sorted(TUNE_KEYS)}')
+    prev = int(_lib.load().scf_tune(TUNE_KEYS[key], int(value)))
+    if prev < 0:
+        _lib.check(prev, f'scf_tune({key}, {value})')
+    return prev
 
 
 class record_conv_kernels:

@@ -39,6 +39,24 @@ __global__ void flush_kernel(float4* p, size_t n) {
   for (; i < n; i += st) { float4 v = p[i]; acc += v.x + v.y + v.z + v.w; }
   if (acc == 123.456f) p[0].x = acc;      // never true: the flush only READS (no dirty lines left behind)
 }
+// flush that leaves the Infinity Cache full of DIRTY lines (what the convolutions of a step leave behind)
+__global__ void dirty_kernel(float4* p, size_t n, float v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t st = (size_t)gridDim.x * blockDim.x;
+  const float4 w = {v, v, v, v};
+  for (; i < n; i += st) p[i] = w;
+}
+// matrix-pipe burn: pulls the shader clock down to what it is inside the step (power management)
+__global__ __launch_bounds__(256) void burn_kernel(float* out, int iters) {
+  typedef float v16 __attribute__((ext_vector_type(16)));
+  v16 acc = {0};
+  float a = (float)threadIdx.x * 1e-3f, b = 1.0f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  if (acc[0] == 123.f) out[0] = acc[1];
+}
 // streaming ceiling: each block reads rd_bytes and writes wr_bytes (float4, coalesced)
 __global__ __launch_bounds__(256) void stream_kernel(const float4* src, float4* dst, int rd4, int wr4) {
   const float4* s = src + (size_t)blockIdx.x * rd4;
@@ -72,6 +90,7 @@ struct Timer { hipEvent_t a, b; };
 static double median(std::vector<float> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
 
 int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IOLBF, 0);              // a device fault must not swallow the lines before it
   const int B = argc > 1 ? atoi(argv[1]) : 32;      // pairs per launch
   const int reps = argc > 2 ? atoi(argv[2]) : 20;
   const int h = argc > 3 ? atoi(argv[3]) : 32, w = argc > 4 ? atoi(argv[4]) : 32;
@@ -108,12 +127,17 @@ int main(int argc, char** argv) {
   CK(hipStreamCreate(&st));
   const unsigned tiled = getenv("LAB_ROWMAJOR") ? 0u : scf_corr_preferred_layout(h, w, r, L);      // tile mask
 
-  auto run = [&](const char* name, int skip_dma, int skip_store, bool with_trace, bool flush, int rotate = -1, int grid = 0) {
-    scf_lab_skip_dma = skip_dma; scf_lab_skip_store = skip_store; scf_lab_rotate = rotate; scf_lab_grid = grid;
+  auto run = [&](const char* name, int skip_dma, int skip_store, bool with_trace, bool flush, int rotate = -1, int grid = 0, int pipe = 1) {
+    scf_lab_skip_dma = skip_dma; scf_lab_skip_store = skip_store; scf_lab_rotate = rotate; scf_lab_grid = grid; scf_lab_pipe = pipe;
+    printf("[run] %s\n", name);
     std::vector<float> us;
     std::vector<unsigned long long> tr((size_t)nblk * 32);
     for (int it = 0; it < reps + 3; ++it) {
-      if (flush) flush_kernel<<<4096, 256, 0, st>>>(flushbuf, fl4);
+      if (flush) {
+        if (getenv("LAB_DIRTY")) dirty_kernel<<<4096, 256, 0, st>>>(flushbuf, fl4 / 2, (float)it);   // 512 MiB written
+        else flush_kernel<<<4096, 256, 0, st>>>(flushbuf, fl4);
+      }
+      if (getenv("LAB_BURN")) burn_kernel<<<1024, 256, 0, st>>>((float*)flushbuf, atoi(getenv("LAB_BURN")));
       scf_lab_trace = with_trace ? trace : nullptr;
       if (with_trace) CK(hipMemsetAsync(trace, 0, (size_t)nblk * 32 * 8, st));
       scf_timer_t tm;
@@ -148,9 +172,37 @@ int main(int argc, char** argv) {
             }
           if (v.empty()) { printf(" %s -", nm[s]); continue; }
           std::sort(v.begin(), v.end());
-          printf(" %s %.1f/%.1f/%.1f", nm[s], v[v.size() / 20], v[v.size() / 2], v[v.size() - 1 - v.size() / 20]);
+          printf(" %s %.1f/%.1f/%.1f/%.1f", nm[s], v[v.size() / 20], v[v.size() / 2], v[v.size() - 1 - v.size() / 20], v.back());
         }
-        printf("   (p5/p50/p95 us)\n");
+        printf("   (p5/p50/p95/max us)\n");
+      }
+      // timeline: per 0.5 us bin, the units with gathers in flight (pre-dma .. landed) and the units emitting
+      // (landed .. emitted); "both" = bins in which at least 10 % of the units are in each phase
+      {
+        const int NB = 64;
+        int gat[NB] = {0}, emi[NB] = {0};
+        float tend = 0;
+        const size_t units = (size_t)nblk * 4;
+        for (size_t i = 0; i < units; ++i) {
+          const unsigned long long* e = &tr[i * 8];
+          if (!e[2] || !e[4] || !e[5]) continue;
+          const float a = (float)(e[2] - t0) * 0.01f, b = (float)(e[4] - t0) * 0.01f, c = (float)(e[5] - t0) * 0.01f;
+          tend = std::max(tend, e[6] ? (float)(e[6] - t0) * 0.01f : c);
+          for (int k = 0; k < NB; ++k) {
+            const float lo = 0.5f * k, hi = lo + 0.5f;
+            if (a < hi && b > lo) gat[k]++;
+            if (b < hi && c > lo) emi[k]++;
+          }
+        }
+        int both = 0, nbins = (int)(tend / 0.5f) + 1;
+        printf("  timeline (0.5 us bins, %% of units gathering | emitting):\n   ");
+        for (int k = 0; k < nbins && k < NB; ++k) {
+          const int pg = (int)(100.0 * gat[k] / units), pe = (int)(100.0 * emi[k] / units);
+          if (pg >= 10 && pe >= 10) ++both;
+          printf(" %d|%d", pg, pe);
+        }
+        printf("\n  last stamp %.1f us; bins with >= 10 %% of the units in BOTH phases: %d of %d (%.0f %% of the wave-active time, %.0f %% of the kernel's %.2f us)\n",
+               tend, both, nbins, 100.0 * both / nbins, 100.0 * both * 0.5 / m, m);
       }
       // hardware placement: HW_ID of (group, wave): SIMD = bits 5:4, TG_ID = bits 19:16, CU = 11:8
       int simd_of_wave[4][4] = {{0}}, tg_hist[16] = {0}, lvl_on_simd[4][4] = {{0}};
@@ -176,6 +228,48 @@ int main(int argc, char** argv) {
 
   printf("lookup lab: B=%d h=%d w=%d queries=%zu blocks=%d tiled=%d pyramid=%.0f MiB per half\n", B, h, w, Q, nblk,
          (int)tiled, Q * (double)(hw + hw / 4 + hw / 16 + hw / 64) * 4 / 1048576.0);
+  if (getenv("LAB_ABL")) {          // ablations of the pipelined kernel only (fault hunt)
+    scf_lab_store_mode = 0;
+    const int which = atoi(getenv("LAB_ABL"));
+    const bool tr = getenv("LAB_TRACE") != nullptr;
+    if (which & 1) run("v9 G=2: no stores (cold)", 0, 1, tr, true, -1, 0, 2);
+    if (which & 2) run("v9 G=2: no gathers (cold)", 1, 0, tr, true, -1, 0, 2);
+    if (which & 4) run("v9 G=2: neither (cold)", 1, 1, tr, true, -1, 0, 2);
+    if (which & 8) run("v9 G=2: no gathers (warm)", 1, 0, tr, false, -1, 0, 2);
+    printf("done\n");
+    return 0;
+  }
+  if (getenv("LAB_POL")) {          // store-policy sweep of v8 (the tap policy is this binary's -DSCF_LOOKUP_TAP_POL)
+    const char* nm[6] = {"", "nt", "sc1", "sc0 sc1", "sc1 nt", "plain"};
+    for (int rep = 0; rep < 2; ++rep)
+      for (int m = 1; m < 6; ++m) {
+        scf_lab_store_mode = m;
+        char buf[64];
+        snprintf(buf, sizeof buf, "v8 stores %s cold", nm[m]);
+        run(buf, 0, 0, false, true, -1, 0, 1);
+      }
+    return 0;
+  }
+  if (getenv("LAB_QUICK")) {        // the A/B set of round 5 (cold = what the pipeline sees)
+    const bool tr = getenv("LAB_TRACE") != nullptr;
+    scf_lab_store_mode = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+      scf_lab_early = 0; scf_lab_stagger = 0;
+      run("v8 late maps warm", 0, 0, false, false, -1, 0, 1);
+      run("v8 late maps cold", 0, 0, tr && rep, true, -1, 0, 1);
+      scf_lab_early = 1;
+      run("v8 early maps warm", 0, 0, false, false, -1, 0, 1);
+      run("v8 early maps cold", 0, 0, tr && rep, true, -1, 0, 1);
+      scf_lab_stagger = 4;
+      run("v8 early maps, odd slots +2 us, cold", 0, 0, tr && rep, true, -1, 0, 1);
+      scf_lab_stagger = 8;
+      run("v8 early maps, odd slots +4 us, cold", 0, 0, tr && rep, true, -1, 0, 1);
+      scf_lab_stagger = 0;
+      run("v9 pipe G=2 warm", 0, 0, false, false, -1, 0, 2);
+      run("v9 pipe G=2 cold", 0, 0, tr && rep, true, -1, 0, 2);
+    }
+    return 0;
+  }
 #ifdef LAB_V5
   run("v5 warm", 0, 0, false, false);
   run("v5 cold", 0, 0, false, true);
@@ -197,13 +291,24 @@ int main(int argc, char** argv) {
     run("sc1: no stores (cold)", 0, 1, true, true);
     run("sc1: no gathers (cold)", 1, 0, true, true);
     run("sc1: neither (cold)", 1, 1, true, true);
+    for (int rep = 0; rep < 2; ++rep) {
+      run("v8 (1 group/block) warm", 0, 0, false, false, -1, 0, 1);
+      run("v8 (1 group/block) cold", 0, 0, rep == 1, true, -1, 0, 1);
+      run("v9 pipe G=2 warm", 0, 0, false, false, -1, 0, 2);
+      run("v9 pipe G=2 cold", 0, 0, rep == 1, true, -1, 0, 2);
+      run("v9 pipe G=3 warm", 0, 0, false, false, -1, 0, 3);
+      run("v9 pipe G=3 cold", 0, 0, rep == 1, true, -1, 0, 3);
+    }
+    run("v9 G=2: no stores (cold)", 0, 1, true, true, -1, 0, 2);
+    run("v9 G=2: no gathers (cold)", 1, 0, true, true, -1, 0, 2);
+    run("v9 G=2: neither (cold)", 1, 1, true, true, -1, 0, 2);
     if (nblk > 768) run("sc1 cold, grid 768", 0, 0, false, true, -1, 768);
     if (nblk > 512) run("sc1 cold, grid 512", 0, 0, false, true, -1, 512);
     scf_lab_store_mode = 0;
   }
 #endif
-  {   // checksum of the output of a full run (compare across kernel versions: same inputs)
-    scf_lab_skip_dma = scf_lab_skip_store = 0; scf_lab_rotate = -1; scf_lab_grid = 0; scf_lab_trace = nullptr;
+  for (int pipe = 1; pipe <= 3; ++pipe) {   // checksum of the output of a full run (compare across kernel versions: same inputs)
+    scf_lab_skip_dma = scf_lab_skip_store = 0; scf_lab_rotate = -1; scf_lab_grid = 0; scf_lab_trace = nullptr; scf_lab_pipe = pipe;
     CK(hipMemset(out, 0xff, Q * 324 * 4));
     const float* lvp[4] = {lv[0][0], lv[0][1], lv[0][2], lv[0][3]};
     scf_corr_lookup_ex(lvp, flow, out, B, h, w, r, L, tiled, st);
@@ -218,7 +323,7 @@ int main(int argc, char** argv) {
       unsigned u; memcpy(&u, &v, 4); if (u == 0x80000000u) u = 0;      // -0 == +0
       hsh = (hsh ^ u) * 1099511628211ull;
     }
-    printf("checksum: sum %.9e  wsum2 %.9e  nan %zu  fnv %016llx\n", s1, s2, nan, hsh);
+    printf("checksum (pipe mode %d): sum %.9e  wsum2 %.9e  nan %zu  fnv %016llx\n", pipe, s1, s2, nan, hsh);
   }
 
   // streaming ceilings with the same per-launch bytes and the same grid
