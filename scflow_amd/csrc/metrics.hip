@@ -35,7 +35,9 @@ void cal_epe_partial_kernel(EpeK k, unsigned long long* ws) {
   // the divisions are the correctly rounded ones (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt; the
   // __fsqrt_rn / __fdiv_rn intrinsics are the 1-ulp NATIVE instructions in this toolchain and must not be used)
 #pragma clang fp contract(off)
-  const int n = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
+  // one flat grid (sample-major): any N with N * blocks_per_sample < 2^31
+  const int n = (int)(blockIdx.x / (unsigned)k.blocks_per_sample), b = (int)(blockIdx.x - (unsigned)n * (unsigned)k.blocks_per_sample);
+  const int tid = threadIdx.x;
   const float* tx = k.tgt + (long long)n * 2 * k.HW;
   const float* ty = tx + k.HW;
   const float* px = k.pred + (long long)n * 2 * k.HW;
@@ -104,8 +106,8 @@ void cal_epe_partial_kernel(EpeK k, unsigned long long* ws) {
   }
 }
 
-// thread n combines the block partials of sample n in block order ('mean'); thread 0 then walks all partials in
-// (sample, block) order for 'total_mean' (an evaluation batch: tens to thousands of samples x <= a few hundred blocks)
+// thread n combines the block partials of sample n in block order ('mean'); 'total_mean' is a strided fixed-order
+// sum per thread + a fixed LDS tree over the block's 256 threads
 __global__ void cal_epe_final_kernel(const unsigned long long* ws, int N, int bps, int nthr, int fix_quirk,
                                      float* mean, float* ratios, float* total_mean, float* total_ratios) {
 #pragma clang fp contract(off)
@@ -127,19 +129,37 @@ __global__ void cal_epe_final_kernel(const unsigned long long* ws, int N, int bp
               ((float)(long long)(fix_quirk ? c[1 + t] : c[1 + EPE_MAX_THR + t]) / total);
     }
   }
-  if ((total_mean || total_ratios) && threadIdx.x == 0) {
+  if (total_mean || total_ratios) {
+    // 'total_mean': thread t adds the partials t, t + T, t + 2T, ... in that order (fp64 sums, exact integer
+    // counts), then the T thread totals are folded by a fixed binary tree through LDS: the order depends on the
+    // launch shape only, never on timing
+    __shared__ double t_sum[256];
+    __shared__ unsigned long long t_cnt[256][1 + EPE_MAX_THR];
+    const int T = (int)blockDim.x, t = (int)threadIdx.x;
     double s = 0.0;
     unsigned long long c[1 + EPE_MAX_THR];
     for (int j = 0; j < 1 + EPE_MAX_THR; ++j) c[j] = 0;
-    for (long long i = 0; i < (long long)N * bps; ++i) {
+    for (long long i = t; i < (long long)N * bps; i += T) {
       const unsigned long long* o = ws + i * EPE_WS_WORDS;
       s += __longlong_as_double((long long)o[0]);
       for (int j = 0; j < 1 + EPE_MAX_THR; ++j) c[j] += o[1 + j];
     }
-    const float total = ((float)(long long)c[0] + 1e-10f);
-    if (total_mean) total_mean[0] = ((float)s / total);
-    if (total_ratios)
-      for (int t = 0; t < nthr; ++t) total_ratios[t] = ((float)(long long)c[1 + t] / total);
+    t_sum[t] = s;
+    for (int j = 0; j < 1 + EPE_MAX_THR; ++j) t_cnt[t][j] = c[j];
+    __syncthreads();
+    for (int o = T >> 1; o > 0; o >>= 1) {
+      if (t < o) {
+        t_sum[t] += t_sum[t + o];
+        for (int j = 0; j < 1 + EPE_MAX_THR; ++j) t_cnt[t][j] += t_cnt[t + o][j];
+      }
+      __syncthreads();
+    }
+    if (t == 0) {
+      const float total = ((float)(long long)t_cnt[0][0] + 1e-10f);
+      if (total_mean) total_mean[0] = ((float)t_sum[0] / total);
+      if (total_ratios)
+        for (int q = 0; q < nthr; ++q) total_ratios[q] = ((float)(long long)t_cnt[0][1 + q] / total);
+    }
   }
 }
 
@@ -157,7 +177,7 @@ extern "C" int scf_cal_epe(const float* flow_tgt, const float* flow_pred, const 
   if (!flow_tgt || !flow_pred || !workspace || N <= 0 || H <= 0 || W <= 0 || nthr < 0 || nthr > EPE_MAX_THR ||
       (nthr && !threshs))
     return SCF_EINVAL;
-  if ((int64_t)H * W > 0x7fffffffLL || N > 65535) return SCF_EUNSUPPORTED;
+  if ((int64_t)H * W > 0x7fffffffLL || (int64_t)N * epe_blocks(H * W) > 0x7fffffffLL) return SCF_EUNSUPPORTED;
   const bool reduce = mean || ratios || total_mean || total_ratios;
   if (!reduce && !err_map) return SCF_EINVAL;
   EpeK k;
@@ -166,7 +186,7 @@ extern "C" int scf_cal_epe(const float* flow_tgt, const float* flow_pred, const 
   for (int t = 0; t < EPE_MAX_THR; ++t) k.thr[t] = t < nthr ? threshs[t] : 0.f;
   hipStream_t st = scf_stream(stream);
   unsigned long long* ws = static_cast<unsigned long long*>(workspace);
-  scf_launch(cal_epe_partial_kernel, dim3((unsigned)k.blocks_per_sample, (unsigned)N), dim3(EPE_THREADS), 0, st, k, ws);
+  scf_launch(cal_epe_partial_kernel, dim3((unsigned)((int64_t)k.blocks_per_sample * N)), dim3(EPE_THREADS), 0, st, k, ws);
   if (scf_launch_status() != SCF_OK) return SCF_ELAUNCH;
   if (!reduce) return SCF_OK;
   scf_launch(cal_epe_final_kernel, dim3(1), dim3(256), 0, st, (const unsigned long long*)ws, N, k.blocks_per_sample,

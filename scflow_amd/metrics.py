@@ -48,9 +48,13 @@ def cal_epe(flow_tgt: torch.Tensor, flow_pred: torch.Tensor, mask, max_flow: flo
     from . import _lib, ops
     if reduction not in ('none', 'mean', 'total_mean'):
         raise ValueError(reduction)
-    pt, pp = ops._dense(flow_tgt, 'flow_tgt'), ops._dense(flow_pred, 'flow_pred')
     if flow_tgt.dim() != 4 or flow_tgt.shape[1] != 2 or flow_tgt.shape != flow_pred.shape:
         raise _lib.ScflowHipError('cal_epe: flow_tgt / flow_pred must be equal-shape (N,2,H,W)')
+    # any float dtype / memory layout, like the reference's torch expressions (the arithmetic is fp32, as it is
+    # there for fp32 inputs); the device must be the GPU: there is no CPU path in this package
+    flow_tgt = flow_tgt.to(torch.float32).contiguous()
+    flow_pred = flow_pred.to(torch.float32).contiguous()
+    pt, pp = ops._dense(flow_tgt, 'flow_tgt'), ops._dense(flow_pred, 'flow_pred')
     n, _, h, w = flow_tgt.shape
     pm = None
     if mask is not None:
@@ -60,31 +64,33 @@ def cal_epe(flow_tgt: torch.Tensor, flow_pred: torch.Tensor, mask, max_flow: flo
         pm = ops._dense(mask, 'mask')
     lib = _lib.load()
     dev = flow_tgt.device
-    thr = (C.c_float * max(len(threshs), 1))(*[float(t) for t in threshs])
+    threshs = tuple(threshs)
     ws = torch.empty((int(lib.scf_cal_epe_workspace_bytes(n, h, w)),), dtype=torch.uint8, device=dev)
     E = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-    err_map = mean = ratios = tmean = tratios = None
+    P = lambda t: None if t is None else t.data_ptr()
     if reduction == 'none':
         err_map = E(n, h, w)
-    elif reduction == 'mean':
-        mean, ratios = E(n), E(max(len(threshs), 1), n)
-    else:
-        tmean, tratios = E(1), E(max(len(threshs), 1))
-    P = lambda t: None if t is None else t.data_ptr()
-    _lib.check(lib.scf_cal_epe(pt, pp, pm, n, h, w, float(max_flow), thr, len(threshs), int(fix_threshold_quirk),
-                               P(err_map), P(mean), P(ratios), P(tmean), P(tratios), ws.data_ptr(), ops._stream()),
-               'scf_cal_epe')
-    if reduction == 'none':
+        _lib.check(lib.scf_cal_epe(pt, pp, pm, n, h, w, float(max_flow), None, 0, int(fix_threshold_quirk),
+                                   P(err_map), None, None, None, None, ws.data_ptr(), ops._stream()), 'scf_cal_epe')
         return err_map
     acc = {}
-    if reduction == 'mean':
-        acc['mean'] = mean
-        for i, t in enumerate(threshs):
-            acc[f'{t}px'] = ratios[i]
-    else:
-        acc['mean'] = tmean.reshape(())
-        for i, t in enumerate(threshs):
-            acc[f'{t}px'] = tratios[i]
+    # the kernel counts up to 8 thresholds per pass: longer lists take one pass per group of 8 (the mean is the same
+    # number every time)
+    groups = [threshs[i:i + 8] for i in range(0, len(threshs), 8)] or [()]
+    for grp in groups:
+        thr = (C.c_float * max(len(grp), 1))(*[float(t) for t in grp])
+        mean = ratios = tmean = tratios = None
+        if reduction == 'mean':
+            mean, ratios = E(n), E(max(len(grp), 1), n)
+        else:
+            tmean, tratios = E(1), E(max(len(grp), 1))
+        _lib.check(lib.scf_cal_epe(pt, pp, pm, n, h, w, float(max_flow), thr, len(grp), int(fix_threshold_quirk),
+                                   None, P(mean), P(ratios), P(tmean), P(tratios), ws.data_ptr(), ops._stream()),
+                   'scf_cal_epe')
+        if 'mean' not in acc:
+            acc['mean'] = mean if reduction == 'mean' else tmean.reshape(())
+        for i, t in enumerate(grp):
+            acc[f'{t}px'] = ratios[i] if reduction == 'mean' else tratios[i]
     return acc
 
 

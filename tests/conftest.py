@@ -44,7 +44,15 @@ def _library_built():
 DISPATCH_PLAN = os.path.join(GOLDEN, 'dispatch_plan.json')
 
 
+def _cu_count():
+    import torch
+    return int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count)
+
+
 def check_dispatch(name, ran):
+    """the plan is a property of (library, device): it carries the CU count it was recorded on ('_cus'), and a
+    device with another CU count (a partitioned MI355X, another gfx950 SKU) skips the comparison instead of failing
+    every golden test on it -- the numerics assertions of the calling test still run."""
     import json
     got = sorted({f'{tag} | {kind}' for tag, kind in ran})
     assert got, f'{name}: no convolution launch was recorded'
@@ -52,11 +60,17 @@ def check_dispatch(name, ran):
         out = os.path.join(ROOT, 'gpurun_out', 'dispatch_plan.json')
         os.makedirs(os.path.dirname(out), exist_ok=True)
         plan = json.load(open(out)) if os.path.exists(out) else {}
+        plan['_cus'] = _cu_count()
         plan[name] = got
         with open(out, 'w') as f:
             json.dump(plan, f, indent=1, sort_keys=True)
         return
-    plan = json.load(open(DISPATCH_PLAN))
+    plan = json.load(open(os.environ.get('SCF_DISPATCH_PLAN', DISPATCH_PLAN)))
+    if plan.get('_cus', 256) != _cu_count():
+        import warnings
+        warnings.warn(f"{name}: dispatch plan recorded on {plan.get('_cus', 256)} CUs, this device has {_cu_count()}: "
+                      'kernel-selection check skipped')
+        return
     assert name in plan, f'{name}: no pinned dispatch plan (run the GPU tests with SCF_WRITE_DISPATCH_PLAN=1)'
     want = plan[name]
     assert got == want, (f'{name}: the convolution kernels that ran differ from the pinned plan -- '

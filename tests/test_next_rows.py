@@ -372,3 +372,27 @@ def test_cal_epe_rejects_cpu_tensors():
     from scflow_amd._lib import ScflowHipError
     with pytest.raises(ScflowHipError):
         cal_epe(torch.zeros(1, 2, 4, 4), torch.zeros(1, 2, 4, 4), None)
+
+
+@pytest.mark.gpu
+def test_cal_epe_accepts_any_float_dtype_layout_and_threshold_count():
+    """like the reference's torch expressions, cal_epe takes non-contiguous / non-fp32 flows (coerced to
+    dense fp32) and any number of thresholds (one pass per group of 8); 'total_mean' is a parallel fixed-order sum."""
+    g = torch.Generator().manual_seed(5)
+    tgt = torch.randn((3, 2, 37, 53), generator=g) * 3
+    pred = tgt + torch.randn((3, 2, 37, 53), generator=g)
+    m = (torch.rand((3, 37, 53), generator=g) > 0.3).float()
+    threshs = (0.25, 0.5, 0.75, 1, 1.5, 2, 3, 4, 5, 8, 12)
+    for red in ('mean', 'total_mean'):
+        want = oracle.cal_epe(tgt, pred, m, reduction=red, threshs=threshs)
+        base = cal_epe(tgt.to(DEV), pred.to(DEV), m.to(DEV), reduction=red, threshs=threshs)
+        # fp64 inputs, channel-last memory layout, boolean mask
+        odd = cal_epe(tgt.double().to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2),
+                      pred.double().to(DEV), m.bool().to(DEV), reduction=red, threshs=threshs)
+        assert set(base) == set(want) == set(odd)
+        for k in want:
+            _close(base[k].cpu(), want[k], atol=1e-6, rtol=2e-6)
+            assert torch.equal(base[k], odd[k]), k
+    a = cal_epe(tgt.to(DEV), pred.to(DEV), m.to(DEV), reduction='total_mean')
+    b = cal_epe(tgt.to(DEV), pred.to(DEV), m.to(DEV), reduction='total_mean')
+    assert all(torch.equal(a[k], b[k]) for k in a)          # run-to-run identical
