@@ -694,14 +694,20 @@ class record_conv_kernels:
     (the tag ``conv_timing`` uses), family = one of ``_lib.KERNEL_NAMES``' values.  Parity tests assert with
     it that the kernel they name really ran (the choice depends on grid size and device)."""
 
+    _active = False      # the library keeps ONE process-wide log: a nested recorder would clear the outer one's records
+
     def __init__(self, capacity: int = 1 << 16) -> None:
         self.capacity, self.ran = capacity, []
 
     def __enter__(self):
+        if record_conv_kernels._active:
+            raise RuntimeError('record_conv_kernels does not nest (one process-wide dispatch log)')
         _lib.check(_lib.load().scf_conv_log_enable(self.capacity), 'scf_conv_log_enable')
+        record_conv_kernels._active = True
         return self.ran
 
     def __exit__(self, *exc):
+        record_conv_kernels._active = False
         lib = _lib.load()
         n = lib.scf_conv_log_read(None, 0)
         buf = (_lib.ConvLogEntry * max(n, 1))()

@@ -59,10 +59,23 @@ def test_tune_knobs_validate_their_values():
     from scflow_amd import ops
     assert lib.scf_tune(999, 0) < 0
     assert lib.scf_tune(ops.TUNE_KEYS['wino1d4'], 3) < 0 and lib.scf_tune(ops.TUNE_KEYS['wino1d4'], -1) < 0
-    assert ops.tune('wino1d4', 0) == 1            # default: F(4, 5) where the dispatch prefers it
-    assert ops.tune('wino1d4', 2) == 0
-    assert ops.tune('wino1d4', 1) == 2
-    assert ops.tune('wino_variant', 0) == 0
+    try:
+        assert ops.tune('wino1d4', 0) == 1            # default: F(4, 5) where the dispatch prefers it
+        assert ops.tune('wino1d4', 2) == 0
+        assert ops.tune('wino1d4', 1) == 2
+        assert ops.tune('wino_variant', 0) == 0
+        # the lookup knobs (r5): pipelined variant 0..3, store policy 0..5
+        assert lib.scf_tune(ops.TUNE_KEYS['lookup_pipe'], 4) < 0 and lib.scf_tune(ops.TUNE_KEYS['lookup_store'], 6) < 0
+        assert ops.tune('lookup_pipe', 2) == 0 and ops.tune('lookup_pipe', 0) == 2
+        assert ops.tune('lookup_store', 4) == 0 and ops.tune('lookup_store', 0) == 4
+        # ops.tune never hands an error code back as a "previous value"
+        with pytest.raises(ValueError):
+            ops.tune('no_such_knob', 1)
+        with pytest.raises(_lib.ScflowHipError):
+            ops.tune('wino1d4', 7)
+    finally:                                          # a failed assertion must not leave a knob off its default
+        for key, default in (('wino1d4', 1), ('wino_variant', 0), ('lookup_pipe', 0), ('lookup_store', 0)):
+            lib.scf_tune(ops.TUNE_KEYS[key], default)
 
 
 def test_conv_desc_layout_matches_c():
