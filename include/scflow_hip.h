@@ -54,7 +54,7 @@ enum {
  * returns the number the LIBRARY was built with: a C caller compares scf_version() / 100 with
  * SCF_ABI_MAJOR before its first call; structs additionally carry no size field,
  * so a mismatch must be refused, not worked around. */
-#define SCF_ABI_MAJOR 4
+#define SCF_ABI_MAJOR 5
 #define SCF_VERSION (SCF_ABI_MAJOR * 100 + 0)
 int scf_version(void);
 const char* scf_error_string(int code);
@@ -190,6 +190,15 @@ typedef struct scf_conv_desc {
   const float* wp_wino1d4;              /* optional: the F(4, 5) packing of the same 1x5 / 5x1 layer (scf_pack_conv_weight_wino1d4):
                                            four outputs per 8 multiplies; taken before wp_wino1d on grids of more than CUs / 2 of its
                                            blocks (64 channels x 256 pixels); same contract as wp_wino */
+  int32_t k_slices;                     /* 0 / 1: off.  S > 1 (r5): the contraction over the input channels is split across
+                                           S groups of BLOCKS: slice s contracts its share of the channel chunks and stores the
+                                           raw partial sums at out + s * out_slice_stride; the CONSUMER adds the S partial
+                                           tensors in slice order (scf_group_norm_relu_parts, scf_fc_splitk's x_parts) -- no
+                                           atomics, a fixed summation order.  Small grids only (a block there is a chain of one
+                                           memory round trip per chunk: S slices = 1 / S of the chain on S times the blocks).
+                                           Plain epilogue required: no bias / scale / res / act / GRU mode / out_div / tiled
+                                           output; LDS-DMA kernel only (wp_a4 or wp_a4s), else SCF_EUNSUPPORTED */
+  int64_t out_slice_stride;             /* floats between consecutive partial tensors (>= N * out_nstride) */
 } scf_conv_desc;
 
 int scf_conv2d(const scf_conv_desc* desc, scf_stream_t stream);
@@ -352,6 +361,11 @@ int scf_instance_norm(const float* x, const float* res, float* out, int64_t plan
 /* GroupNorm(G, eps, affine) + ReLU on (N, C, HW).     replaces pose_head.py:151-159 */
 int scf_group_norm_relu(const float* x, const float* gamma, const float* beta, float* out,
                         int N, int C, int HW, int G, float eps, scf_stream_t stream);
+/* the same on an input that arrives as `parts` partial tensors part_stride floats apart (a convolution launched
+ * with scf_conv_desc.k_slices = parts): every element is the sum of its parts in part order */
+int scf_group_norm_relu_parts(const float* x, int parts, int64_t part_stride, const float* gamma,
+                              const float* beta, float* out, int N, int C, int HW, int G, float eps,
+                              scf_stream_t stream);
 
 /* y[n, o] = act(sum_k W[o,k] x[n,k] + b[o]);  W row-major (O, K). replaces nn.Linear
  * at pose_head.py:166-172, 203-206.                                                 */

@@ -15,7 +15,7 @@ SCF_OK = 0
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 CONV_PLAIN, CONV_GRU_ZR, CONV_GRU_Q = 0, 1, 2
 MAX_LEVELS = 12
-ABI_MAJOR = 4            # SCF_ABI_MAJOR of include/scflow_hip.h this binding was written against
+ABI_MAJOR = 5            # SCF_ABI_MAJOR of include/scflow_hip.h this binding was written against
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -54,6 +54,8 @@ class ConvDesc(C.Structure):
         ('wp_wino1d', _fp),
         ('wp_wino', _fp),
         ('wp_wino1d4', _fp),
+        ('k_slices', C.c_int32),
+        ('out_slice_stride', C.c_int64),
     ]
 
 
@@ -180,6 +182,8 @@ SIGNATURES = {
     'scf_instance_norm': (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int, C.c_float, C.c_int, _fp]),
     'scf_group_norm_relu': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_float, _fp]),
+    'scf_group_norm_relu_parts': (C.c_int, [_fp, C.c_int, C.c_int64, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_float, _fp]),
     'scf_fc_splitk': (C.c_int, [C.POINTER(FcDesc), _fp]),
     'scf_linear': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     'scf_linear_pair': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int,

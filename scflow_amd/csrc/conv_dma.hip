@@ -144,7 +144,19 @@ __global__ __launch_bounds__(256 * NG, (KSP || NST > 2) ? 1 : 2) void conv_dma_k
   // block-uniform tile coordinates, pinned to SGPRs (the integer divisions are expanded on the
   // vector ALU and would otherwise leave n / m0 / the tile origin -- and every pointer derived
   // from them -- in VGPRs)
-  const int lb = scf_xcd_remap(blockIdx.x, gridDim.x);
+  int lb = scf_xcd_remap(blockIdx.x, gridDim.x);
+  // K split across blocks (r5): slice ksl contracts chunks [cb, cb + nch) and stores raw partial sums into its own
+  // output tensor; the consumer adds the slices in order.  kslices <= 1: one slice = everything.
+  int cb = 0, nch = p.nchunk;
+  if (p.kslices > 1) {
+    const int ksl = __builtin_amdgcn_readfirstlane(lb / p.slice_blocks);
+    lb -= ksl * p.slice_blocks;
+    const int cps = (p.nchunk + p.kslices - 1) / p.kslices;
+    cb = ksl * cps;
+    nch = min(cps, p.nchunk - cb);
+    nch = nch < 0 ? 0 : nch;
+    p.out += (long long)ksl * p.slice_ns;
+  }
   const int mblk = __builtin_amdgcn_readfirstlane(lb % p.mblocks);
   const int tile = __builtin_amdgcn_readfirstlane(lb / p.mblocks);
   const int m0 = mblk * BM;
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(256 * NG, (KSP || NST > 2) ? 1 : 2) void conv_dma_k
       bdma_slot<true>(wrs, woff[u], wl0 + u * 4096, wrem - u * 256);
   };
   CTRACE(1);
-  if (grp < p.nchunk) stage_w(grp, 0);
+  if (grp < nch) stage_w(cb + grp, 0);
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- gather table: LDS patch float e = tid + 256u <-> (group g, half h, py, px, s) ----
@@ -308,31 +320,31 @@ __global__ __launch_bounds__(256 * NG, (KSP || NST > 2) ? 1 : 2) void conv_dma_k
   // DMA instructions this wave issues per chunk (the same for every chunk): vmcnt bookkeeping
   const int cnt = __builtin_amdgcn_readfirstlane(max(0, (prem0 + 255) >> 8) + max(0, (wrem0 + 255) >> 8));
 
-  if (grp < p.nchunk) stage_p(grp, 0);   // (its weights went out before the table)
+  if (grp < nch) stage_p(cb + grp, 0);   // (its weights went out before the table)
 #pragma unroll
   for (int c = 1; c < NST - 1; ++c)
-    if (c < p.nchunk) stage(c, c);
+    if (c < nch) stage(cb + c, c);
   CTRACE(2);
 
   int buf = 0;                         // ring slot of the current chunk
   // wave group g walks chunks g, g + NG, ...; every group runs the same number of iterations (the barriers are the
   // block's), an iteration past the group's last chunk does nothing between them
-  const int niter = (p.nchunk + NG - 1) / NG;
+  const int niter = (nch + NG - 1) / NG;
   for (int iter = 0; iter < niter; ++iter) {
     const int chunk = iter * NG + grp;
-    const bool live = NG == 1 || chunk < p.nchunk;
+    const bool live = NG == 1 || chunk < nch;
     __builtin_amdgcn_s_setprio(3);
     // this wave's DMA of THIS chunk has landed; up to NST-2 later chunks stay in flight
     if (NST == 2) {
       __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
     } else {
-      const int later = min(NST - 2, p.nchunk - 1 - chunk);
+      const int later = min(NST - 2, nch - 1 - chunk);
       wait_vmcnt_le(later * cnt);
     }
     CTRACE(4 + chunk * 4);
     __syncthreads();                                   // everyone's has; previous MFMA phase done
     CTRACE(5 + chunk * 4);
-    if (!CLAB(0) && chunk + NG * (NST - 1) < p.nchunk) stage(chunk + NG * (NST - 1), buf == 0 ? NST - 1 : buf - 1);
+    if (!CLAB(0) && chunk + NG * (NST - 1) < nch) stage(cb + chunk + NG * (NST - 1), buf == 0 ? NST - 1 : buf - 1);
     CTRACE(6 + chunk * 4);
     __builtin_amdgcn_s_setprio(0);                     // the MFMA stream yields to the other waves
     if (!live) continue;
@@ -519,6 +531,10 @@ int scf_dma_ksplit_groups_set(int v) { return g_ksp_groups.exchange(v); }
 
 int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st) {
   if ((!k.wp4 && !k.wp4s) || (k.stride != 1 && k.stride != 2) || k.w_ns != 0) return SCF_EUNSUPPORTED;
+  // K split across blocks: S slices are S times the blocks (grid-size decisions below see N * S samples) and 1 / S of
+  // every block's chunk chain
+  const int S = k.kslices > 1 ? k.kslices : 1;
+  const long long NE = (long long)N * S;
   // A 1x1 / stride-2 / pad-0 layer (the ResNet shortcuts, resnet.py:721-730) reads every second row and column of
   // its input and nothing else: it runs as a DENSE 1x1 over that sub-grid -- the gather table of the dword staging
   // path doubles its row / column steps (in_step), everything behind the staging sees a stride-1 layer on an
@@ -570,7 +586,7 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
       if (PE > (px4_large ? 1024 * SCF_DMA_PU_X4 : 256 * SCF_DMA_PU) || WF4 > 256 * SCF_DMA_WU ||
           ldsb > SCF_DMA_LDS_MAX) continue;
       const long long tiles_y = (k.Ho + TR - 1) / TR;
-      const long long blk = (long long)N * tiles_y * ((k.Wo + FC - 1) / FC) * ((frags_m + WM - 1) / WM);
+      const long long blk = NE * tiles_y * ((k.Wo + FC - 1) / FC) * ((frags_m + WM - 1) / WM);
       if (blk >= slots) {
         const long long full = blk / slots, rem = blk % slots;
         const float rounds = (float)full + (rem == 0 ? 0.f : rem * 2 <= slots ? 0.6f : 1.0f);
@@ -593,7 +609,7 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   if (!pix_ok) {
     // only the small-grid packing is present (dense 1x1): it is for small grids only -- fewer than
     // 256 blocks even with the smallest pixel-split tile (32 channels x 128 pixels)
-    const long long blk11 = (long long)N * ((k.Ho + 4 * FR - 1) / (4 * FR)) * ((k.Wo + FC - 1) / FC) * frags_m;
+    const long long blk11 = NE * ((k.Ho + 4 * FR - 1) / (4 * FR)) * ((k.Wo + FC - 1) / FC) * frags_m;
     if (blk11 >= 256) return SCF_EUNSUPPORTED;
   }
   if (KC) k.nchunk = (k.Cin + KC - 1) / KC;
@@ -608,7 +624,7 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   // batch 8 8.95 -> 8.14; the 4- and 6-deep rings of round 2 lost at every batch size).
   bool use_ksp = !large || g_force_ksp.load(std::memory_order_relaxed) != 0;
   const ConvK k_in = k;
-  const long long ksp_blk = (long long)N * ((k.Ho + FR - 1) / FR) * ((k.Wo + FC - 1) / FC) * frags_m;
+  const long long ksp_blk = NE * ((k.Ho + FR - 1) / FR) * ((k.Wo + FC - 1) / FC) * frags_m;
   // TINY grids (no more blocks than CUs: every block alone on its CU): a launch is a chain of one
   // memory round trip per staged chunk (~1.8 us each, whatever the arithmetic: 17 us for a 128 -> 128
   // 3x3 onto a 4 x 4 map), so 3x3 layers take 32-channel chunks there when the caller provides that
@@ -637,7 +653,7 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
     for (int c = 0; c < 3; ++c) {
       const int g = cand_g[c];
       if (!cand_w[c] || !(g == 1 || g == 2 || g == 4) || (k.in1 && (k.C0 % (8 * g)) != 0)) continue;
-      const int nch = (k.Cin + 8 * g - 1) / (8 * g);
+      const int nch = ((k.Cin + 8 * g - 1) / (8 * g) + S - 1) / S;      // chunks of one slice
       const int ng = (groups_ok && nch >= 4 && fits_ksp(g, 2)) ? 2 : 1;
       if (!fits_ksp(g, ng)) continue;
       const int chain = (nch + ng - 1) / ng;
@@ -691,6 +707,8 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
 
   k.tiles_x = (k.Wo + FC - 1) / FC;
   k.mblocks = (frags_m + WM - 1) / WM;
+  k.slice_blocks = (int)(nblk / S);
+  if (S > 1 && k.nchunk < S) return SCF_EUNSUPPORTED;        // every slice owns at least one chunk
   if (info) { info[0] = WM; info[1] = ksp ? ngroups : WN; info[2] = (int)nblk; info[3] = k.T * G * 4 * WM * WN / (ksp ? 4 : 1); }
   if (dry_run) return SCF_OK;
 #define SCF_GO(...) return px4 ? launch_dma<__VA_ARGS__, true>(k, (int)nblk, ldsb, st)            \

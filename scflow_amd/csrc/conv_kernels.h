@@ -30,6 +30,9 @@ struct ConvK {
   const float* gru_h; long long gru_h_ns;
   float* gru_aux; long long gru_aux_ns;
   const float* gru_z; long long gru_z_ns;
+  int kslices;               // > 1: K split across groups of blocks (conv_dma.hip), partial tensors slice_ns floats apart
+  long long slice_ns;
+  int slice_blocks;          // blocks per slice
 };
 
 // Per-sample base pointers of every tensor the epilogue touches.  The sample index is uniform

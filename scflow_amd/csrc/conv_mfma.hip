@@ -414,6 +414,12 @@ static int conv_plan(const scf_conv_desc* d, ConvPlan* plan) {
   if (d->mode == SCF_CONV_GRU_Q && (!d->gru_h || !d->gru_z)) return SCF_EINVAL;
   if ((d->scale == nullptr) != (d->shift == nullptr)) return SCF_EINVAL;
   if (d->out_tile8x4 && (d->mode != SCF_CONV_PLAIN || d->res)) return SCF_EUNSUPPORTED;
+  if (d->k_slices > 1) {      // partial tensors: raw sums only, the consumer finishes them
+    if (d->k_slices > 16 || d->out_slice_stride < (int64_t)d->N * d->out_nstride) return SCF_EINVAL;
+    if (d->bias || d->scale || d->res || d->act != SCF_ACT_NONE || d->act_split > 0 || d->mode != SCF_CONV_PLAIN ||
+        d->out_tile8x4 || (d->out_div != 0.f && d->out_div != 1.f) || d->w_nstride != 0)
+      return SCF_EINVAL;
+  }
 
   ConvK& k = plan->k;
   k.in0 = d->in0; k.in1 = d->C1 > 0 ? d->in1 : nullptr;
@@ -449,6 +455,7 @@ static int conv_plan(const scf_conv_desc* d, ConvPlan* plan) {
   k.gru_h = d->gru_h; k.gru_h_ns = d->gru_h_nstride;
   k.gru_aux = d->gru_aux; k.gru_aux_ns = d->gru_aux_nstride;
   k.gru_z = d->gru_z; k.gru_z_ns = d->gru_z_nstride;
+  k.kslices = d->k_slices > 1 ? d->k_slices : 1; k.slice_ns = d->out_slice_stride; k.slice_blocks = 0;
 
   // fragment = FR rows x FC columns of the output (FR * FC = 32).  FC = 32 unless a narrower
   // fragment wastes clearly fewer columns of the last tile of each row (Wo = 80: 3 x 32 covers 96
@@ -550,6 +557,11 @@ static int conv2d_launch(const scf_conv_desc* d, scf_stream_t stream, int* which
   ConvPlan pl;
   const int rc = conv_plan(d, &pl);
   if (rc != SCF_OK) return rc;
+  if (d->k_slices > 1) {        // only the LDS-DMA kernel splits K across blocks
+    *which = SCF_KERNEL_DMA;
+    if (!want_dma(d)) return SCF_EUNSUPPORTED;
+    return scf_conv_dma_dispatch(pl.k, d->N, false, nullptr, scf_stream(stream));
+  }
   {
     *which = SCF_KERNEL_THIN;
     const int rt = scf_conv_thin_dispatch(pl.k, d->N, false, scf_stream(stream));
@@ -776,6 +788,12 @@ extern "C" int scf_conv2d_query(const scf_conv_desc* d, int32_t* info) {
   ConvPlan pl;
   const int rc = conv_plan(d, &pl);
   if (rc != SCF_OK) return rc;
+  if (d->k_slices > 1) {
+    if (!want_dma(d)) return SCF_EUNSUPPORTED;
+    const int rs = scf_conv_dma_dispatch(pl.k, d->N, true, info, nullptr);
+    if (rs == SCF_OK) info[3] = -info[3];
+    return rs;
+  }
   if (scf_conv_thin_dispatch(pl.k, d->N, true, nullptr) == SCF_OK) {
     info[0] = info[1] = 0; info[2] = 0; info[3] = -1;      // vector-ALU thin-output kernel
     return SCF_OK;

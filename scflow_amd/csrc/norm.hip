@@ -140,7 +140,10 @@ extern "C" int scf_instance_norm(const float* x, const float* res, float* out, i
 // Channels of a group are contiguous in NCHW, so a group is one contiguous run of
 // (C/G)*HW floats.  One block per (n, g).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void group_norm_relu_kernel(const float* __restrict__ x,
+// x may arrive as `parts` partial tensors (a convolution whose K was split across blocks, scf_conv_desc.k_slices):
+// the value of an element is the sum of its parts IN PART ORDER, formed the same way in all three passes.
+__global__ __launch_bounds__(256) void group_norm_relu_kernel(const float* __restrict__ x, int parts,
+                                                              long long part_stride,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta,
                                                               float* __restrict__ out, int C, int HW,
@@ -151,30 +154,42 @@ __global__ __launch_bounds__(256) void group_norm_relu_kernel(const float* __res
   const int cnt = cpg * HW;
   const long long base = ((long long)n * C + (long long)g * cpg) * HW;
   const float* xp = x + base;
+  auto at = [&](int i) {
+    float v = xp[i];
+    for (int sl = 1; sl < parts; ++sl) v += xp[(long long)sl * part_stride + i];
+    return v;
+  };
   float s = 0.f;
-  for (int i = threadIdx.x; i < cnt; i += 256) s += xp[i];
+  for (int i = threadIdx.x; i < cnt; i += 256) s += at(i);
   const float mean = block_sum_256(s, red) / (float)cnt;
   float q = 0.f;
   for (int i = threadIdx.x; i < cnt; i += 256) {
-    const float a = xp[i] - mean;
+    const float a = at(i) - mean;
     q += a * a;
   }
   const float var = block_sum_256(q, red) / (float)cnt;
   const float rstd = 1.0f / sqrtf(var + eps);
   for (int i = threadIdx.x; i < cnt; i += 256) {
     const int c = g * cpg + i / HW;
-    const float o = (xp[i] - mean) * rstd * gamma[c] + beta[c];
+    const float o = (at(i) - mean) * rstd * gamma[c] + beta[c];
     out[base + i] = fmaxf(o, 0.f);
   }
 }
 
+extern "C" int scf_group_norm_relu_parts(const float* x, int parts, int64_t part_stride, const float* gamma,
+                                         const float* beta, float* out, int N, int C, int HW, int G, float eps,
+                                         scf_stream_t stream) {
+  if (!x || !gamma || !beta || !out || N <= 0 || C <= 0 || HW <= 0 || G <= 0 || parts < 1) return SCF_EINVAL;
+  if (parts > 1 && part_stride < (int64_t)N * C * HW) return SCF_EINVAL;
+  if (C % G != 0) return SCF_EUNSUPPORTED;
+  scf_launch(group_norm_relu_kernel, dim3(N * G), dim3(256), 0, scf_stream(stream), x, parts, (long long)part_stride,
+             gamma, beta, out, C, HW, G, eps);
+  return scf_launch_status();
+}
+
 extern "C" int scf_group_norm_relu(const float* x, const float* gamma, const float* beta, float* out,
                                    int N, int C, int HW, int G, float eps, scf_stream_t stream) {
-  if (!x || !gamma || !beta || !out || N <= 0 || C <= 0 || HW <= 0 || G <= 0) return SCF_EINVAL;
-  if (C % G != 0) return SCF_EUNSUPPORTED;
-  scf_launch(group_norm_relu_kernel, dim3(N * G), dim3(256), 0, scf_stream(stream), x, gamma,
-                     beta, out, C, HW, G, eps);
-  return scf_launch_status();
+  return scf_group_norm_relu_parts(x, 1, 0, gamma, beta, out, N, C, HW, G, eps, stream);
 }
 
 // ---------------------------------------------------------------------------------

@@ -156,12 +156,15 @@ extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stre
     SCF_TRY(scf_conv2d(&it->pose[i], stream));
     const scf_iter_gn& g = it->gn[i];
     if (it->fc_fused && i == 2) break;          // the last GroupNorm + ReLU is folded into fc1's operand load
-    SCF_TRY(scf_group_norm_relu(it->pose[i].out, g.gamma, g.beta, g.out, N, g.C, g.HW, g.G, g.eps, stream));
+    const scf_conv_desc& pc = it->pose[i];      // K split across blocks: the normalisation adds the partial tensors
+    SCF_TRY(scf_group_norm_relu_parts(pc.out, pc.k_slices > 1 ? pc.k_slices : 1, pc.out_slice_stride, g.gamma, g.beta, g.out,
+                                      N, g.C, g.HW, g.G, g.eps, stream));
   }
   if (it->fc_fused) {
     const scf_iter_gn& g = it->gn[2];
     scf_fc_desc f = {};
-    f.x = it->pose[2].out; f.x_parts = 1; f.gn_groups = g.G; f.gn_hw = g.HW; f.gn_gamma = g.gamma; f.gn_beta = g.beta;
+    f.x = it->pose[2].out; f.x_parts = it->pose[2].k_slices > 1 ? it->pose[2].k_slices : 1;
+    f.x_part_stride = it->pose[2].out_slice_stride; f.gn_groups = g.G; f.gn_hw = g.HW; f.gn_gamma = g.gamma; f.gn_beta = g.beta;
     f.gn_eps = g.eps; f.N = N; f.K = it->fc1_K; f.W = it->fc1_w; f.y = it->fc1_out; f.O = it->fc1_O; f.slices = it->fc1_slices;
     SCF_TRY(scf_fc_splitk(&f, stream));
     scf_fc_desc f2 = {};

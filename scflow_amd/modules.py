@@ -145,9 +145,11 @@ class ConvBlock(HipModule):
     def forward(self, x0: Tensor, x1: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
         if self.groups is None:
             return ops.conv2d(self.packed, x0, x1, out=out, act=self.act)
-        y = ops.conv2d(self.packed, x0, x1)
         if self.act != ACT_RELU:
             raise NotImplementedError('GN is fused with ReLU only')
+        # small grids: K split across blocks, the normalisation adds the partial tensors (ops.conv_kslices)
+        ks = ops.conv_kslices(self.packed, x0.shape[0], x0.shape[2], x0.shape[3])
+        y = ops.conv2d(self.packed, x0, x1, kslices=ks)
         return ops.group_norm_relu(y, self.gn.weight, self.gn.bias, self.groups, self.gn.eps, out=out)
 
 
@@ -509,11 +511,15 @@ class MultiClassPoseHead(HipModule):
         fc1, fc2 = self.fc_layers[0][0], self.fc_layers[1][0]
         if s1:
             last = self.conv_layers[2]
-            y = ops.conv2d(last.packed, x)                     # GroupNorm + ReLU: applied by fc1's operand load
-            hw = y.shape[2] * y.shape[3]
-            if y[0].numel() != fc1.in_features:
-                raise _lib_error(f'pose head expects {fc1.in_features} features, the maps give {y[0].numel()}')
-            p1 = ops.fc_splitk(y.view(y.shape[0], -1), fc1.weight, gn=(last.groups, hw, last.gn.weight, last.gn.bias, last.gn.eps),
+            # GroupNorm + ReLU: applied by fc1's operand load, which also adds the partial tensors of a K-sliced launch
+            ks = ops.conv_kslices(last.packed, x.shape[0], x.shape[2], x.shape[3])
+            y = ops.conv2d(last.packed, x, kslices=ks)
+            hw = y.shape[-2] * y.shape[-1]
+            feat = y.shape[-3] * hw
+            if feat != fc1.in_features:
+                raise _lib_error(f'pose head expects {fc1.in_features} features, the maps give {feat}')
+            yv = y.view(ks, x.shape[0], feat) if ks > 1 else y.view(x.shape[0], feat)
+            p1 = ops.fc_splitk(yv, fc1.weight, gn=(last.groups, hw, last.gn.weight, last.gn.bias, last.gn.eps),
                                slices=s1)
             p2 = ops.fc_splitk(p1, fc2.weight, x_bias=fc1.bias, x_relu=True, slices=s2)
             return ops.fc_splitk(p2, self.rotation_pred.weight, self.rotation_pred.bias, x_bias=fc2.bias, x_relu=True,
@@ -739,11 +745,12 @@ def _scflow_forward_c(self, pyramid, tiled, hx, ctx, rot0, trans0, depth, intern
     for i, blk in enumerate(ph.conv_layers):
         if blk.groups is None or blk.act != ACT_RELU:
             raise NotImplementedError('pose head: conv + GroupNorm + ReLU blocks')
-        d_, y = ops.conv_desc(blk.packed, x0, x1)
-        g = torch.empty_like(y)
+        ks = ops.conv_kslices(blk.packed, x0.shape[0], x0.shape[2], x0.shape[3])
+        d_, y = ops.conv_desc(blk.packed, x0, x1, kslices=ks)       # ks > 1: (ks, N, C, h, w) partial tensors
+        g = torch.empty_like(y[0] if ks > 1 else y)
         it.pose[i] = d_
         it.gn[i].gamma, it.gn[i].beta, it.gn[i].out = blk.gn.weight.data_ptr(), blk.gn.bias.data_ptr(), g.data_ptr()
-        it.gn[i].C, it.gn[i].HW, it.gn[i].G, it.gn[i].eps = y.shape[1], y.shape[2] * y.shape[3], blk.groups, blk.gn.eps
+        it.gn[i].C, it.gn[i].HW, it.gn[i].G, it.gn[i].eps = y.shape[-3], y.shape[-2] * y.shape[-1], blk.groups, blk.gn.eps
         keep += [y, g]
         x0, x1 = g, None
     fc1, fc2 = ph.fc_layers[0][0], ph.fc_layers[1][0]

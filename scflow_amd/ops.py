@@ -26,7 +26,7 @@ from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_GRU_Q, CONV_G
 Tensor = torch.Tensor
 
 __all__ = ['record_conv_kernels', 'PackedConv', 'conv_desc', 'gru_passes', 'scflow_iteration', 'side_stream_handle', 'pyramid_layout', 'untile_level', 'level_storage_shape', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision', 'set_conv_winograd', 'get_conv_winograd', 'pack_conv_weight_wino', 'pack_conv_weight_wino1d', 'pack_conv_weight_wino1d4',
-           'get_conv_precision', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
+           'get_conv_precision', 'set_conv_kslices', 'conv_kslices', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
            'instance_norm', 'group_norm_relu', 'linear', 'fc_splitk', 'fc_slices', 'pose_update', 'reproject_flow',
            'unproject_depth', 'linear_pair', 'resize_bilinear', 'convex_upsample', 'avgpool2x2', 'copy_channels',
            'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_TANH', 'CONV_PLAIN', 'CONV_GRU_ZR',
@@ -455,9 +455,13 @@ def conv_desc(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Opti
 def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optional[Tensor] = None,
            *, res: Optional[Tensor] = None, act: int = ACT_NONE, act2: int = ACT_NONE,
            act_split: int = 0, mode: int = CONV_PLAIN, gru_h: Optional[Tensor] = None,
-           gru_aux: Optional[Tensor] = None, gru_z: Optional[Tensor] = None, _launch: bool = True):
+           gru_aux: Optional[Tensor] = None, gru_z: Optional[Tensor] = None, kslices: int = 1,
+           _launch: bool = True):
     """implicit-GEMM MFMA convolution with fused epilogue (scf_conv2d).
-    input = channel concat of x0 and x1; ``out`` may be a channel slice."""
+    input = channel concat of x0 and x1; ``out`` may be a channel slice.
+    ``kslices`` = S > 1: the contraction over the input channels is split across S groups of blocks
+    (``scf_conv_desc.k_slices``); returns the (S, N, Cout, Ho, Wo) RAW partial sums -- the consumer adds them in slice
+    order (``group_norm_relu`` / ``fc_splitk`` take such a tensor).  Plain epilogue only (the layer has no bias)."""
     p0, n, c0, h, w, s0 = _nchw(x0, 'x0')
     p1, c1, s1 = None, 0, 0
     if x1 is not None:
@@ -467,6 +471,14 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
     if c0 + c1 != pc.cin:
         raise _lib.ScflowHipError(f'conv expects {pc.cin} input channels, got {c0}+{c1}')
     ho, wo = pc.out_hw(h, w)
+    sliced = None
+    if kslices > 1:
+        if pc.bias is not None or pc.scale is not None or res is not None or act != ACT_NONE or mode != CONV_PLAIN:
+            raise _lib.ScflowHipError('conv2d(kslices > 1): partial sums take a plain epilogue (no bias / BN / res / act)')
+        sliced = out if out is not None else torch.empty((kslices, n, pc.cout, ho, wo), dtype=torch.float32, device=x0.device)
+        if tuple(sliced.shape) != (kslices, n, pc.cout, ho, wo) or not sliced.is_contiguous():
+            raise _lib.ScflowHipError(f'conv2d(kslices={kslices}): out must be a contiguous {(kslices, n, pc.cout, ho, wo)} tensor')
+        out = sliced[0]
     if out is None:
         out = torch.empty((n, pc.cout // 2 if mode == CONV_GRU_ZR else pc.cout, ho, wo),
                           dtype=torch.float32, device=x0.device)
@@ -485,6 +497,9 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
     d.in0_nstride, d.in1_nstride = s0, s1
     d.N, d.H, d.W = n, h, w
     d.out, d.out_nstride = po, so
+    if sliced is not None:
+        d.k_slices, d.out_slice_stride = kslices, sliced.stride(0)
+        out = sliced
     if res is not None:
         pr, nr, cr, hr, wr, sr = _nchw(res, 'res')
         if (nr, cr, hr, wr) != (n, pc.cout, ho, wo):
@@ -555,6 +570,34 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
 
 
 _CONV_EVENTS = None
+
+# ---- K split across blocks for bias-free conv + GroupNorm blocks on small grids (the pose head's stride-2 layers) ----
+_CONV_KSLICES = True
+
+
+def set_conv_kslices(on: bool) -> bool:
+    """False: ``conv_kslices`` answers 1 (every convolution contracts its whole K inside one block: the r4 arithmetic
+    order); returns the previous setting."""
+    global _CONV_KSLICES
+    prev, _CONV_KSLICES = _CONV_KSLICES, bool(on)
+    return prev
+
+
+def conv_kslices(pc: 'PackedConv', n: int, h: int, w: int) -> int:
+    """slice count for ``conv2d(pc, x, kslices=...)`` of a bias-free layer whose consumer adds partial tensors.
+    A launch with few blocks is a serial chain of one memory round trip per staged channel chunk; S slices are S times
+    the blocks and 1 / S of that chain.  Rule from ``tools/lab/kslice_sweep.py`` on the MI355X (kb = blocks of the
+    32-channel x 32-pixel tile): kb < 128 -> 4 (11.8 -> 6.1 us, 18.0 -> 8.3), 128 <= kb < 512 -> 2 (4 can tip the
+    launch onto the pixel-split tile: 11.9 -> 16.4 us), kb >= 512 -> 4 (64.2 -> 44.6, 31.8 -> 28.4); never more
+    slices than 32-channel chunks."""
+    if not _CONV_KSLICES or pc.bias is not None or pc.scale is not None or (pc.wp4 is None and pc.wp4s is None):
+        return 1
+    if _CONV_PRECISION == 'f16x3' and pc.wp16 is not None:
+        return 1
+    ho, wo = pc.out_hw(h, w)
+    kb = n * ((ho * wo + 31) // 32) * ((pc.cout + 31) // 32)
+    s = 2 if 128 <= kb < 512 else 4
+    return max(1, min(s, pc.cin // 32))
 
 
 def _gru_passes(packs):
@@ -953,13 +996,19 @@ def instance_norm(x: Tensor, res: Optional[Tensor] = None, relu: bool = False,
 
 def group_norm_relu(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float = 1e-5,
                     out: Optional[Tensor] = None) -> Tensor:
+    """GroupNorm(groups, eps, affine) + ReLU of an (N, C, H, W) map, or of the (S, N, C, H, W) partial sums of
+    ``conv2d(..., kslices=S)`` (added in slice order inside the kernel) -> (N, C, H, W)."""
     px = _dense(x, 'x')
+    parts, pstride = 1, 0
+    if x.dim() == 5:
+        parts, pstride = x.shape[0], x.stride(0)
+        x = x[0]
     n, c, h, w = x.shape
     if out is None:
         out = torch.empty_like(x)
-    _lib.check(_lib.load().scf_group_norm_relu(px, _dense(gamma, 'gamma'), _dense(beta, 'beta'),
-                                               _dense(out, 'out'), n, c, h * w, groups, eps,
-                                               _stream()), 'scf_group_norm_relu')
+    _lib.check(_lib.load().scf_group_norm_relu_parts(px, parts, pstride, _dense(gamma, 'gamma'), _dense(beta, 'beta'),
+                                                     _dense(out, 'out'), n, c, h * w, groups, eps,
+                                                     _stream()), 'scf_group_norm_relu')
     return out
 
 

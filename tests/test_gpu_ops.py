@@ -1237,3 +1237,69 @@ def test_conv2d_small_grid_kernels(case):
     # same result as the register-staged kernel (no DMA packing) within round-off
     pc0 = ops.PackedConv.from_weight(w.to(DEV), b.to(DEV), stride=stride, padding=pad, dma_packing=False)
     close(ops.conv2d(pc0, xd, act=ops.ACT_RELU), want, atol=3e-5 * max(1.0, float(want.abs().max())), what='register-staged')
+
+
+# ------------------------------------------------------------------ K split across blocks (r5)
+@pytest.mark.parametrize('n,cin,cout,hw,ks', [(1, 224, 128, 32, 4), (3, 128, 128, 16, 4), (32, 128, 128, 8, 2),
+                                              (2, 224, 128, 30, 3), (32, 224, 128, 32, 4), (5, 96, 64, 12, 2)])
+def test_conv2d_kslices_partial_tensors(n, cin, cout, hw, ks):
+    """scf_conv_desc.k_slices: S groups of blocks each contract 1 / S of the channel chunks into their own partial tensor.
+    The partial tensors add up (in slice order) to the unsliced launch's result within the re-association error, and to
+    torch fp64 within the direct kernels' tolerance; GroupNorm on the partial tensors is bit-identical to GroupNorm on
+    their ordered sum (what the pose head relies on)."""
+    x = rnd((n, cin, hw, hw), 31 + n).abs().to(DEV)
+    wt = rnd((cout, cin, 3, 3), 32 + n, (1.0 / (cin * 9)) ** 0.5).to(DEV)
+    pc = ops.PackedConv.from_weight(wt, None, stride=2, padding=1)
+    want = F.conv2d(x.double(), wt.double(), None, stride=2, padding=1)
+    with ops.record_conv_kernels() as ran:
+        parts = ops.conv2d(pc, x, kslices=ks)
+    assert [k for _, k in ran] == ['direct-dma'], ran
+    assert parts.shape == (ks, n) + tuple(want.shape[1:])
+    total = parts[0].clone()
+    for s_ in range(1, ks):
+        total += parts[s_]
+    base = ops.conv2d(pc, x)
+    scale = F.conv2d(x.double().abs(), wt.double().abs(), None, stride=2, padding=1)
+    eps = 2.0 ** -24
+    r = float(((total.double() - want).abs() / (eps * scale)).max())
+    rb = float(((base.double() - want).abs() / (eps * scale)).max())
+    print(f'[measured] kslices={ks} N{n} {cin}->{cout} @{hw // 2}: err / (eps sum|w||x|) = {r:.2f} (unsliced {rb:.2f})')
+    assert r <= 24.0 and rb <= 24.0
+    g, b = (rnd((cout,), 5).abs() + 0.5).to(DEV), rnd((cout,), 6).to(DEV)
+    a = ops.group_norm_relu(parts, g, b, 32)
+    ref = ops.group_norm_relu(total, g, b, 32)
+    assert torch.equal(a, ref)
+    # every element of every partial tensor was written (no stale memory where a slice owns few chunks)
+    parts2 = ops.conv2d(pc, x, kslices=ks, out=torch.full_like(parts, float('nan')))
+    assert torch.equal(parts, parts2)
+
+
+def test_conv2d_kslices_rejects_epilogues():
+    x = rnd((1, 128, 8, 8), 1).to(DEV)
+    wt = rnd((128, 128, 3, 3), 2, 0.03).to(DEV)
+    with pytest.raises(ops._lib.ScflowHipError):
+        ops.conv2d(ops.PackedConv.from_weight(wt, rnd((128,), 3).to(DEV), stride=2, padding=1), x, kslices=2)
+    with pytest.raises(ops._lib.ScflowHipError):
+        ops.conv2d(ops.PackedConv.from_weight(wt, None, stride=2, padding=1), x, kslices=2, act=ops.ACT_RELU)
+
+
+def test_pose_head_kslices_policy_and_parity(golden_dir):
+    """the pose head with its convolutions K-sliced (ops.conv_kslices) against the unsliced head: same features within
+    1e-5 relative, at batch 1 (4 slices per layer) and batch 32 (4 / 2 / 2)."""
+    import json, os, scflow_amd
+    shapes = json.load(open(os.path.join(golden_dir, 'state_dict_keys.json')))['shapes']
+    m = scflow_amd.build_refiner(scflow_amd.scflow_model_cfg())
+    m.load_state_dict(scflow_amd.fill_state_dict(shapes, seed=3), strict=True)
+    ph = m.to(DEV).decoder.pose_pred
+    for n in (1, 32):
+        x0, x1 = rnd((n, 128, 32, 32), 9).to(DEV), rnd((n, 96, 32, 32), 10).abs().to(DEV)
+        ks = [ops.conv_kslices(b.packed, n, hh, hh) for b, hh in zip(ph.conv_layers, (32, 16, 8))]
+        assert ks == ([4, 4, 4] if n == 1 else [4, 2, 2]), ks
+        ra, ta = ph.features(x0, x1)
+        prev = ops.set_conv_kslices(False)
+        try:
+            rb, tb = ph.features(x0, x1)
+        finally:
+            ops.set_conv_kslices(prev)
+        for a, b in ((ra, rb), (ta, tb)):
+            assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
