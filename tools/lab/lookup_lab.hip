@@ -3,17 +3,9 @@
 // Compiles the PRODUCT kernel source with SCF_LOOKUP_LAB (lookup_lab_hooks.h: s_memrealtime stamps per
 // wave + two ablation switches) and times it against streaming ceilings on a pyramid that cannot sit in the
 // 256 MiB Infinity Cache (two batch-B halves used alternately + a 1 GiB flush between launches).
-// -DLAB_V5: the round-1 kernel (corr_lookup_v5.inc, a snapshot of the file at commit 339ccd8) for A/B
-// timing and an output checksum on identical inputs (no trace hooks in that build).
 #include "../../scflow_amd/csrc/capi.hip"
-#ifdef LAB_V5
-#include "corr_lookup_v5.inc"
-static unsigned long long* scf_lab_trace = nullptr;
-static int scf_lab_skip_dma = 0, scf_lab_skip_store = 0, scf_lab_rotate = -1, scf_lab_grid = 0, scf_lab_store_mode = 0;
-#else
 #define SCF_LOOKUP_LAB 1
 #include "../../scflow_amd/csrc/corr_lookup.hip"
-#endif
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -270,10 +262,6 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
-#ifdef LAB_V5
-  run("v5 warm", 0, 0, false, false);
-  run("v5 cold", 0, 0, false, true);
-#else
   {
     const char* nm[5] = {"plain", "nt", "sc1", "sc0 sc1", "sc1 nt"};
     const int modes[3] = {0, 2, 1};
@@ -306,7 +294,6 @@ int main(int argc, char** argv) {
     if (nblk > 512) run("sc1 cold, grid 512", 0, 0, false, true, -1, 512);
     scf_lab_store_mode = 0;
   }
-#endif
   for (int pipe = 1; pipe <= 3; ++pipe) {   // checksum of the output of a full run (compare across kernel versions: same inputs)
     scf_lab_skip_dma = scf_lab_skip_store = 0; scf_lab_rotate = -1; scf_lab_grid = 0; scf_lab_trace = nullptr; scf_lab_pipe = pipe;
     CK(hipMemset(out, 0xff, Q * 324 * 4));
