@@ -775,8 +775,8 @@ extern "C" unsigned scf_corr_preferred_layout(int h, int w, int r, int L) {
   return mask;
 }
 
-// scf_tune(SCF_TUNE_LOOKUP_PIPE, v): 0 = the dispatch's own choice (pipelined kernel with two groups per
-// block where two such blocks fit a CU), 1 = v8 (one group per block), 2 / 3 = pipelined with that many groups
+// scf_tune(SCF_TUNE_LOOKUP_PIPE, v): 0 = the dispatch's own choice (= 1), 1 = one group per block, 2 / 3 = the
+// pipelined kernel with that many groups per block wherever it fits
 static std::atomic<int> g_lookup_pipe{0};
 int scf_lookup_pipe_set(int v) {
   if (v < 0 || v > 3) return SCF_EINVAL;
@@ -853,7 +853,9 @@ static int lookup_launch(const float* const* levels, const float* flow, float* o
   // ---- pipelined kernel: G groups per block, their G * L units dealt to the four waves by cost ----
   // (r = 4 and three or four levels -- every configuration the reference ships; anything else keeps v8)
   const int pipe_mode = LK_LAB_PIPE_MODE(g_lookup_pipe.load(std::memory_order_relaxed));
-  int G = pipe_mode == 0 ? 2 : pipe_mode >= 2 ? pipe_mode : 0;
+  // the dispatch's own choice (0) is the one-group kernel: the pipelined one is faster on a cache-resident pyramid
+  // only and 0.7-1.0 us slower inside the step at batch 8 / 16 / 32 (profiles/r5_lookup_inpipe_ab.txt)
+  const int G = pipe_mode >= 2 ? pipe_mode : 0;
   if (G && r == 4 && (L == 3 || L == 4) && ngroups >= 2 * G) {
     struct Unit { int gs, lvl, cost, fl; };
     Unit u[3 * 4];
@@ -892,7 +894,7 @@ static int lookup_launch(const float* const* levels, const float* flow, float* o
     int pper = fits ? (int)((160 * 1024) / (plds + 512)) : 0;
     pper = pper > 2 ? 2 : pper;
     // worth it only with at least two blocks (8 waves) per CU issuing gathers
-    if (fits && numax <= nu_k && pper >= (pipe_mode == 0 ? 2 : 1)) {
+    if (fits && numax <= nu_k && pper >= 1) {
       p.gpb = G;
       p.nsg = (int)scf_cdiv(ngroups, G);
       long long pblk = (long long)scf_cu_count() * pper;

@@ -630,7 +630,7 @@ class SCFlowDecoder(HipModule):
                                    invalid_flow_num, (ov_flow, ov_mask, ov_up))
         # occlusion mask of the previous iteration (ones before the first: the 1/8 bilinear
         # down-sampling of a ones map, :188-190), used only with mask_flow / mask_corr
-        mask = torch.ones((n, 1, h, w), **f32) if (self.mask_flow or self.mask_corr) else None
+        mask = ops.constant((n, 1, h, w), 1.0, dev) if (self.mask_flow or self.mask_corr) else None
         # scratch reused by every iteration (allocated once, before any fork point: the side branches
         # write into cf; z / rh are the GRU's gate buffers)
         cf = torch.empty((n, 256, h, w), **f32)
@@ -697,7 +697,7 @@ def _scflow_forward_c(self, pyramid, tiled, hx, ctx, rot0, trans0, depth, intern
     f1, c1, cf = E(n, 128, h, w), E(n, 256, h, w), E(n, 256, h, w)
     zbuf, heads, dm = E(2, n, hc, h, w), E(n, 512, h, w), E(n, 96, h, w)
     d_flow, mask, m1, d1 = E(n, 2, h, w), E(n, 1, h, w), E(n, 64, h, w), E(n, 128, h, w)
-    ones = torch.ones((n, 1, h, w), **f32) if (self.mask_flow or self.mask_corr) else None
+    ones = ops.constant((n, 1, h, w), 1.0, depth.device) if (self.mask_flow or self.mask_corr) else None
     hv, xm = hx[:, :hc], hx[:, hc + cc:]
     # ---- outputs of all iterations: one buffer per kind, a view per iteration ----
     flows, fpreds, masks = E(iters, n, 2, H, W), E(iters, n, 2, H, W), E(iters, n, 1, H, W)

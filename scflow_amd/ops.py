@@ -26,7 +26,7 @@ from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_GRU_Q, CONV_G
 Tensor = torch.Tensor
 
 __all__ = ['record_conv_kernels', 'PackedConv', 'conv_desc', 'gru_passes', 'scflow_iteration', 'side_stream_handle', 'pyramid_layout', 'untile_level', 'level_storage_shape', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision', 'set_conv_winograd', 'get_conv_winograd', 'pack_conv_weight_wino', 'pack_conv_weight_wino1d', 'pack_conv_weight_wino1d4',
-           'get_conv_precision', 'set_conv_kslices', 'conv_kslices', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
+           'get_conv_precision', 'set_conv_kslices', 'conv_kslices', 'constant', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
            'instance_norm', 'group_norm_relu', 'linear', 'fc_splitk', 'fc_slices', 'pose_update', 'reproject_flow',
            'unproject_depth', 'linear_pair', 'resize_bilinear', 'convex_upsample', 'avgpool2x2', 'copy_channels',
            'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_TANH', 'CONV_PLAIN', 'CONV_GRU_ZR',
@@ -570,6 +570,23 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
 
 
 _CONV_EVENTS = None
+
+# ---- read-only constant tensors (the all-zero initial flow, the all-ones first-iteration mask): filled ONCE per
+#      (device, shape, value) and handed out again -- a steady-state step then launches no fill kernel.  Kernels only
+#      READ them (init_flow feeds the first 1/8 down-sampling, the ones map the first mask multiply); callers that
+#      want to write must not ask here. ----
+_CONSTANTS = {}
+
+
+def constant(shape, value: float, device) -> Tensor:
+    key = (str(torch.device(device)), tuple(int(d) for d in shape), float(value))
+    t = _CONSTANTS.get(key)
+    if t is None:
+        if len(_CONSTANTS) > 64:
+            _CONSTANTS.clear()
+        t = _CONSTANTS[key] = torch.full(key[1], float(value), dtype=torch.float32, device=device)
+    return t
+
 
 # ---- K split across blocks for bias-free conv + GroupNorm blocks on small grids (the pose head's stride-2 layers) ----
 _CONV_KSLICES = True

@@ -107,7 +107,7 @@ class SCFlowRefiner(HipModule):
         feat_render, feat_real, h_feat, cxt_feat = self.extract_feat(render_images, real_images)
         if init_flow is None:
             n, _, H, W = real_images.shape
-            init_flow = torch.zeros((n, 2, H, W), dtype=torch.float32, device=feat_render.device)
+            init_flow = ops.constant((n, 2, H, W), 0.0, feat_render.device)      # read-only, filled once
         return self.decoder(feat_render, feat_real, h_feat, cxt_feat, ref_rotation,
                             ref_translation, depth.contiguous(), internel_k.contiguous(),
                             label=label, init_flow=init_flow, invalid_flow_num=0.,
@@ -179,7 +179,7 @@ class _FlowRefinerBase(HipModule):
         feat_render, feat_real, h_feat, cxt_feat = self.extract_feat(render_images, real_images)
         if init_flow is None:
             b, _, h, w = feat_real.shape
-            init_flow = torch.zeros((b, 2, h, w), dtype=torch.float32, device=feat_real.device)
+            init_flow = ops.constant((b, 2, h, w), 0.0, feat_real.device)
         return self.decoder(feat_render, feat_real, init_flow, h_feat, cxt_feat, _consume_state=True)
 
     def solve_pose(self, *a, **k):

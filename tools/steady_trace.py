@@ -1,0 +1,40 @@
+"""Steady-state kernel trace of the batch-N step: the launches of warm-up, weight packing and timer set-up stay out.
+    rocprofv3 --kernel-trace --stats --collection-period 40:2:1 --output-format csv -d OUT -o steady -- \
+        python tools/steady_trace.py [batch] [until_seconds=44]
+After set-up and 5 warm-up steps the script runs steps back to back until `until_seconds` after ITS OWN start, so a
+collection window that opens well after set-up (40 s: a cold `import torch` can take a minute on a fresh box -- the
+script then says so and the trace is void) sees nothing but steady-state steps.  The window cuts the first and last
+step somewhere, so per-kernel call counts are not exact multiples; shares and "is there any at::native row" are what
+VERDICT r4 item 7 asks to read."""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch
+
+import bench
+
+
+def main():
+    import time
+    t0 = time.time() - float(os.environ.get('STEADY_T0_OFFSET', '0'))
+    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    until = float(sys.argv[2]) if len(sys.argv) > 2 else 44.0
+    model, _ = bench.build_model(8, 'cuda')
+    d = bench.make_batch(batch, 1000, 'cuda')
+    for _ in range(5):
+        bench.run_step(model, d)
+    torch.cuda.synchronize()
+    ready = time.time() - t0
+    n = 0
+    while time.time() - t0 < until:
+        for _ in range(10):
+            bench.run_step(model, d)
+        torch.cuda.synchronize()
+        n += 10
+    print(f'ready after {ready:.1f} s; {n} steady steps at batch {batch} until {until:.0f} s'
+          + (' -- SET-UP OVERRAN THE WINDOW START: trace void' if ready > until - 6 else ''))
+
+
+if __name__ == '__main__':
+    main()
