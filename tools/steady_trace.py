@@ -27,11 +27,17 @@ def main():
     torch.cuda.synchronize()
     ready = time.time() - t0
     n = 0
+    timers = os.environ.get('STEADY_TIMERS')          # A/B: does a launch-bound timer change the launch it measures?
+    if timers:
+        from scflow_amd import ops
+        ops.lookup_timing(True, reserve=8 * 10)
     while time.time() - t0 < until:
         for _ in range(10):
             bench.run_step(model, d)
         torch.cuda.synchronize()
         n += 10
+        if timers:
+            ops.lookup_timing_reset()
     print(f'ready after {ready:.1f} s; {n} steady steps at batch {batch} until {until:.0f} s'
           + (' -- SET-UP OVERRAN THE WINDOW START: trace void' if ready > until - 6 else ''))
 
