@@ -5,17 +5,21 @@
 // ALUs straight from NCHW:
 //   block = 32 output columns x PY output rows x NCG = 16 channel groups (512 threads);
 //   lane <-> column (128-byte coalesced rows), thread = PY vertically adjacent pixels of one
-//   channel group (c = cg, cg+NCG, ...): (K+PY-1)*K loads feed PY*K*K*Cout FMAs per channel,
-//   eight channels' loads in flight per thread: a block's run time is a chain of dependent
-//   memory round trips (22 us per launch with 8 groups x 4 in flight, whatever the batch), so
-//   the channel loop is made as short as the register file allows;
+//   channel group (c = cg, cg+NCG, ...): K = 3 loads the centre column of each of the K+PY-1 window rows and
+//   takes the neighbours from the adjacent lanes (DPP whole-wave shifts, r5), K = 1 loads what it uses; a
+//   block's run time is a chain of dependent memory round trips (22 us per launch with 8 groups x 4 loads in
+//   flight, whatever the batch), so the channel loop keeps as many channels in flight as registers allow;
 //   weights are staged once per block in LDS and read as wave-uniform broadcasts;
 //   the NCG partial sums per pixel are combined through LDS in a fixed order.
 #include "scf_common.h"
 #include "conv_kernels.h"
+#include <type_traits>
 
 #define SCF_THIN_NCG 16
-template <int K, int CO>
+// UNROLL (K = 3): channels whose loads are in flight together per thread -- 2 on full grids (126 registers: two
+// blocks per CU; 18.7 -> 13.4 us at batch 32), 4 on grids of at most one block per CU (a lone block is a chain of
+// memory round trips: 15.2 -> 7.6 us at batch 1; 16.2 us at batch 32)
+template <int K, int CO, int UNROLL = 2>
 __global__ __launch_bounds__(32 * SCF_THIN_NCG) void conv_thin_kernel(ConvK p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int PY = 2;                        // output rows per thread
@@ -56,6 +60,76 @@ __global__ __launch_bounds__(32 * SCF_THIN_NCG) void conv_thin_kernel(ConvK p) {
     for (int co = 0; co < CO; ++co) acc[py][co] = 0.f;
 
   const float* xin = p.in0 + (long long)n * p.in0_ns;
+  if constexpr (K == 3) {
+    // r5: ONE load per window row and channel (the centre column); the left / right neighbours come from the
+    // adjacent lanes by whole-wave DPP shifts (lane = column; the two 32-lane halves of a wave are two channel
+    // groups, so lanes 0 / 32 and 31 / 63 take their neighbour -- the adjacent tile's column, or zero padding --
+    // from memory: no lane executes those loads when the map is one tile wide).  A third of the load
+    // instructions (6 -> 2 per output pixel and channel), so all 16 channels of a group's share are in flight at
+    // once: the block is one memory round trip instead of two.
+    const bool edge_l = col == 0, edge_r = col == 31;
+    int offc[NR];
+    bool okc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { offc[r] = off[r][1]; okc[r] = ok[r][1]; }
+    // EDGES = false: the map is one tile wide, a tile's outer neighbours are zero padding (no load at all: the
+    // loop body is branch-free and unrolls over all of a thread's channels)
+    auto run = [&](auto edges_tag) {
+      constexpr bool EDGES = decltype(edges_tag)::value;
+      // trips of UN channels with a compile-time count (the DPP shifts are convergent operations: a loop with a
+      // run-time trip count is not unrolled around them); a channel past Cin re-reads channel cg with zero data
+      constexpr int UN = UNROLL;
+      for (int c0 = cg; c0 < p.Cin; c0 += UN * NCG) {
+        float t[UN][NR];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int c = c0 + u * NCG;
+          const float* xc = xin + (long long)(c < p.Cin ? c : cg) * HW;
+#pragma unroll
+          for (int r = 0; r < NR; ++r) t[u][r] = xc[offc[r]];
+        }
+        __builtin_amdgcn_sched_barrier(0);        // all UN x NR loads are in flight before the first one is used ...
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int c = c0 + u * NCG;
+          const bool cok = c < p.Cin;
+          const float* xc = xin + (long long)(cok ? c : cg) * HW;
+          float v[NR][K];
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            v[r][1] = (okc[r] && cok) ? t[u][r] : 0.f;
+            // wave_shr:1 (lane i <- lane i - 1, lane 0 <- 0), wave_shl:1 (lane i <- lane i + 1, lane 63 <- 0)
+            const int ci = __float_as_int(v[r][1]);
+            float l = __int_as_float(__builtin_amdgcn_update_dpp(0, ci, 0x138, 0xf, 0xf, true));
+            float rr = __int_as_float(__builtin_amdgcn_update_dpp(0, ci, 0x130, 0xf, 0xf, true));
+            if constexpr (EDGES) {
+              if (edge_l) l = (ok[r][0] && cok) ? xc[off[r][0]] : 0.f;
+              if (edge_r) rr = (ok[r][2] && cok) ? xc[off[r][2]] : 0.f;
+            } else {
+              l = edge_l ? 0.f : l;
+              rr = edge_r ? 0.f : rr;
+            }
+            v[r][0] = l;
+            v[r][2] = rr;
+          }
+          const float* wc = wl + (cok ? c : cg) * T * CO;
+#pragma unroll
+          for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+              for (int co = 0; co < CO; ++co) {
+                const float w = wc[(ky * K + kx) * CO + co];
+#pragma unroll
+                for (int py = 0; py < PY; ++py) acc[py][co] += v[py + ky][kx] * w;
+              }
+          __builtin_amdgcn_sched_barrier(0);      // ... and one channel's weights / shifts at a time (registers)
+        }
+      }
+    };
+    if (p.tiles_x == 1) run(std::false_type{});
+    else run(std::true_type{});
+  } else {
 #pragma unroll 8
   for (int c = cg; c < p.Cin; c += NCG) {
     const float* xc = xin + (long long)c * HW;
@@ -78,6 +152,7 @@ __global__ __launch_bounds__(32 * SCF_THIN_NCG) void conv_thin_kernel(ConvK p) {
 #pragma unroll
           for (int py = 0; py < PY; ++py) acc[py][co] += v[py + ky][kx] * w;
         }
+  }
   }
 
   // ---- combine the channel groups (fixed order), bias, activation, store ----
@@ -105,7 +180,10 @@ __global__ __launch_bounds__(32 * SCF_THIN_NCG) void conv_thin_kernel(ConvK p) {
 
 template <int K, int CO>
 static int launch_thin(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
-  scf_launch((conv_thin_kernel<K, CO>), dim3(nblk), dim3(32 * SCF_THIN_NCG), lds_bytes, st, k);
+  if (K == 3 && nblk <= scf_cu_count())
+    scf_launch((conv_thin_kernel<K, CO, 4>), dim3(nblk), dim3(32 * SCF_THIN_NCG), lds_bytes, st, k);
+  else
+    scf_launch((conv_thin_kernel<K, CO, 2>), dim3(nblk), dim3(32 * SCF_THIN_NCG), lds_bytes, st, k);
   return scf_launch_status();
 }
 

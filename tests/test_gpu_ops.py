@@ -698,6 +698,11 @@ def test_conv2d_thin_output(cout, k):
     xs = rnd((2, cin, 12, 20), 53)                              # ragged tile
     pc = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), padding=k // 2)
     close(ops.conv2d(pc, xs.to(DEV)), F.conv2d(xs, wt, b, padding=k // 2), atol=2e-5, what='thin ragged')
+    # maps wider than one 32-column tile (the 3x3 kernel takes a tile's edge columns from memory, the inner ones from
+    # the neighbouring lanes): 60 x 80 (configs[4]), an odd width with a ragged last tile, one column
+    for hh, ww in ((60, 80), (9, 67), (5, 33), (4, 1)):
+        xw = rnd((2, cin, hh, ww), 54 + ww)
+        close(ops.conv2d(pc, xw.to(DEV)), F.conv2d(xw, wt, b, padding=k // 2), atol=2e-5, what=f'thin {hh}x{ww}')
 
 
 def test_conv2d_two_segments_into_channel_slice():
