@@ -66,8 +66,9 @@ enum {
                                  2: F(4, 5) on every grid it supports (tests of small ragged shapes) */
   SCF_TUNE_LOOKUP_STORE = 6,  /* correlation lookup (r = 4, one group per block): cache policy of the output stores, 0 = the build's,
                                  1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt, 5 plain */
-  SCF_TUNE_LOOKUP_PIPE = 5    /* correlation lookup: 0 = the dispatch's own choice, 1 = one group per block (the r3 kernel),
-                                 2 / 3 = the pipelined kernel with two / three groups per block wherever it fits */
+  SCF_TUNE_LOOKUP_PIPE = 5    /* correlation lookup: 0 = the dispatch's own choice, 1 = one group of 32 queries per block (the r3
+                                 kernel), 2 / 3 = the pipelined kernel with two / three groups per block wherever it fits,
+                                 4 / 5 = two / four groups per 512- / 1024-thread block (same waves, fewer workgroups) */
 };
 int scf_tune(int key, int value);
 int scf_conv_log_read(scf_conv_log_entry* out, int max_entries);

@@ -258,8 +258,10 @@ __device__ __forceinline__ void lookup_emit(const lds_cfp_t (&rowp)[2 * R + 2], 
   }
 }
 
-template <int R, int SM>
-__global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
+// GPB = groups per block: 2 = the same waves in half as many workgroups (the four waves of a group never
+// synchronise with the other group's; A/B knob lookup_pipe = 4)
+template <int R, int SM, int GPB = 1>
+__global__ __launch_bounds__(256 * GPB, 4 / GPB) void corr_lookup_kernel(LookupParams p) {
   constexpr int FW = 2 * R + 2;       // footprint width
   constexpr int FS = FW * FW;         // footprint size
   constexpr int FSP = FS | 1;         // odd LDS stride per query (conflict-free lane = query reads)
@@ -273,12 +275,13 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
 
   const bool skip_dma = LK_SKIP_DMA, skip_store = LK_SKIP_STORE;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
+  const int wave = wave_all & 3, gsel = GPB == 1 ? 0 : wave_all >> 2;
   const int l32 = lane & 31, half = lane >> 5;                // query within the group, half-wave
   const int hw = p.h * p.w;
   const int ktot = p.L * D * D;
   const size_t cs = (size_t)hw * 4;   // channel stride in bytes
-  const lds_fp_t myfp = (lds_fp_t)lds_fp + p.woff[wave];
+  const lds_fp_t myfp = (lds_fp_t)lds_fp + gsel * p.nsg + p.woff[wave];      // (GPB > 1: p.nsg = LDS floats per group)
 
   // gather-lane roles: this lane fetches footprint elements e = lane + 64 s of EVERY query
   const lds_u16p_t tbl = (lds_u16p_t)(myfp + QB * FSP);   // [QB][TQ]
@@ -304,12 +307,13 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
       fy_ = fl[hw];
     }
   };
-  int g = blockIdx.x;
+  const int gstep = (int)gridDim.x * GPB;
+  int g = (int)blockIdx.x * GPB + gsel;
   float fx = 0.f, fy = 0.f;
   LK_LAB_STAGGER;
   if (g < p.ngroups) flow_of(g, fx, fy);       // issued before any setup
 
-  for (; g < p.ngroups; g += gridDim.x) {
+  for (; g < p.ngroups; g += gstep) {
     LK_TRACE(0);
     const unsigned gq0 = (unsigned)g * QB;
     const int n0 = (int)(gq0 / (unsigned)hw);     // sample of the group's first query (wave-uniform)
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
     // byte offset of this lane's query from the group-uniform base out[n0, k, 0, 0]
     const unsigned lane_off = ((unsigned)(n - n0) * (unsigned)(ktot * hw) + (unsigned)q) * 4u;
     const int nq = (int)((total_q - gq0) < (unsigned)QB ? (total_q - gq0) : (unsigned)QB);   // wave-uniform
-    const bool more = g + (int)gridDim.x < p.ngroups;
+    const bool more = g + gstep < p.ngroups;
     float fxn = 0.f, fyn = 0.f;
 
     for (int lvl = wave; lvl < p.L; lvl += 4) {
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(256, 4) void corr_lookup_kernel(LookupParams p) {
       }
       LK_TRACE(3);
       // flow of this block's next group: issued behind the gathers, consumed after the stores
-      if (more && lvl + 4 >= p.L) flow_of(g + (int)gridDim.x, fxn, fyn);
+      if (more && lvl + 4 >= p.L) flow_of(g + gstep, fxn, fyn);
 
       // ---- lane = (query, half); halves split the x-offsets ----
       char* obase = (char*)p.out + ((size_t)n0 * ktot + (size_t)lvl * D * D) * cs;
@@ -775,11 +779,12 @@ extern "C" unsigned scf_corr_preferred_layout(int h, int w, int r, int L) {
   return mask;
 }
 
-// scf_tune(SCF_TUNE_LOOKUP_PIPE, v): 0 = the dispatch's own choice (= 1), 1 = one group per block, 2 / 3 = the
-// pipelined kernel with that many groups per block wherever it fits
+// scf_tune(SCF_TUNE_LOOKUP_PIPE, v): 0 = the dispatch's own choice, 1 = one group per block, 2 / 3 = the pipelined
+// kernel with that many groups per block wherever it fits, 4 / 5 = two / four groups per block (the same waves in
+// fewer workgroups)
 static std::atomic<int> g_lookup_pipe{0};
 int scf_lookup_pipe_set(int v) {
-  if (v < 0 || v > 3) return SCF_EINVAL;
+  if (v < 0 || v > 5) return SCF_EINVAL;
   return g_lookup_pipe.exchange(v);
 }
 
@@ -855,7 +860,7 @@ static int lookup_launch(const float* const* levels, const float* flow, float* o
   const int pipe_mode = LK_LAB_PIPE_MODE(g_lookup_pipe.load(std::memory_order_relaxed));
   // the dispatch's own choice (0) is the one-group kernel: the pipelined one is faster on a cache-resident pyramid
   // only and 0.7-1.0 us slower inside the step at batch 8 / 16 / 32 (profiles/r5_lookup_inpipe_ab.txt)
-  const int G = pipe_mode >= 2 ? pipe_mode : 0;
+  const int G = (pipe_mode == 2 || pipe_mode == 3) ? pipe_mode : 0;
   if (G && r == 4 && (L == 3 || L == 4) && ngroups >= 2 * G) {
     struct Unit { int gs, lvl, cost, fl; };
     Unit u[3 * 4];
@@ -917,6 +922,35 @@ static int lookup_launch(const float* const* levels, const float* flow, float* o
     }
   }
   p.gpb = 1; p.nsg = p.ngroups;
+  // several groups per block: the same waves in fewer workgroups (the head of this kernel is the workgroup dispatch:
+  // 1024 blocks enter over 2.0 us, 512 over 1.3).  Mode 4 / 5 = two / four groups per block of 512 / 1024 threads.
+  // The dispatch's own choice (mode 0): four groups per block when that still fills every CU (>= 4 x CUs groups of
+  // four-per-CU blocks: batch 32 at 256 x 256), measured in the step at batch 32 / 16 / 8 (profiles/r5_lookup_inpipe_ab.txt):
+  // 20.2 -> 19.4 us at batch 32; at batch 16 / 8 one group per block stays (12.7 vs 16.0, 9.9 vs 15.0 us).
+  int gpb = pipe_mode == 4 ? 2 : pipe_mode == 5 ? 4 : 1;
+  if (pipe_mode == 0 && per_cu == 4 && ngroups >= 4LL * scf_cu_count()) gpb = 4;
+  if (gpb > 1 && r == 4 && (size_t)gpb * lds + 512 <= 160 * 1024 && ngroups >= gpb) {
+    const size_t ldsg = (size_t)gpb * lds;
+    p.nsg = (int)(lds / sizeof(float));
+    int perg = (int)((160 * 1024) / (ldsg + 512));
+    perg = perg > 4 / gpb ? 4 / gpb : perg < 1 ? 1 : perg;
+    long long nbg = (long long)scf_cu_count() * perg;
+    if (nbg > scf_cdiv(ngroups, gpb)) nbg = scf_cdiv(ngroups, gpb);
+    LK_LAB_SETUP(p, nbg);
+    int rc = SCF_OK;
+    if (gpb == 2) {
+      static std::atomic<unsigned long long> done{0};
+      if (ldsg > 64 * 1024) rc = scf_raise_dynamic_lds(done, (const void*)corr_lookup_kernel<4, SCF_LOOKUP_STORE_MODE, 2>, (int)ldsg);
+      if (rc != SCF_OK) return rc;
+      scf_launch((corr_lookup_kernel<4, SCF_LOOKUP_STORE_MODE, 2>), dim3((unsigned)nbg), dim3(512), ldsg, scf_stream(stream), p);
+    } else {
+      static std::atomic<unsigned long long> done{0};
+      if (ldsg > 64 * 1024) rc = scf_raise_dynamic_lds(done, (const void*)corr_lookup_kernel<4, SCF_LOOKUP_STORE_MODE, 4>, (int)ldsg);
+      if (rc != SCF_OK) return rc;
+      scf_launch((corr_lookup_kernel<4, SCF_LOOKUP_STORE_MODE, 4>), dim3((unsigned)nbg), dim3(1024), ldsg, scf_stream(stream), p);
+    }
+    return scf_launch_status();
+  }
   LK_LAB_LAUNCH(p, nblk);
 #define SCF_LK(R_)                                                                                 \
   case R_:                                                                                         \

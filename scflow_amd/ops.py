@@ -736,7 +736,7 @@ def tune(key: str, value: int) -> int:
     ``'wino_variant'``: 0 = the dispatch's choice, 1 = pair kernel, 2 / 3 = quarter-domain kernel (4 / 8 waves);
     ``'wino1d4'``: 1 = F(4, 5) where the dispatch prefers it (default), 0 = never, 2 = on every grid it supports;
     ``'lookup_pipe'``: 0 = the dispatch's choice, 1 = one group per block (r3 kernel), 2 / 3 = pipelined kernel with
-    that many groups per block.  Unknown keys raise ``ValueError``; a value the library refuses raises
+    that many groups per block, 4 / 5 = two / four groups per block (same waves, fewer workgroups).  Unknown keys raise ``ValueError``; a value the library refuses raises
     ``RuntimeError`` (the return value is always a previous setting, never an error code)."""
     if key not in TUNE_KEYS:
         raise ValueError(f'unknown tune key {key!r}; known: {sorted(TUNE_KEYS)}')

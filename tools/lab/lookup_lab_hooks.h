@@ -16,7 +16,7 @@ static int scf_lab_pipe = -1;     // -1: the library's own choice; else the SCF_
 #define LK_TRACE(slot)                                                                             \
   do {                                                                                             \
     if (p.trace && (threadIdx.x & 63) == 0)                                                        \
-      p.trace[((size_t)g * 4 + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+      p.trace[((size_t)g * 4 + ((threadIdx.x >> 6) & 3)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 
 // after the emit of one (wave, level): emitted, stores acknowledged, (level, HW_ID)
