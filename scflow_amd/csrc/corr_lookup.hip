@@ -261,7 +261,7 @@ __device__ __forceinline__ void lookup_emit(const lds_cfp_t (&rowp)[2 * R + 2], 
 // GPB = groups per block: 2 = the same waves in half as many workgroups (the four waves of a group never
 // synchronise with the other group's; A/B knob lookup_pipe = 4)
 template <int R, int SM, int GPB = 1>
-__global__ __launch_bounds__(256 * GPB, 4 / GPB) void corr_lookup_kernel(LookupParams p) {
+__global__ __launch_bounds__(256 * GPB, GPB == 3 ? 1 : 4 / GPB) void corr_lookup_kernel(LookupParams p) {
   constexpr int FW = 2 * R + 2;       // footprint width
   constexpr int FS = FW * FW;         // footprint size
   constexpr int FSP = FS | 1;         // odd LDS stride per query (conflict-free lane = query reads)
@@ -784,7 +784,7 @@ extern "C" unsigned scf_corr_preferred_layout(int h, int w, int r, int L) {
 // fewer workgroups)
 static std::atomic<int> g_lookup_pipe{0};
 int scf_lookup_pipe_set(int v) {
-  if (v < 0 || v > 5) return SCF_EINVAL;
+  if (v < 0 || v > 6) return SCF_EINVAL;
   return g_lookup_pipe.exchange(v);
 }
 
@@ -927,7 +927,10 @@ static int lookup_launch(const float* const* levels, const float* flow, float* o
   // The dispatch's own choice (mode 0): four groups per block when that still fills every CU (>= 4 x CUs groups of
   // four-per-CU blocks: batch 32 at 256 x 256), measured in the step at batch 32 / 16 / 8 (profiles/r5_lookup_inpipe_ab.txt):
   // 20.2 -> 19.4 us at batch 32; at batch 16 / 8 one group per block stays (12.7 vs 16.0, 9.9 vs 15.0 us).
-  int gpb = pipe_mode == 4 ? 2 : pipe_mode == 5 ? 4 : 1;
+  int gpb = pipe_mode == 4 ? 2 : pipe_mode == 5 ? 4 : pipe_mode == 6 ? 3 : 1;
+  // own choice: four groups per block where four one-group blocks fit a CU and the grid still fills every CU; maps
+  // with three blocks per CU (configs[4]: 1200 groups on 768 slots) lose with three-group blocks (30.3 -> 32.6 us:
+  // the 1.56 rounds are then made of three times coarser pieces)
   if (pipe_mode == 0 && per_cu == 4 && ngroups >= 4LL * scf_cu_count()) gpb = 4;
   if (gpb > 1 && r == 4 && (size_t)gpb * lds + 512 <= 160 * 1024 && ngroups >= gpb) {
     const size_t ldsg = (size_t)gpb * lds;
@@ -937,19 +940,18 @@ static int lookup_launch(const float* const* levels, const float* flow, float* o
     long long nbg = (long long)scf_cu_count() * perg;
     if (nbg > scf_cdiv(ngroups, gpb)) nbg = scf_cdiv(ngroups, gpb);
     LK_LAB_SETUP(p, nbg);
-    int rc = SCF_OK;
-    if (gpb == 2) {
-      static std::atomic<unsigned long long> done{0};
-      if (ldsg > 64 * 1024) rc = scf_raise_dynamic_lds(done, (const void*)corr_lookup_kernel<4, SCF_LOOKUP_STORE_MODE, 2>, (int)ldsg);
-      if (rc != SCF_OK) return rc;
-      scf_launch((corr_lookup_kernel<4, SCF_LOOKUP_STORE_MODE, 2>), dim3((unsigned)nbg), dim3(512), ldsg, scf_stream(stream), p);
-    } else {
-      static std::atomic<unsigned long long> done{0};
-      if (ldsg > 64 * 1024) rc = scf_raise_dynamic_lds(done, (const void*)corr_lookup_kernel<4, SCF_LOOKUP_STORE_MODE, 4>, (int)ldsg);
-      if (rc != SCF_OK) return rc;
-      scf_launch((corr_lookup_kernel<4, SCF_LOOKUP_STORE_MODE, 4>), dim3((unsigned)nbg), dim3(1024), ldsg, scf_stream(stream), p);
+#define SCF_LKG(G_)                                                                                                   \
+    case G_: {                                                                                                        \
+      static std::atomic<unsigned long long> done{0};                                                                 \
+      if (ldsg > 64 * 1024) {                                                                                         \
+        const int rc = scf_raise_dynamic_lds(done, (const void*)corr_lookup_kernel<4, SCF_LOOKUP_STORE_MODE, G_>, (int)ldsg); \
+        if (rc != SCF_OK) return rc;                                                                                  \
+      }                                                                                                               \
+      scf_launch((corr_lookup_kernel<4, SCF_LOOKUP_STORE_MODE, G_>), dim3((unsigned)nbg), dim3(256 * G_), ldsg, scf_stream(stream), p); \
+      return scf_launch_status();                                                                                     \
     }
-    return scf_launch_status();
+    switch (gpb) { SCF_LKG(2) SCF_LKG(3) SCF_LKG(4) default: break; }
+#undef SCF_LKG
   }
   LK_LAB_LAUNCH(p, nblk);
 #define SCF_LK(R_)                                                                                 \

@@ -65,7 +65,7 @@ def test_tune_knobs_validate_their_values():
         assert ops.tune('wino1d4', 1) == 2
         assert ops.tune('wino_variant', 0) == 0
         # the lookup knobs (r5): pipelined variant 0..3, store policy 0..5
-        assert lib.scf_tune(ops.TUNE_KEYS['lookup_pipe'], 6) < 0 and lib.scf_tune(ops.TUNE_KEYS['lookup_store'], 6) < 0
+        assert lib.scf_tune(ops.TUNE_KEYS['lookup_pipe'], 7) < 0 and lib.scf_tune(ops.TUNE_KEYS['lookup_store'], 6) < 0
         assert ops.tune('lookup_pipe', 2) == 0 and ops.tune('lookup_pipe', 0) == 2
         assert ops.tune('lookup_store', 4) == 0 and ops.tune('lookup_store', 0) == 4
         # ops.tune never hands an error code back as a "previous value"
