@@ -63,25 +63,21 @@ if calib_f and calib_w:
     fetch_factor = calibration['calib_dma<4, 1, 1>']['requested_per_reported']
     write_factor = calibration['calib_store<1>']['written_per_reported']
 
-f = per_kernel(fetch_csv, 'FETCH_SIZE')
-w = per_kernel(write_csv, 'WRITE_SIZE')
-lk = [k for k in f if 'corr_lookup' in k][0]
+# every lookup dispatch of the run, whatever instantiation took it (r5: the batch-32 launches run four groups per
+# 1024-thread block, configs[4] one group per 256-thread block).  The two workloads are told apart by the launch's
+# TOTAL thread count: 32 x 1024 queries x 4 waves x 64 lanes / 32 = 262144 at batch 32 (1024 x 256 or 256 x 1024).
+MAIN_THREADS = 262144
 
 
-fv, wv = f[lk], w[lk]
-# launches of the main workload come first (8 per step); the configs[4] block follows (12 per step)
-def main_and_c4(vals, grids):
-    main = [v for v, g in zip(vals, grids) if g == 1024]
-    c4 = [v for v, g in zip(vals, grids) if g != 1024]
-    return main, c4
+def lookup_rows(path, counter):
+    return [(float(r['Counter_Value']), int(r['Grid_Size']), re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', ''))
+            for r in rows(path, counter) if 'corr_lookup' in r['Kernel_Name']]
 
 
-def grids_of(path, counter):
-    return [int(r['Grid_Size']) // int(r['Workgroup_Size']) for r in rows(path, counter) if 'corr_lookup' in r['Kernel_Name']]
-
-
-fm, f4 = main_and_c4(fv, grids_of(fetch_csv, 'FETCH_SIZE'))
-wm, w4 = main_and_c4(wv, grids_of(write_csv, 'WRITE_SIZE'))
+fr, wr = lookup_rows(fetch_csv, 'FETCH_SIZE'), lookup_rows(write_csv, 'WRITE_SIZE')
+fm, f4 = [v for v, g, _ in fr if g == MAIN_THREADS], [v for v, g, _ in fr if g != MAIN_THREADS]
+wm, w4 = [v for v, g, _ in wr if g == MAIN_THREADS], [v for v, g, _ in wr if g != MAIN_THREADS]
+lk = sorted({n for _, g, n in fr if g == MAIN_THREADS})[0]
 fetch = sum(fm) / len(fm) * 1024 * fetch_factor
 write = sum(wm) / len(wm) * 1024 * write_factor
 out = {
@@ -106,15 +102,15 @@ if stats_csv:
     # ones by grid size) or a --stats summary CSV
     rd = list(csv.DictReader(open(stats_csv)))
     if rd and 'Start_Timestamp' in rd[0]:
-        nblk = lambda r: int(r['Grid_Size_X']) // int(r['Workgroup_Size_X'])
+        nthr = lambda r: int(r['Grid_Size_X'])
         d32 = [(float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e3 for r in rd
-               if 'corr_lookup' in r['Kernel_Name'] and nblk(r) == 1024]
+               if 'corr_lookup' in r['Kernel_Name'] and nthr(r) == MAIN_THREADS]
         d4 = [(float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e3 for r in rd
-              if 'corr_lookup' in r['Kernel_Name'] and nblk(r) != 1024]
+              if 'corr_lookup' in r['Kernel_Name'] and nthr(r) != MAIN_THREADS]
         if d32:
             out['rocprof_kernel_trace'] = {'calls': len(d32), 'avg_us': round(sum(d32) / len(d32), 2),
                                            'min_us': round(min(d32), 2), 'max_us': round(max(d32), 2),
-                                           'note': 'batch-32 launches (grid 1024) of the traced bench.py run'}
+                                           'note': 'batch-32 launches (262144 threads) of the traced bench.py run'}
         if d4 and 'config4' in out:
             out['config4']['rocprof_kernel_trace'] = {'calls': len(d4), 'avg_us': round(sum(d4) / len(d4), 2),
                                                       'min_us': round(min(d4), 2), 'max_us': round(max(d4), 2)}
