@@ -74,7 +74,13 @@ extern "C" int scf_resize_bilinear(const float* a, const float* b, float* out, i
   if (planes > 0x7fffffffLL) return SCF_EINVAL;
   const float sh = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
   const float sw = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
-  const dim3 grid((unsigned)scf_cdiv(Wout, 256), (unsigned)scf_cdiv(Hout, 4), (unsigned)(planes < 65535 ? planes : 65535));
+  // about four workgroups per CU, each walking several planes: the x8 flow up-sampling of a batch of 32 was 4096
+  // workgroups of one plane-row-group each -- a launch the workgroup dispatcher (~1.4 ns per workgroup), not the
+  // memory system, paced (r5: 8.8 -> see DESIGN)
+  const long long gxy = scf_cdiv(Wout, 256) * scf_cdiv(Hout, 4);
+  long long gz = (4LL * scf_cu_count() + gxy - 1) / gxy;
+  gz = gz < 1 ? 1 : gz > planes ? planes : gz > 65535 ? 65535 : gz;
+  const dim3 grid((unsigned)scf_cdiv(Wout, 256), (unsigned)scf_cdiv(Hout, 4), (unsigned)gz);
   if (grid.y > 65535u) return SCF_EUNSUPPORTED;
   if ((Wout & 3) == 0 && ((uintptr_t)out & 15) == 0)
     scf_launch(resize_bilinear_kernel<true>, grid, dim3(256), 0, scf_stream(stream), a, b,
@@ -180,24 +186,43 @@ extern "C" int scf_mul_mask(const float* x, int64_t x_nstride, const float* mask
   return scf_launch_status();
 }
 
+// VEC: count, both sample strides and both base pointers are multiples of 4 floats: 16 bytes per lane.  The grid is a
+// few workgroups per CU walking the tensor with a grid stride (one workgroup per 256 elements was tens of thousands of
+// workgroups for the stacked encoder input: the dispatcher, not the memory system, paced the launch).
+template <bool VEC>
 __global__ __launch_bounds__(256) void copy_strided_kernel(const float* __restrict__ src,
                                                            long long sns, float* __restrict__ dst,
                                                            long long dns, int N, long long count) {
-  const long long total = (long long)N * count;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const long long n = idx / count, r = idx - n * count;
-    dst[n * dns + r] = src[n * sns + r];
+  if (VEC) {
+    const long long c4 = count >> 2, total = (long long)N * c4;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+      const long long n = idx / c4, r = idx - n * c4;
+      reinterpret_cast<float4*>(dst + n * dns)[r] = reinterpret_cast<const float4*>(src + n * sns)[r];
+    }
+  } else {
+    const long long total = (long long)N * count;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+      const long long n = idx / count, r = idx - n * count;
+      dst[n * dns + r] = src[n * sns + r];
+    }
   }
 }
 
 extern "C" int scf_copy_strided(const float* src, int64_t src_nstride, float* dst,
                                 int64_t dst_nstride, int N, int64_t count, scf_stream_t stream) {
   if (!src || !dst || N <= 0 || count <= 0) return SCF_EINVAL;
-  const long long total = (long long)N * count;
-  const int grid = (int)(scf_cdiv(total, 256) < 262144 ? scf_cdiv(total, 256) : 262144);
-  scf_launch(copy_strided_kernel, dim3(grid), dim3(256), 0, scf_stream(stream), src,
-                     (long long)src_nstride, dst, (long long)dst_nstride, N, (long long)count);
+  const bool vec = ((count | src_nstride | dst_nstride) & 3) == 0 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
+  const long long units = (long long)N * (vec ? count >> 2 : count);
+  const long long cap = 8LL * scf_cu_count();
+  const int grid = (int)(scf_cdiv(units, 256) < cap ? scf_cdiv(units, 256) : cap);
+  if (vec)
+    scf_launch(copy_strided_kernel<true>, dim3(grid), dim3(256), 0, scf_stream(stream), src, (long long)src_nstride, dst,
+               (long long)dst_nstride, N, (long long)count);
+  else
+    scf_launch(copy_strided_kernel<false>, dim3(grid), dim3(256), 0, scf_stream(stream), src, (long long)src_nstride, dst,
+               (long long)dst_nstride, N, (long long)count);
   return scf_launch_status();
 }
 
