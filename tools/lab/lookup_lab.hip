@@ -259,6 +259,10 @@ int main(int argc, char** argv) {
       scf_lab_stagger = 0;
       run("v9 pipe G=2 warm", 0, 0, false, false, -1, 0, 2);
       run("v9 pipe G=2 cold", 0, 0, tr && rep, true, -1, 0, 2);
+      run("v8, 2 groups per block, warm", 0, 0, false, false, -1, 0, 4);
+      run("v8, 2 groups per block, cold", 0, 0, tr && rep, true, -1, 0, 4);
+      run("v8, 4 groups per block, warm", 0, 0, false, false, -1, 0, 5);
+      run("v8, 4 groups per block, cold", 0, 0, tr && rep, true, -1, 0, 5);
     }
     return 0;
   }
