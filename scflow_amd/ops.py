@@ -92,12 +92,14 @@ _SIDE = {}      # (device, main stream handle) -> that stream's side stream
 
 
 OVERLAP_BRANCHES = {'context', 'flow', 'mask', 'upsample'}      # tools/lab switches these off one by one
+OVERLAP_MAX_PIXELS = {'context': 4 * 256 * 256, 'flow': 4 * 256 * 256, 'mask': 4 * 256 * 256, 'upsample': 4 * 256 * 256}
 
 
 def small_work(n: int, h: int, w: int, branch: Optional[str] = None) -> bool:
     """whether a batch of n (h, w) images is small enough for branch-level concurrency to pay
     (``branch``: and that branch is enabled)."""
-    return n * h * w <= 4 * 256 * 256 and (branch is None or branch in OVERLAP_BRANCHES)
+    lim = OVERLAP_MAX_PIXELS.get(branch, 4 * 256 * 256)
+    return n * h * w <= lim and (branch is None or branch in OVERLAP_BRANCHES)
 
 
 def fork_point() -> 'torch.cuda.Event':
