@@ -1308,3 +1308,24 @@ def test_pose_head_kslices_policy_and_parity(golden_dir):
             ops.set_conv_kslices(prev)
         for a, b in ((ra, rb), (ta, tb)):
             assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_corr_lookup_groups_per_block_are_bit_identical():
+    """r5: at >= 4 x CUs groups the dispatch packs four groups of 32 queries into one 1024-thread block (the same waves in a
+    quarter of the workgroups); every packing behind the knob (one / two / four groups per block, the pipelined variants)
+    returns the same bits as the one-group kernel, on both pyramid layouts, incl. a ragged last group."""
+    for (n, h, w) in ((32, 32, 32), (33, 32, 32), (5, 24, 40)):
+        f1, f2 = rnd((n, 64, h, w), 70).to(DEV), rnd((n, 64, h, w), 71).to(DEV)
+        flow = (rnd((n, 2, h, w), 72) * 4).to(DEV)
+        flow[0, :, 0, 0] = 1e6
+        for mask in (0, ops.pyramid_layout(h, w, 4, 4)):
+            pyr = ops.corr_build(f1, f2, 4, tiled_levels=mask)
+            try:
+                ops.tune('lookup_pipe', 1)
+                want = ops.corr_lookup(pyr, flow, 4, tiled_levels=mask)
+                for mode in (0, 2, 3, 4, 5, 6):
+                    ops.tune('lookup_pipe', mode)
+                    got = ops.corr_lookup(pyr, flow, 4, tiled_levels=mask)
+                    assert torch.equal(got, want), (n, h, w, mask, mode)
+            finally:
+                ops.tune('lookup_pipe', 0)
