@@ -203,6 +203,16 @@ typedef struct scf_conv_desc {
 
 int scf_conv2d(const scf_conv_desc* desc, scf_stream_t stream);
 
+/* Optional scratch for small grids (r5): register `floats` floats of device memory for launches on `stream` (borrowed until
+ * replaced or cleared with ptr = NULL, floats = 0; one workspace per stream -- concurrent streams must not share one).  A
+ * convolution whose every block would be alone on its CU with a chain of >= 4 staged chunks (batch 1 ... 4: one memory
+ * round trip per chunk, whatever it computes) is then split into up to 4 K slices that write partial tensors to the
+ * workspace, followed by one combine launch that adds them in slice order and applies the descriptor's whole epilogue (any
+ * kind, GRU gates included).  Same result as the single launch up to the re-association of the partial sums;
+ * deterministic; applies to every entry point that launches convolutions on that stream (scf_sepconv_gru*,
+ * scf_scflow_iteration).  Needs N * Cout * Ho * Wo * slices floats; launches that need more stay unsliced. */
+int scf_conv_workspace(scf_stream_t stream, float* ptr, int64_t floats);
+
 /* Host-side weight packers (plain CPU loops, run once per checkpoint): w is a HOST pointer to a
  * contiguous (Cout, Cin, KH, KW) fp32 tensor -- a torch Conv2d weight as stored in the reference's
  * state_dict -- and out a HOST buffer of scf_pack_conv_weight*_size() floats; copy the result

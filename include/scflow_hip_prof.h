@@ -64,6 +64,8 @@ enum {
   SCF_TUNE_DMA_KSPLIT_GROUPS = 3, /* 1: K-split blocks keep one wave group (no intra-block split of the chunk chain) */
   SCF_TUNE_WINO1D4 = 4,       /* 1 (default): 1x5 / 5x1 layers that carry an F(4, 5) packing use it on large grids; 0: F(2, 5);
                                  2: F(4, 5) on every grid it supports (tests of small ragged shapes) */
+  SCF_TUNE_CONV_AUTOSLICE = 7, /* 1 (default): small-grid convolutions on a stream with a registered workspace (scf_conv_workspace) are
+                                 split into K slices + a combine launch; 0: never */
   SCF_TUNE_LOOKUP_STORE = 6,  /* correlation lookup (r = 4, one group per block): cache policy of the output stores, 0 = the build's,
                                  1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt, 5 plain */
   SCF_TUNE_LOOKUP_PIPE = 5    /* correlation lookup: 0 = the dispatch's own choice, 1 = one group of 32 queries per block (the r3

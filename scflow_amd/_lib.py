@@ -182,6 +182,7 @@ SIGNATURES = {
     'scf_instance_norm': (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int, C.c_float, C.c_int, _fp]),
     'scf_group_norm_relu': (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_float, _fp]),
+    'scf_conv_workspace': (C.c_int, [_fp, _fp, C.c_int64]),
     'scf_group_norm_relu_parts': (C.c_int, [_fp, C.c_int, C.c_int64, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_float, _fp]),
     'scf_fc_splitk': (C.c_int, [C.POINTER(FcDesc), _fp]),

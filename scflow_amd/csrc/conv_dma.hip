@@ -723,3 +723,64 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
 #undef SCF_GO
   return SCF_EUNSUPPORTED;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K slices WITHOUT a cooperating consumer (r5): a small-grid launch is a serial chain of one memory round trip per staged
+// chunk whatever it computes (batch 1: 256 -> 192 3x3 = 8 chunks = 21 us for 1.2 GFLOP).  With a workspace registered for the
+// launch stream (scf_conv_workspace) scf_conv2d splits such a launch into S slices writing partial tensors to the workspace
+// and one combine launch that adds them IN SLICE ORDER and runs the layer's own fused epilogue (the same code the
+// convolution kernels use): same result as one launch up to the re-association of S partial sums, deterministic.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_kcombine_kernel(ConvK p, const float* __restrict__ parts, int S, long long slice_ns,
+                                                            int N) {
+  const int HWo = p.Ho * p.Wo, CG = (p.Cout + 3) >> 2;
+  const long long total = (long long)N * CG * HWo;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int pix = (int)(idx % HWo);
+    const long long t = idx / HWo;
+    const int cg = (int)(t % CG), n = (int)(t / CG);
+    const int cb = cg * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* q0 = parts + ((long long)n * p.Cout + cb) * HWo + pix;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (cb + q < p.Cout) {
+        float a = q0[(long long)q * HWo];
+        for (int sl = 1; sl < S; ++sl) a += q0[(long long)sl * slice_ns + (long long)q * HWo];
+        v[q] = a;
+      }
+    const ConvEpi e = scf_conv_epi(p, n);
+    scf_conv_epilogue_group(p, e, v, cb, pix, p.out_div != 1.0f);
+  }
+}
+
+int scf_conv_kcombine_launch(const ConvK& k, const float* parts, int S, long long slice_ns, int N, hipStream_t st) {
+  const long long total = (long long)N * ((k.Cout + 3) / 4) * k.Ho * k.Wo;
+  long long nb = scf_cdiv(total, 256);
+  const long long cap = 8LL * scf_cu_count();
+  nb = nb > cap ? cap : nb;
+  scf_launch(conv_kcombine_kernel, dim3((unsigned)nb), dim3(256), 0, st, k, parts, S, slice_ns, N);
+  return scf_launch_status();
+}
+
+// slice count for a launch nobody asked to slice: only grids on which every K-split block is alone on its CU, only
+// chains of at least four chunks; the combine launch costs ~4.5 us, a chunk ~2 us
+int scf_conv_dma_autoslice(const ConvK& k, int N) {
+  if ((!k.wp4 && !k.wp4s) || (k.stride != 1 && k.stride != 2) || k.w_ns != 0 || k.out_tile || k.kslices > 1) return 1;
+  if (k.T == 1 && k.stride == 2) return 1;                        // dilated 1x1 shortcuts: short chains
+  const int FC = 1 << k.fc_log2, FR = 32 / FC;
+  const long long ksp_blk = (long long)N * ((k.Ho + FR - 1) / FR) * ((k.Wo + FC - 1) / FC) * ((k.Cout + 31) / 32);
+  if (ksp_blk > scf_cu_count()) return 1;
+  int chain = 1 << 30;
+  const int gs[3] = {k.wp4t ? k.G4t : 0, k.wp4s ? k.G4s : 0, k.wp4 ? k.G4 : 0};
+  for (int i = 0; i < 3; ++i)
+    if (gs[i] == 1 || gs[i] == 2 || gs[i] == 4) {
+      const int nch = (k.Cin + 8 * gs[i] - 1) / (8 * gs[i]);
+      chain = nch < chain ? nch : chain;
+    }
+  if (chain == (1 << 30) || chain < 4) return 1;
+  int S = chain / 2 < 4 ? chain / 2 : 4;
+  while (S > 1 && ksp_blk * S > 4LL * scf_cu_count()) --S;
+  return S;
+}

@@ -552,6 +552,36 @@ static bool want_dma(const scf_conv_desc* d) {      // a layer opts in by carryi
          d->w_nstride == 0 && d->a4_mld >= d->Cout;
 }
 
+// ---- workspace for automatically K-sliced small-grid launches: one per launch stream (two streams never share one:
+//      the side-stream branches of a step run concurrently), registered by the caller, borrowed ----
+int scf_conv_kcombine_launch(const ConvK& k, const float* parts, int S, long long slice_ns, int N, hipStream_t st);   // conv_dma.hip
+int scf_conv_dma_autoslice(const ConvK& k, int N);
+namespace {
+struct KWorkspace { hipStream_t st; float* ptr; int64_t floats; };
+std::mutex g_kws_mu;
+std::vector<KWorkspace> g_kws;
+std::atomic<int> g_autoslice{1};      // SCF_TUNE_CONV_AUTOSLICE
+}
+extern "C" int scf_conv_workspace(scf_stream_t stream, float* ptr, int64_t floats) {
+  if (floats < 0 || (ptr == nullptr) != (floats == 0)) return SCF_EINVAL;
+  std::lock_guard<std::mutex> lk(g_kws_mu);
+  hipStream_t st = scf_stream(stream);
+  for (size_t i = 0; i < g_kws.size(); ++i)
+    if (g_kws[i].st == st) {
+      if (ptr) { g_kws[i].ptr = ptr; g_kws[i].floats = floats; }
+      else g_kws.erase(g_kws.begin() + (long)i);
+      return SCF_OK;
+    }
+  if (ptr) g_kws.push_back({st, ptr, floats});
+  return SCF_OK;
+}
+static bool kws_lookup(hipStream_t st, float** ptr, int64_t* floats) {
+  std::lock_guard<std::mutex> lk(g_kws_mu);
+  for (const KWorkspace& w : g_kws)
+    if (w.st == st) { *ptr = w.ptr; *floats = w.floats; return true; }
+  return false;
+}
+
 // which kernel family took the launch (SCF_KERNEL_* of scflow_hip_prof.h)
 static int conv2d_launch(const scf_conv_desc* d, scf_stream_t stream, int* which) {
   ConvPlan pl;
@@ -595,6 +625,24 @@ static int conv2d_launch(const scf_conv_desc* d, scf_stream_t stream, int* which
   }
   if (want_dma(d)) {
     *which = SCF_KERNEL_DMA;
+    // small-grid launch with a workspace on its stream: S slices into the workspace + the combine launch (conv_dma.hip)
+    float* ws = nullptr;
+    int64_t ws_floats = 0;
+    if (g_autoslice.load(std::memory_order_relaxed) && d->k_slices <= 1 && kws_lookup(scf_stream(stream), &ws, &ws_floats)) {
+      const int S = scf_conv_dma_autoslice(pl.k, d->N);
+      const int64_t per_slice = (int64_t)d->N * d->Cout * pl.k.Ho * pl.k.Wo;
+      if (S > 1 && per_slice * S <= ws_floats) {
+        ConvK part = pl.k;
+        part.out = ws; part.out_ns = (long long)d->Cout * pl.k.Ho * pl.k.Wo;
+        part.bias = nullptr; part.scale = nullptr; part.shift = nullptr; part.res = nullptr; part.res_ns = 0;
+        part.out_div = 1.f; part.out_div_pow2 = 1; part.act = SCF_ACT_NONE; part.act2 = SCF_ACT_NONE; part.act_split = 0;
+        part.mode = SCF_CONV_PLAIN; part.gru_h = nullptr; part.gru_aux = nullptr; part.gru_z = nullptr;
+        part.kslices = S; part.slice_ns = per_slice;
+        const int rs = scf_conv_dma_dispatch(part, d->N, false, nullptr, scf_stream(stream));
+        if (rs == SCF_OK) return scf_conv_kcombine_launch(pl.k, ws, S, per_slice, d->N, scf_stream(stream));
+        if (rs != SCF_EUNSUPPORTED) return rs;
+      }
+    }
     const int rd = scf_conv_dma_dispatch(pl.k, d->N, false, nullptr, scf_stream(stream));
     if (rd != SCF_EUNSUPPORTED) return rd;
   }
@@ -637,6 +685,10 @@ extern "C" int scf_tune(int key, int value) {
   if (key == SCF_TUNE_DMA_KSPLIT_GROUPS) return scf_dma_ksplit_groups_set(value);
   if (key == SCF_TUNE_LOOKUP_PIPE) return scf_lookup_pipe_set(value);
   if (key == SCF_TUNE_LOOKUP_STORE) return scf_lookup_store_set(value);
+  if (key == SCF_TUNE_CONV_AUTOSLICE) {
+    if (value < 0 || value > 1) return SCF_EINVAL;
+    return g_autoslice.exchange(value);
+  }
   if (key == SCF_TUNE_WINO1D4) {
     if (value < 0 || value > 2) return SCF_EINVAL;
     return g_wino1d4.exchange(value);

@@ -26,7 +26,7 @@ from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_GRU_Q, CONV_G
 Tensor = torch.Tensor
 
 __all__ = ['record_conv_kernels', 'PackedConv', 'conv_desc', 'gru_passes', 'scflow_iteration', 'side_stream_handle', 'pyramid_layout', 'untile_level', 'level_storage_shape', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision', 'set_conv_winograd', 'get_conv_winograd', 'pack_conv_weight_wino', 'pack_conv_weight_wino1d', 'pack_conv_weight_wino1d4',
-           'get_conv_precision', 'set_conv_kslices', 'conv_kslices', 'constant', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
+           'get_conv_precision', 'set_conv_kslices', 'conv_kslices', 'constant', 'register_conv_workspace', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
            'instance_norm', 'group_norm_relu', 'linear', 'fc_splitk', 'fc_slices', 'pose_update', 'reproject_flow',
            'unproject_depth', 'linear_pair', 'resize_bilinear', 'convex_upsample', 'avgpool2x2', 'copy_channels',
            'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_TANH', 'CONV_PLAIN', 'CONV_GRU_ZR',
@@ -38,6 +38,27 @@ __all__ = ['record_conv_kernels', 'PackedConv', 'conv_desc', 'gru_passes', 'scfl
 # a fifth of the host cost of an eager batch-1 pass (tools/lab/host_profile.py).
 _cur_dev = torch._C._cuda_getDevice
 _raw_stream = torch._C._cuda_getCurrentRawStream
+
+
+# ---- K-slice workspaces (scf_conv_workspace): opt-in.  With a workspace registered for a stream the library splits small-grid
+#      convolutions launched on it into K slices + a combine launch.  Measured on this network (tools/lab/b1_autoslice_ab.py,
+#      hipGraph replay): batch 1 3.09 vs 2.88 ms, batch 2 3.65 vs 3.42, batch 4 4.52 vs 4.47, batch 8 equal -- the combine
+#      launch (~5.5 us) costs more than the shorter chains save (<= 7 us on the longest one), so nothing registers one by
+#      default; ``register_conv_workspace()`` is for callers whose layers have longer chains. ----
+_KWS = {}
+_KWS_FLOATS = 1 << 20       # the rule slices only launches of <= 256 K-split blocks: N * Cout * Ho * Wo <= 2^18 floats, x 4 slices
+
+
+def register_conv_workspace(enable: bool = True) -> None:
+    """register (or clear) a 4 MB K-slice workspace for the CURRENT stream of the current device."""
+    dev = _cur_dev()
+    handle = _raw_stream(dev)
+    if enable:
+        ws = torch.empty((_KWS_FLOATS,), dtype=torch.float32, device=f'cuda:{dev}')
+        _lib.check(_lib.load().scf_conv_workspace(handle, ws.data_ptr(), _KWS_FLOATS), 'scf_conv_workspace')
+        _KWS[(dev, handle)] = ws
+    elif _KWS.pop((dev, handle), None) is not None:
+        _lib.check(_lib.load().scf_conv_workspace(handle, None, 0), 'scf_conv_workspace')
 
 
 def _stream() -> int:
@@ -599,6 +620,7 @@ def set_conv_kslices(on: bool) -> bool:
     order); returns the previous setting."""
     global _CONV_KSLICES
     prev, _CONV_KSLICES = _CONV_KSLICES, bool(on)
+    _lib.load().scf_tune(TUNE_KEYS['conv_autoslice'], int(bool(on)))      # ... and the library's own slicing of small grids
     return prev
 
 
@@ -730,7 +752,7 @@ def conv_timing(enable: bool):
     return list(zip(_read_timers([e[0] for e in evs]), [e[1] for e in evs], [e[2] for e in evs]))
 
 
-TUNE_KEYS = {'wino_variant': 1, 'dma_force_ksplit': 2, 'dma_ksplit_groups': 3, 'wino1d4': 4, 'lookup_pipe': 5, 'lookup_store': 6}
+TUNE_KEYS = {'wino_variant': 1, 'dma_force_ksplit': 2, 'dma_ksplit_groups': 3, 'wino1d4': 4, 'lookup_pipe': 5, 'lookup_store': 6, 'conv_autoslice': 7}
 
 
 def tune(key: str, value: int) -> int:

@@ -1329,3 +1329,64 @@ def test_corr_lookup_groups_per_block_are_bit_identical():
                     assert torch.equal(got, want), (n, h, w, mask, mode)
             finally:
                 ops.tune('lookup_pipe', 0)
+
+
+def test_conv2d_autoslice_small_grids():
+    """r5: with a workspace registered on the launch stream (ops.register_conv_workspace: opt-in) the library splits small-grid
+    convolutions into K slices + a combine launch that runs the layer's own epilogue.  Same result as the single launch up to
+    the re-association of <= 4 partial sums -- for the affine, sigmoid / tanh and both GRU epilogues, one- and two-segment
+    inputs -- and run-to-run identical; scf_tune('conv_autoslice', 0) is the single-launch path."""
+    n, H, W = 1, 32, 32
+    eps = 2.0 ** -24
+
+    def both(fn):
+        ops.register_conv_workspace(True)        # opt-in: nothing registers a workspace by default (measured: a loss here)
+        try:
+            a = fn()
+            a2 = fn()
+            prev = ops.tune('conv_autoslice', 0)
+            try:
+                b = fn()
+            finally:
+                ops.tune('conv_autoslice', prev)
+        finally:
+            ops.register_conv_workspace(False)
+        c = fn()                                 # cleared: the single launch again
+        assert torch.equal(b, c)
+        return a, a2, b
+
+    # (cin, cout, k, pad, act): the batch-1 layers whose chains are long enough to be sliced
+    for cin, cout, k, pad, act in ((256, 192, (3, 3), 1, ops.ACT_RELU), (256, 126, (3, 3), 1, ops.ACT_RELU),
+                                   (324, 256, (1, 1), 0, ops.ACT_RELU), (256, 64, (3, 3), 1, ops.ACT_TANH)):
+        x = rnd((n, cin, H, W), 80 + cout).abs().to(DEV)
+        wt = rnd((cout, cin) + k, 81 + cout, (1.0 / (cin * k[0] * k[1])) ** 0.5).to(DEV)
+        b = rnd((cout,), 82, 0.1).to(DEV)
+        pc = ops.PackedConv.from_weight(wt, b, padding=pad)
+        got, again, single = both(lambda: ops.conv2d(pc, x, act=act))
+        assert torch.equal(got, again)
+        assert not torch.equal(got, single), 'the launch was not sliced (rule or workspace missing)'
+        want = F.conv2d(x.double(), wt.double(), b.double(), padding=pad)
+        want = torch.relu(want) if act == ops.ACT_RELU else torch.tanh(want)
+        scale = F.conv2d(x.double().abs(), wt.double().abs(), b.double().abs(), padding=pad)
+        for t, what in ((got, 'sliced'), (single, 'single')):
+            r = float(((t.double() - want).abs() / (eps * scale)).max())
+            assert r <= 24.0, (what, cin, cout, r)
+    # the whole GRU cell (z|r and q epilogues, hoisted context term) at batch 1
+    from scflow_amd.modules import ConvGRU
+    torch.manual_seed(5)
+    gru = ConvGRU(128, 256, 'SeqConv').to(DEV)
+    hx0 = rnd((n, 128 + 128 + 128, H, W), 90).to(DEV)
+    hx0[:, :128] = torch.tanh(hx0[:, :128])
+    hx0[:, 128:] = hx0[:, 128:].abs()
+
+    def cell():
+        hx = hx0.clone()
+        ctx = gru.context_terms(hx[:, 128:256])
+        for _ in range(3):
+            gru.forward_inplace(hx, ctx, 128)
+        return hx[:, :128].clone()
+    got, again, single = both(cell)
+    assert torch.equal(got, again)
+    d = float((got - single).abs().max())
+    print(f'[measured] GRU cell x3 at batch 1, K-sliced vs single launches: max |dh| {d:.2e}')
+    assert 0.0 < d <= 2e-5
