@@ -159,20 +159,56 @@ __global__ __launch_bounds__(256) void group_norm_relu_kernel(const float* __res
     for (int sl = 1; sl < parts; ++sl) v += xp[(long long)sl * part_stride + i];
     return v;
   };
+  // groups of up to 8 elements per thread (every group of the pose head: 4 channels x 256 / 64 / 16 pixels) are read ONCE
+  // -- parts added in order -- and kept in registers through the three passes; larger groups re-read (L2)
+  constexpr int KEEP = 8;
+  const bool keep = cnt <= KEEP * 256;
+  float kv[KEEP];
+  if (keep) {
+#pragma unroll
+    for (int j = 0; j < KEEP; ++j) {
+      const int i = threadIdx.x + j * 256;
+      kv[j] = i < cnt ? at(i) : 0.f;
+    }
+  }
   float s = 0.f;
-  for (int i = threadIdx.x; i < cnt; i += 256) s += at(i);
+  if (keep) {
+#pragma unroll
+    for (int j = 0; j < KEEP; ++j) s += kv[j];
+  } else {
+    for (int i = threadIdx.x; i < cnt; i += 256) s += at(i);
+  }
   const float mean = block_sum_256(s, red) / (float)cnt;
   float q = 0.f;
-  for (int i = threadIdx.x; i < cnt; i += 256) {
-    const float a = at(i) - mean;
-    q += a * a;
+  if (keep) {
+#pragma unroll
+    for (int j = 0; j < KEEP; ++j) {
+      const float a = kv[j] - mean;
+      q += (threadIdx.x + j * 256 < cnt) ? a * a : 0.f;
+    }
+  } else {
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+      const float a = at(i) - mean;
+      q += a * a;
+    }
   }
   const float var = block_sum_256(q, red) / (float)cnt;
   const float rstd = 1.0f / sqrtf(var + eps);
-  for (int i = threadIdx.x; i < cnt; i += 256) {
-    const int c = g * cpg + i / HW;
-    const float o = (at(i) - mean) * rstd * gamma[c] + beta[c];
-    out[base + i] = fmaxf(o, 0.f);
+  if (keep) {
+#pragma unroll
+    for (int j = 0; j < KEEP; ++j) {
+      const int i = threadIdx.x + j * 256;
+      if (i < cnt) {
+        const int c = g * cpg + i / HW;
+        out[base + i] = fmaxf((kv[j] - mean) * rstd * gamma[c] + beta[c], 0.f);
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+      const int c = g * cpg + i / HW;
+      const float o = (at(i) - mean) * rstd * gamma[c] + beta[c];
+      out[base + i] = fmaxf(o, 0.f);
+    }
   }
 }
 

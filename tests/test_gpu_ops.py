@@ -855,7 +855,7 @@ def test_instance_norm(hw):
           torch.relu(F.instance_norm(x, eps=1e-5) + res), atol=2e-5, what='in+res+relu')
 
 
-@pytest.mark.parametrize('hw', [(16, 16), (8, 8), (4, 4)])
+@pytest.mark.parametrize('hw', [(16, 16), (8, 8), (4, 4), (32, 32), (5, 7), (23, 23)])      # register-resident groups, and larger ones
 def test_group_norm_relu(hw):
     x = rnd((3, 128, *hw), 52, 1.5)
     g, b = 1 + 0.1 * rnd((128,), 53), 0.1 * rnd((128,), 54)
