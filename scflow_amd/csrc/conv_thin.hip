@@ -60,11 +60,38 @@ __global__ __launch_bounds__(32 * SCF_THIN_NCG) void conv_thin_kernel(ConvK p) {
     for (int co = 0; co < CO; ++co) acc[py][co] = 0.f;
 
   const float* xin = p.in0 + (long long)n * p.in0_ns;
-  if constexpr (K == 3) {
+  // generic form: every tap is its own load (K = 1; K = 3 on maps wider than one tile, where a tile's edge columns
+  // would need divergent loads inside the unrolled trips: 28.6 us against 40.4 at (8, 256, 60, 80))
+  auto run_generic = [&]() {
+#pragma unroll 8
+    for (int c = cg; c < p.Cin; c += NCG) {
+      const float* xc = xin + (long long)c * HW;
+      float v[NR][K];
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+          const float t = xc[off[r][d]];
+          v[r][d] = ok[r][d] ? t : 0.f;
+        }
+      const float* wc = wl + c * T * CO;
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+          for (int co = 0; co < CO; ++co) {
+            const float w = wc[(ky * K + kx) * CO + co];
+#pragma unroll
+            for (int py = 0; py < PY; ++py) acc[py][co] += v[py + ky][kx] * w;
+          }
+    }
+  };
+  if constexpr (K == 3 && UNROLL > 0) {
     // r5: ONE load per window row and channel (the centre column); the left / right neighbours come from the
     // adjacent lanes by whole-wave DPP shifts (lane = column; the two 32-lane halves of a wave are two channel
-    // groups, so lanes 0 / 32 and 31 / 63 take their neighbour -- the adjacent tile's column, or zero padding --
-    // from memory: no lane executes those loads when the map is one tile wide).  A third of the load
+    // groups, so lanes 0 / 32 and 31 / 63 take zero padding: this instantiation runs maps of ONE tile per row; wider
+    // maps take the UNROLL = 0 form, where every tap is its own load).  A third of the load
     // instructions (6 -> 2 per output pixel and channel), so all 16 channels of a group's share are in flight at
     // once: the block is one memory round trip instead of two.
     const bool edge_l = col == 0, edge_r = col == 31;
@@ -72,10 +99,9 @@ __global__ __launch_bounds__(32 * SCF_THIN_NCG) void conv_thin_kernel(ConvK p) {
     bool okc[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) { offc[r] = off[r][1]; okc[r] = ok[r][1]; }
-    // EDGES = false: the map is one tile wide, a tile's outer neighbours are zero padding (no load at all: the
-    // loop body is branch-free and unrolls over all of a thread's channels)
-    auto run = [&](auto edges_tag) {
-      constexpr bool EDGES = decltype(edges_tag)::value;
+    // the map is one tile wide (the dispatch's condition for this instantiation): a tile's outer neighbours are zero
+    // padding, the loop body is branch-free
+    {
       // trips of UN channels with a compile-time count (the DPP shifts are convergent operations: a loop with a
       // run-time trip count is not unrolled around them); a channel past Cin re-reads channel cg with zero data
       constexpr int UN = UNROLL;
@@ -93,7 +119,6 @@ __global__ __launch_bounds__(32 * SCF_THIN_NCG) void conv_thin_kernel(ConvK p) {
         for (int u = 0; u < UN; ++u) {
           const int c = c0 + u * NCG;
           const bool cok = c < p.Cin;
-          const float* xc = xin + (long long)(cok ? c : cg) * HW;
           float v[NR][K];
 #pragma unroll
           for (int r = 0; r < NR; ++r) {
@@ -102,13 +127,8 @@ __global__ __launch_bounds__(32 * SCF_THIN_NCG) void conv_thin_kernel(ConvK p) {
             const int ci = __float_as_int(v[r][1]);
             float l = __int_as_float(__builtin_amdgcn_update_dpp(0, ci, 0x138, 0xf, 0xf, true));
             float rr = __int_as_float(__builtin_amdgcn_update_dpp(0, ci, 0x130, 0xf, 0xf, true));
-            if constexpr (EDGES) {
-              if (edge_l) l = (ok[r][0] && cok) ? xc[off[r][0]] : 0.f;
-              if (edge_r) rr = (ok[r][2] && cok) ? xc[off[r][2]] : 0.f;
-            } else {
-              l = edge_l ? 0.f : l;
-              rr = edge_r ? 0.f : rr;
-            }
+            l = edge_l ? 0.f : l;           // one tile per row: the tile's outer neighbours are zero padding
+            rr = edge_r ? 0.f : rr;
             v[r][0] = l;
             v[r][2] = rr;
           }
@@ -126,33 +146,9 @@ __global__ __launch_bounds__(32 * SCF_THIN_NCG) void conv_thin_kernel(ConvK p) {
           __builtin_amdgcn_sched_barrier(0);      // ... and one channel's weights / shifts at a time (registers)
         }
       }
-    };
-    if (p.tiles_x == 1) run(std::false_type{});
-    else run(std::true_type{});
+    }      // (the dispatch sends maps of more than one tile per row to the UNROLL = 0 instantiation)
   } else {
-#pragma unroll 8
-  for (int c = cg; c < p.Cin; c += NCG) {
-    const float* xc = xin + (long long)c * HW;
-    float v[NR][K];
-#pragma unroll
-    for (int r = 0; r < NR; ++r)
-#pragma unroll
-      for (int d = 0; d < K; ++d) {
-        const float t = xc[off[r][d]];
-        v[r][d] = ok[r][d] ? t : 0.f;
-      }
-    const float* wc = wl + c * T * CO;
-#pragma unroll
-    for (int ky = 0; ky < K; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < K; ++kx)
-#pragma unroll
-        for (int co = 0; co < CO; ++co) {
-          const float w = wc[(ky * K + kx) * CO + co];
-#pragma unroll
-          for (int py = 0; py < PY; ++py) acc[py][co] += v[py + ky][kx] * w;
-        }
-  }
+    run_generic();
   }
 
   // ---- combine the channel groups (fixed order), bias, activation, store ----
@@ -180,7 +176,11 @@ __global__ __launch_bounds__(32 * SCF_THIN_NCG) void conv_thin_kernel(ConvK p) {
 
 template <int K, int CO>
 static int launch_thin(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
-  if (K == 3 && nblk <= scf_cu_count())
+  // UNROLL 0 = every tap its own load (K = 1; K = 3 on maps wider than one 32-column tile: its own instantiation, 76
+  // registers -- sharing a kernel with the DPP form cost it occupancy: 35.8 vs 28.6 us at (8, 256, 60, 80))
+  if (K != 3 || k.tiles_x != 1)
+    scf_launch((conv_thin_kernel<K, CO, 0>), dim3(nblk), dim3(32 * SCF_THIN_NCG), lds_bytes, st, k);
+  else if (nblk <= scf_cu_count())
     scf_launch((conv_thin_kernel<K, CO, 4>), dim3(nblk), dim3(32 * SCF_THIN_NCG), lds_bytes, st, k);
   else
     scf_launch((conv_thin_kernel<K, CO, 2>), dim3(nblk), dim3(32 * SCF_THIN_NCG), lds_bytes, st, k);
