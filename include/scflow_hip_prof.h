@@ -59,7 +59,8 @@ int scf_conv_log_enable(int capacity);
 /* measurement knobs (A/B runs of kernel variants from bench.py / tools): returns the previous value, or
  * SCF_EINVAL for an unknown key.  0 always means "the dispatch's own choice". */
 enum {
-  SCF_TUNE_WINO_VARIANT = 1,  /* F(2x2,3x3): 1 = pair kernel, 2 / 3 = quarter-domain kernel with 4 / 8 waves */
+  SCF_TUNE_WINO_VARIANT = 1,  /* F(2x2,3x3): 1 = pair kernel, 2 / 3 = quarter-domain kernel with 4 / 8 waves, 4 = quarter-domain kernel,
+                                 4 waves, four ring slots (80 KB of LDS) */
   SCF_TUNE_DMA_FORCE_KSPLIT = 2, /* 1: the LDS-DMA kernel takes its K-split tile (32 channels x 32 pixels per block) on every grid */
   SCF_TUNE_DMA_KSPLIT_GROUPS = 3, /* 1: K-split blocks keep one wave group (no intra-block split of the chunk chain) */
   SCF_TUNE_WINO1D4 = 4,       /* 1 (default): 1x5 / 5x1 layers that carry an F(4, 5) packing use it on large grids; 0: F(2, 5);
@@ -68,6 +69,8 @@ enum {
                                  split into K slices + a combine launch; 0: never */
   SCF_TUNE_LOOKUP_STORE = 6,  /* correlation lookup (r = 4, one group per block): cache policy of the output stores, 0 = the build's,
                                  1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt, 5 plain */
+  SCF_TUNE_ITER_MERGE = 8,    /* scf_scflow_iteration: 1 (default) = merged launches (1/8 flow + its copy, both up-samplings, pose update +
+                                 re-projection), 0 = one launch each (the r4 sequence; same results) */
   SCF_TUNE_LOOKUP_PIPE = 5    /* correlation lookup: 0 = the dispatch's own choice, 1 = one group of 32 queries per block (the r3
                                  kernel), 2 / 3 = the pipelined kernel with two / three groups per block wherever it fits,
                                  4 / 5 = two / four groups per 512- / 1024-thread block (same waves, fewer workgroups) */

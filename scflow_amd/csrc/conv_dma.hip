@@ -352,6 +352,15 @@ __global__ __launch_bounds__(256 * NG, (KSP || NST > 2) ? 1 : 2) void conv_dma_k
     const f32x4* wl = reinterpret_cast<const f32x4*>(lds + buf * bufsz) + half * BM + l32;
     const f32x4* pl = reinterpret_cast<const f32x4*>(lds + buf * bufsz + WF4 * 4);
     if (++buf == NST) buf = 0;
+    // dense 1x1 (T == 1: a step = one group of 8 channels): a short last chunk of a segment runs only the groups that
+    // hold channels (324 -> 256: 10 chunks of 32 + one of 4 = 41 steps instead of 44); the skipped steps would
+    // multiply the zeros the range check staged
+    int NITc = NIT;
+    if (T == 1) {
+      const int c0 = (cb + chunk) * KC;
+      const int nv = c0 < p.C0 ? p.C0 - c0 : p.Cin - c0;
+      NITc = __builtin_amdgcn_readfirstlane(min(G, (nv + 7) >> 3));
+    }
     if (KSP) {
       // wave w takes the (tap, group) steps it == w (mod 4): one ds_read_b128 pair feeds 4 MFMAs
       // G is 1, 2 or 4: four steps ahead is the same group g, 4 / G taps further.  The operands of
@@ -377,6 +386,7 @@ __global__ __launch_bounds__(256 * NG, (KSP || NST > 2) ? 1 : 2) void conv_dma_k
       };
       f32x4 a0, b0, a1, b1;
       int it = wave;
+      const int NIT = NITc;                  // (shadows the full count: a short last chunk of a 1x1 layer)
       if (it < NIT) opnd(it, a0, b0);
       while (it < NIT) {
         if (it + 4 < NIT) opnd(it + 4, a1, b1);
@@ -431,13 +441,13 @@ __global__ __launch_bounds__(256 * NG, (KSP || NST > 2) ? 1 : 2) void conv_dma_k
     // has just requested for the NEXT step before starting this step's MFMAs.
     load(a[0], b[0], 0);
     int it = 0;
-    for (; it + 2 < NIT; it += 2) {
+    for (; it + 2 < NITc; it += 2) {
       load(a[1], b[1], it + 1);
       mma(a[0], b[0]);
       load(a[0], b[0], it + 2);
       mma(a[1], b[1]);
     }
-    if (it + 1 < NIT) {
+    if (it + 1 < NITc) {
       load(a[1], b[1], it + 1);
       mma(a[0], b[0]);
       mma(a[1], b[1]);

@@ -406,7 +406,10 @@ void conv_wino_kernel(ConvK p, WinoK q) {
 // ===================================================================================================
 #define WQ_NPI(TW, PX4) ((PX4) ? 1 : ((TW) == 2 ? 3 : 4))
 
-template <int TW, bool PX4>
+// NR = slots of the U / patch rings (r5).  3: chunk c + 3 is requested while chunk c is on the matrix cores and has to
+// have landed one chunk later.  4 (80 KB of LDS: still two blocks per CU): one more chunk of latency tolerance -- a
+// block whose CU partner is in its prologue / epilogue then keeps its chunk rate instead of waiting on its copies.
+template <int TW, bool PX4, int NR = 3>
 __global__ __launch_bounds__(256 * TW, TW == 1 ? 2 : 1)
 void conv_wino_q_kernel(ConvK p, WinoK q) {
   extern __shared__ __attribute__((aligned(16))) float wn_lds[];
@@ -435,7 +438,7 @@ void conv_wino_q_kernel(ConvK p, WinoK q) {
   const int HW = p.H * p.W;
 
   float* Us = wn_lds;
-  float* Ps = Us + 3 * USLOT;
+  float* Ps = Us + NR * USLOT;
   const unsigned u_lds = scf_lds_addr(Us), p_lds = scf_lds_addr(Ps);
 
   // ---- chunk-invariant copy offsets (as in the pair kernel) ----
@@ -544,7 +547,8 @@ void conv_wino_q_kernel(ConvK p, WinoK q) {
   issue_p(0); issue_u(0);
   issue_u(1); issue_p(1);
   issue_u(2); issue_p(2);
-  scf_wait_vmcnt_imm<GRP>();
+  if (NR == 4) { issue_u(3); issue_p(3); }
+  scf_wait_vmcnt_imm<(NR - 2) * GRP>();               // chunks 0 and 1 have landed
   __syncthreads();
   const float* ua = Us + row * 512 + lane * 2;      // + fragment * 2048 + j * 128
   wn_f32x2 a0[8], a1[8], b0[2][2], b1[2][2];
@@ -561,8 +565,8 @@ void conv_wino_q_kernel(ConvK p, WinoK q) {
 #define WQ_M(X, S)                                                                                             \
     if (!WN_LAB(0)) acc[X] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[X][S], b[S][((X) & 3) >> 1][(X) & 1], acc[X], 0, 0, 0);    \
     __builtin_amdgcn_sched_barrier(0);
-    int s3 = s1 + 2;
-    s3 = s3 >= 3 ? s3 - 3 : s3;
+    int s3 = s1 + NR - 1;                            // the slot of the chunk in the registers: free
+    s3 = s3 >= NR ? s3 - NR : s3;
     // (measured, r4: the same work as groups of 2-2-4-8 MFMAs with the non-MFMA instructions in three gaps -- what
     // tools/lab/coissue.hip suggests -- runs within +-2 % of this placement on every layer shape; not kept)
     WQ_M(0, 0)
@@ -592,9 +596,9 @@ void conv_wino_q_kernel(ConvK p, WinoK q) {
     __builtin_amdgcn_sched_barrier(0);
     WQ_M(2, 1) WQ_M(3, 1) WQ_M(4, 1) WQ_M(5, 1) WQ_M(6, 1) WQ_M(7, 1)
 #undef WQ_M
-    scf_wait_vmcnt_imm<GRP>();
+    scf_wait_vmcnt_imm<(NR - 2) * GRP>();            // all but the newest NR - 2 chunks have landed: the next one to be read has
     if (!WN_LAB(4)) __syncthreads();
-    s1 = s1 == 2 ? 0 : s1 + 1;
+    s1 = s1 == NR - 1 ? 0 : s1 + 1;
   };
   int c = 0;
   for (; c + 1 < q.nchunk; c += 2) {
@@ -781,12 +785,13 @@ int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* i
 #ifndef SCF_WINO_LAB
   if (variant == 3) variant = 2;          // the 8-wave form is instantiated in lab builds only (measured: no faster)
 #endif
-  if (variant == 2 || variant == 3) {
+  if (variant == 2 || variant == 3 || variant == 4) {
     const int TW = variant == 3 ? 2 : 1;
+    const int NR = variant == 4 ? 4 : 3;                 // ring slots (4: 80 KB of LDS, two blocks per CU still fit)
     const int npi = WQ_NPI(TW, px4), pslot = npi * 256 * TW * (px4 ? 4 : 1);
     const long long nblk = shape(2, TW, pslot);
     if (nblk > 0 && nblk * TW >= min_blocks4) {
-      size_t ldsf = (size_t)(3 * 2 * 2048 + 3 * pslot);
+      size_t ldsf = (size_t)NR * (2 * 2048 + pslot);
       if (ldsf < (size_t)TW * 4 * 3072) ldsf = (size_t)TW * 4 * 3072;      // the output exchange reuses the rings
       const size_t ldsb = ldsf * sizeof(float);
       if (info) { info[0] = 16; info[1] = 2 * TW; info[2] = (int)nblk; info[3] = (int)ldsb; }
@@ -802,10 +807,19 @@ int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* i
         return scf_launch_status();
       }
 #endif
+      if (which) *which = 1;
+      if (NR == 4) {
+        static std::atomic<unsigned long long> raised_q4[2];
+        const void* fn4 = cfg ? (const void*)conv_wino_q_kernel<1, true, 4> : (const void*)conv_wino_q_kernel<1, false, 4>;
+        const int rc4 = scf_raise_dynamic_lds(raised_q4[cfg], fn4, 80 * 1024);
+        if (rc4 != SCF_OK) return rc4;
+        if (cfg) scf_launch((conv_wino_q_kernel<1, true, 4>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
+        else scf_launch((conv_wino_q_kernel<1, false, 4>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
+        return scf_launch_status();
+      }
       const void* fn = cfg ? (const void*)conv_wino_q_kernel<1, true> : (const void*)conv_wino_q_kernel<1, false>;
       const int rc = scf_raise_dynamic_lds(raised_q[cfg], fn, 64 * 1024);
       if (rc != SCF_OK) return rc;
-      if (which) *which = 1;
       if (cfg) scf_launch((conv_wino_q_kernel<1, true>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
       else scf_launch((conv_wino_q_kernel<1, false>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
       return scf_launch_status();

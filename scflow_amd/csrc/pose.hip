@@ -59,13 +59,40 @@ __device__ __forceinline__ void unproject(const PoseMats& s, float x, float y, f
   Z = s.R0inv[6] * cx + s.R0inv[7] * cy + s.R0inv[8] * cz;
 }
 
+// r5: the pose update of the iteration (one thread per sample: a launch of its own, 4.8 us + a launch boundary per
+// iteration) can ride in this kernel: with `pu.rot_all` set, one thread of EVERY block of sample n runs the update of that
+// sample (pose_update_one: the function the stand-alone kernel calls) into LDS, the x = 0 block also stores the results.
+struct PoseOut { float d_rot[6], d_trans[3], R[9], t[3]; };
+struct PoseUpdateArgs {
+  const float* rot_all; const float* trans_all; const long long* label; int num_class, label_mode;
+  const float* R_in; const float* t_in; float* d_rot; float* d_trans; float* R_out; float* t_out;
+};
+__device__ __noinline__ void pose_update_one(const float* __restrict__ rot_all, const float* __restrict__ trans_all,
+                                             const long long* __restrict__ label, int num_class, int label_mode,
+                                             const float* R_in, const float* t_in, int n, PoseOut* o);
+__device__ __forceinline__ void pose_store(const PoseOut& o, int n, float* __restrict__ d_rot, float* __restrict__ d_trans,
+                                           float* R_out, float* t_out);
+
 __global__ __launch_bounds__(256) void reproject_flow_kernel(
     const float* __restrict__ depth, const float* __restrict__ K, const float* __restrict__ R0,
-    const float* __restrict__ t0, const float* __restrict__ R, const float* __restrict__ t,
-    float* __restrict__ flow, int H, int W, float invalid) {
+    const float* __restrict__ t0, const float* R, const float* t,
+    float* __restrict__ flow, int H, int W, float invalid, PoseUpdateArgs pu) {
   __shared__ PoseMats s;
+  __shared__ PoseOut po;
   const int n = blockIdx.y;
-  load_mats(&s, K, R0, t0, R, t, n);
+  const bool fused = pu.rot_all != nullptr;
+  if (fused && threadIdx.x == 224) {
+    PoseOut o;
+    pose_update_one(pu.rot_all, pu.trans_all, pu.label, pu.num_class, pu.label_mode, pu.R_in, pu.t_in, n, &o);
+    po = o;
+    if (blockIdx.x == 0) pose_store(o, n, pu.d_rot, pu.d_trans, pu.R_out, pu.t_out);
+  }
+  load_mats(&s, K, R0, t0, fused ? nullptr : R, fused ? nullptr : t, n);
+  if (fused) {
+    if (threadIdx.x < 9) s.R[threadIdx.x] = po.R[threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x < 67) s.t[threadIdx.x - 64] = po.t[threadIdx.x - 64];
+    __syncthreads();
+  }
   const int hw = H * W;
   const float* dp = depth + (long long)n * hw;
   float* fx = flow + (long long)n * 2 * hw;
@@ -99,8 +126,27 @@ extern "C" int scf_reproject_flow(const float* depth, const float* K, const floa
   if (!depth || !K || !R0 || !t0 || !R || !t || !flow || N <= 0 || H <= 0 || W <= 0) return SCF_EINVAL;
   if (N > 65535) return SCF_EUNSUPPORTED;
   const int bx = (int)(scf_cdiv((int64_t)H * W, 256) < 64 ? scf_cdiv((int64_t)H * W, 256) : 64);
+  const PoseUpdateArgs none = {};
   scf_launch(reproject_flow_kernel, dim3(bx, N), dim3(256), 0, scf_stream(stream), depth, K,
-                     R0, t0, R, t, flow, H, W, invalid_num);
+                     R0, t0, R, t, flow, H, W, invalid_num, none);
+  return scf_launch_status();
+}
+
+int scf_pose_update_reproject(const float* rot_all, const float* trans_all, const int64_t* label, int num_class,
+                              int label_mode, const float* R_in, const float* t_in, float* d_rot, float* d_trans,
+                              float* R_out, float* t_out, const float* depth, const float* K, const float* R0,
+                              const float* t0, float* flow, int N, int H, int W, float invalid_num, scf_stream_t stream) {
+  if (!rot_all || !trans_all || !label || !R_in || !t_in || !d_rot || !d_trans || !R_out || !t_out || num_class <= 0)
+    return SCF_EINVAL;
+  if (!depth || !K || !R0 || !t0 || !flow || N <= 0 || H <= 0 || W <= 0) return SCF_EINVAL;
+  if (N > 65535) return SCF_EUNSUPPORTED;
+  // an in-place update (R_out == R_in) would be read by the other blocks of the sample while block 0 writes it
+  if (R_in == R_out || t_in == t_out) return SCF_EUNSUPPORTED;
+  const int bx = (int)(scf_cdiv((int64_t)H * W, 256) < 64 ? scf_cdiv((int64_t)H * W, 256) : 64);
+  const PoseUpdateArgs pu = {rot_all, trans_all, (const long long*)label, num_class, label_mode, R_in, t_in,
+                             d_rot, d_trans, R_out, t_out};
+  scf_launch(reproject_flow_kernel, dim3(bx, N), dim3(256), 0, scf_stream(stream), depth, K,
+                     R0, t0, (const float*)nullptr, (const float*)nullptr, flow, H, W, invalid_num, pu);
   return scf_launch_status();
 }
 
@@ -138,15 +184,11 @@ extern "C" int scf_unproject_depth(const float* depth, const float* K, const flo
 }
 
 // class select (pose_head.py:207-210) + ortho6d -> R (pose.py:153-169) + pose compose
-// (pose.py:124-149, depth_transform='exp', weight=10).  One thread per sample.
-__global__ void pose_update_kernel(const float* __restrict__ rot_all,
-                                   const float* __restrict__ trans_all,
-                                   const long long* __restrict__ label, int num_class,
-                                   int label_mode, const float* R_in, const float* t_in,
-                                   float* __restrict__ d_rot, float* __restrict__ d_trans,
-                                   float* R_out, float* t_out, int N) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+// (pose.py:124-149, depth_transform='exp', weight=10) of ONE sample.  One function (never inlined) for the stand-alone
+// kernel and for the fused pose-update + re-projection launch: the same instructions, so the same bits.
+__device__ __noinline__ void pose_update_one(const float* __restrict__ rot_all, const float* __restrict__ trans_all,
+                                             const long long* __restrict__ label, int num_class, int label_mode,
+                                             const float* R_in, const float* t_in, int n, PoseOut* o) {
   long long cls = label_mode ? label[n] : label[0];
   if (cls < 0) cls += num_class;                 // torch.index_select rejects these; stay in range
   if (cls < 0) cls = 0;
@@ -154,8 +196,8 @@ __global__ void pose_update_kernel(const float* __restrict__ rot_all,
   const float* a = rot_all + ((long long)n * num_class + cls) * 6;
   const float* dt = trans_all + ((long long)n * num_class + cls) * 3;
   float o6[6], dtr[3];
-  for (int i = 0; i < 6; ++i) { o6[i] = a[i]; d_rot[n * 6 + i] = o6[i]; }
-  for (int i = 0; i < 3; ++i) { dtr[i] = dt[i]; d_trans[n * 3 + i] = dtr[i]; }
+  for (int i = 0; i < 6; ++i) { o6[i] = a[i]; o->d_rot[i] = o6[i]; }
+  for (int i = 0; i < 3; ++i) { dtr[i] = dt[i]; o->d_trans[i] = dtr[i]; }
   // x = normalize(a); z = normalize(x X b); y = z X x
   float nx = sqrtf(o6[0] * o6[0] + o6[1] * o6[1] + o6[2] * o6[2]);
   nx = fmaxf(nx, 1e-12f);
@@ -170,14 +212,35 @@ __global__ void pose_update_kernel(const float* __restrict__ rot_all,
   for (int i = 0; i < 3; ++i) ts[i] = t_in[n * 3 + i];
   for (int r = 0; r < 3; ++r)
     for (int c = 0; c < 3; ++c)
-      R_out[n * 9 + r * 3 + c] = Rd[r * 3 + 0] * Rs[0 * 3 + c] + Rd[r * 3 + 1] * Rs[1 * 3 + c] +
-                                 Rd[r * 3 + 2] * Rs[2 * 3 + c];
+      o->R[r * 3 + c] = Rd[r * 3 + 0] * Rs[0 * 3 + c] + Rd[r * 3 + 1] * Rs[1 * 3 + c] +
+                        Rd[r * 3 + 2] * Rs[2 * 3 + c];
   const float vz = ts[2] / expf(dtr[2]);
   const float vx = vz * (dtr[0] / 10.f + ts[0] / ts[2]);
   const float vy = vz * (dtr[1] / 10.f + ts[1] / ts[2]);
-  t_out[n * 3 + 0] = vx;
-  t_out[n * 3 + 1] = vy;
-  t_out[n * 3 + 2] = vz;
+  o->t[0] = vx;
+  o->t[1] = vy;
+  o->t[2] = vz;
+}
+__device__ __forceinline__ void pose_store(const PoseOut& o, int n, float* __restrict__ d_rot, float* __restrict__ d_trans,
+                                           float* R_out, float* t_out) {
+  for (int i = 0; i < 6; ++i) d_rot[n * 6 + i] = o.d_rot[i];
+  for (int i = 0; i < 3; ++i) d_trans[n * 3 + i] = o.d_trans[i];
+  for (int i = 0; i < 9; ++i) R_out[n * 9 + i] = o.R[i];
+  for (int i = 0; i < 3; ++i) t_out[n * 3 + i] = o.t[i];
+}
+
+// One thread per sample.
+__global__ void pose_update_kernel(const float* __restrict__ rot_all,
+                                   const float* __restrict__ trans_all,
+                                   const long long* __restrict__ label, int num_class,
+                                   int label_mode, const float* R_in, const float* t_in,
+                                   float* __restrict__ d_rot, float* __restrict__ d_trans,
+                                   float* R_out, float* t_out, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  PoseOut o;
+  pose_update_one(rot_all, trans_all, label, num_class, label_mode, R_in, t_in, n, &o);
+  pose_store(o, n, d_rot, d_trans, R_out, t_out);
 }
 
 extern "C" int scf_pose_update(const float* rot_all, const float* trans_all, const int64_t* label,

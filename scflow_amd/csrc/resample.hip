@@ -9,13 +9,17 @@
 // One thread = four consecutive output pixels of one row (one 16-byte store when VEC), a block = 4 rows x 256 columns,
 // grid = (column segments, row groups, planes): 32-bit index arithmetic only (r4: the one-pixel-per-thread form spent
 // its time in three 64-bit divisions per pixel: 10 us for the 16.8 MB of a x8 up-sampled batch-32 flow).
+// r5: a launch carries up to TWO jobs of the same geometry (planes [0, planes) = job 0, the rest job 1: the x8
+// up-sampling of flow + delta flow and of the mask were two launches per iteration), and job 0 may write a second,
+// sample-strided copy of its result (the 1/8 flow also goes into the GRU input buffer: a copy launch per iteration).
+struct ResizeJob {
+  const float* a; const float* b; float* out; float mul;
+};
 template <bool VEC>
-__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ a,
-                                                              const float* __restrict__ b,
-                                                              float* __restrict__ out,
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(ResizeJob j0, ResizeJob j1, int planes0,
                                                               int planes, int Hin, int Win,
                                                               int Hout, int Wout, float sh, float sw,
-                                                              float mul) {
+                                                              float* __restrict__ out2, int out2_group, long long out2_gs) {
   // no fma contraction: torch rounds the source coordinate scale * index before it takes the fraction; a fused
   // sw * ox - x0 is the exact product minus x0 and moves the weights by up to half an ulp of the coordinate (2.5e-5 in the
   // result at coordinate 255)
@@ -37,7 +41,13 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
     x1[i] = x0[i] + (x0[i] < Win - 1 ? 1 : 0);
     lx[i] = fx - (float)x0[i];
   }
-  for (int pl = blockIdx.z; pl < planes; pl += gridDim.z) {
+  for (int plg = blockIdx.z; plg < planes; plg += gridDim.z) {
+    const bool second = plg >= planes0;            // block-uniform
+    const int pl = second ? plg - planes0 : plg;
+    const float* a = second ? j1.a : j0.a;
+    const float* b = second ? j1.b : j0.b;
+    float* out = second ? j1.out : j0.out;
+    const float mul = second ? j1.mul : j0.mul;
     const long long base = (long long)pl * Hin * Win;
     const float* r0 = a + base + (long long)y0 * Win;
     const float* r1 = a + base + (long long)y1 * Win;
@@ -57,21 +67,33 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
       v[i] = mul * (hy * (hx * v00 + lx[i] * v01) + ly * (hx * v10 + lx[i] * v11));
     }
     float* o = out + ((long long)pl * Hout + oy) * Wout + ox0;
+    float* o2 = (out2 && !second) ? out2 + (long long)(pl / out2_group) * out2_gs +
+                                        ((long long)(pl % out2_group) * Hout + oy) * Wout + ox0
+                                  : nullptr;
     if (VEC) {
       *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+      if (o2) *reinterpret_cast<float4*>(o2) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (ox0 + i < Wout) o[i] = v[i];
+        if (ox0 + i < Wout) {
+          o[i] = v[i];
+          if (o2) o2[i] = v[i];
+        }
     }
   }
 }
 
-extern "C" int scf_resize_bilinear(const float* a, const float* b, float* out, int64_t planes,
-                                   int Hin, int Win, int Hout, int Wout, float mul,
-                                   scf_stream_t stream) {
+// internal form (scf_internal.h): job 1 optional (planes1 = 0), second destination of job 0 optional (out2 = nullptr;
+// samples of out2_group planes each, out2_gstride floats apart)
+int scf_resize_bilinear_jobs(const float* a, const float* b, float* out, int64_t planes, float mul,
+                             const float* a1, const float* b1, float* out1, int64_t planes1, float mul1,
+                             float* out2, int out2_group, int64_t out2_gstride,
+                             int Hin, int Win, int Hout, int Wout, scf_stream_t stream) {
   if (!a || !out || planes <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return SCF_EINVAL;
-  if (planes > 0x7fffffffLL) return SCF_EINVAL;
+  if (planes1 < 0 || (planes1 > 0 && (!a1 || !out1)) || (out2 && out2_group <= 0)) return SCF_EINVAL;
+  const long long total = (long long)planes + planes1;
+  if (total > 0x7fffffffLL) return SCF_EINVAL;
   const float sh = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
   const float sw = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
   // about four workgroups per CU, each walking several planes: the x8 flow up-sampling of a batch of 32 was 4096
@@ -79,16 +101,26 @@ extern "C" int scf_resize_bilinear(const float* a, const float* b, float* out, i
   // memory system, paced (r5: 8.8 -> see DESIGN)
   const long long gxy = scf_cdiv(Wout, 256) * scf_cdiv(Hout, 4);
   long long gz = (4LL * scf_cu_count() + gxy - 1) / gxy;
-  gz = gz < 1 ? 1 : gz > planes ? planes : gz > 65535 ? 65535 : gz;
+  gz = gz < 1 ? 1 : gz > total ? total : gz > 65535 ? 65535 : gz;
   const dim3 grid((unsigned)scf_cdiv(Wout, 256), (unsigned)scf_cdiv(Hout, 4), (unsigned)gz);
   if (grid.y > 65535u) return SCF_EUNSUPPORTED;
-  if ((Wout & 3) == 0 && ((uintptr_t)out & 15) == 0)
-    scf_launch(resize_bilinear_kernel<true>, grid, dim3(256), 0, scf_stream(stream), a, b,
-               out, (int)planes, Hin, Win, Hout, Wout, sh, sw, mul);
+  const ResizeJob j0 = {a, b, out, mul}, j1 = {a1, b1, out1, mul1};
+  const bool vec = (Wout & 3) == 0 && ((uintptr_t)out & 15) == 0 && (planes1 == 0 || ((uintptr_t)out1 & 15) == 0) &&
+                   (!out2 || (((uintptr_t)out2 & 15) == 0 && (out2_gstride & 3) == 0));
+  if (vec)
+    scf_launch(resize_bilinear_kernel<true>, grid, dim3(256), 0, scf_stream(stream), j0, j1, (int)planes, (int)total,
+               Hin, Win, Hout, Wout, sh, sw, out2, out2_group, (long long)out2_gstride);
   else
-    scf_launch(resize_bilinear_kernel<false>, grid, dim3(256), 0, scf_stream(stream), a, b,
-               out, (int)planes, Hin, Win, Hout, Wout, sh, sw, mul);
+    scf_launch(resize_bilinear_kernel<false>, grid, dim3(256), 0, scf_stream(stream), j0, j1, (int)planes, (int)total,
+               Hin, Win, Hout, Wout, sh, sw, out2, out2_group, (long long)out2_gstride);
   return scf_launch_status();
+}
+
+extern "C" int scf_resize_bilinear(const float* a, const float* b, float* out, int64_t planes,
+                                   int Hin, int Win, int Hout, int Wout, float mul,
+                                   scf_stream_t stream) {
+  return scf_resize_bilinear_jobs(a, b, out, planes, mul, nullptr, nullptr, nullptr, 0, 1.0f, nullptr, 1, 0,
+                                  Hin, Win, Hout, Wout, stream);
 }
 
 // nn.AvgPool2d(2, 2) of CorrelationPyramid (raft_decoder.py:32, 54-56): window summed in

@@ -97,3 +97,16 @@ __device__ __forceinline__ float scf_apply_act(float v, int act) {
     default: return v;
   }
 }
+
+// ---- launches shared between translation units (not part of the C ABI) ----
+// resample.hip: bilinear resize (align_corners) with an optional second job of the same geometry and an optional second,
+// sample-strided destination of job 0
+int scf_resize_bilinear_jobs(const float* a, const float* b, float* out, int64_t planes, float mul,
+                             const float* a1, const float* b1, float* out1, int64_t planes1, float mul1,
+                             float* out2, int out2_group, int64_t out2_gstride,
+                             int Hin, int Win, int Hout, int Wout, scf_stream_t stream);
+// pose.hip: scf_pose_update + scf_reproject_flow as one launch (every block of a sample recomputes that sample's pose)
+int scf_pose_update_reproject(const float* rot_all, const float* trans_all, const int64_t* label, int num_class,
+                              int label_mode, const float* R_in, const float* t_in, float* d_rot, float* d_trans,
+                              float* R_out, float* t_out, const float* depth, const float* K, const float* R0,
+                              const float* t0, float* flow, int N, int H, int W, float invalid_num, scf_stream_t stream);

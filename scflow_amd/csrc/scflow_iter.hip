@@ -57,8 +57,14 @@ struct OpenBranch {
 
 }  // namespace
 
+// scf_tune(SCF_TUNE_ITER_MERGE, 0): the r4 launch sequence (copy of the 1/8 flow, the two up-samplings, pose update and
+// re-projection as launches of their own) for A/B measurements; 1 (default): merged
+static std::atomic<int> g_iter_merge{1};
+int scf_iter_merge_set(int v) { return (v < 0 || v > 1) ? SCF_EINVAL : g_iter_merge.exchange(v); }
+
 extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stream) {
   if (!it) return SCF_EINVAL;
+  const bool merge = g_iter_merge.load(std::memory_order_relaxed) != 0;
   if (it->struct_size != (int32_t)sizeof(scf_scflow_iter)) return SCF_EINVAL;      // header / binding mismatch
   if (!it->flow_in || !it->flow_out || !it->flow_pred || !it->mask_up || !it->flow_lr || !it->corr ||
       !it->R_in || !it->t_in || !it->R_out || !it->t_out || !it->d_rot || !it->d_trans || !it->hx ||
@@ -77,8 +83,12 @@ extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stre
   const float scale = (float)it->H / (float)it->h;
 
   // ---- 1/8-resolution flow (scflow_decoder.py:196-197) ----
-  SCF_TRY(scf_resize_bilinear(it->flow_in, nullptr, it->flow_lr, (int64_t)N * 2, it->H, it->W, it->h, it->w,
-                              1.0f / scale, stream));
+  // (r5: without flow masking the 1/8 flow is also the motion encoder's input, and its copy into the GRU input buffer
+  // rides in the same launch: a second destination instead of a copy launch per iteration)
+  const bool dual = merge && !it->mask_flow && it->flow_copy_dst != nullptr;
+  SCF_TRY(scf_resize_bilinear_jobs(it->flow_in, nullptr, it->flow_lr, (int64_t)N * 2, 1.0f / scale, nullptr, nullptr, nullptr,
+                                   0, 1.0f, dual ? it->flow_copy_dst : nullptr, 2, it->hx_nstride, it->H, it->W, it->h,
+                                   it->w, stream));
   const float* flow_enc = it->flow_lr;              // what the motion encoder sees (:203-206)
   if (it->mask_flow) {
     if (!it->flow_masked) return SCF_EINVAL;
@@ -112,7 +122,8 @@ extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stre
       if (!fork_to(sideq, mainq, E.ev[1])) return SCF_ELAUNCH;
     }
     SCF_TRY(scf_conv2d(&it->outn, stream));
-    SCF_TRY(scf_copy_strided(flow_enc, (int64_t)2 * hw, it->flow_copy_dst, it->hx_nstride, N, (int64_t)2 * hw, stream));
+    if (!dual)
+      SCF_TRY(scf_copy_strided(flow_enc, (int64_t)2 * hw, it->flow_copy_dst, it->hx_nstride, N, (int64_t)2 * hw, stream));
   }
   // ---- SepConvGRU (:207-208), context part hoisted ----
   if (it->ctx[0])
@@ -147,9 +158,15 @@ extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stre
       if (!fork_to(mainq, sideq, E.ev[4])) return SCF_ELAUNCH;
       br.open = true;
     }
-    SCF_TRY(scf_resize_bilinear(it->flow_lr, it->fpred.out, it->flow_pred, (int64_t)N * 2, it->h, it->w, it->H, it->W,
-                                scale, uq));
-    SCF_TRY(scf_resize_bilinear(it->mpred.out, nullptr, it->mask_up, (int64_t)N, it->h, it->w, it->H, it->W, 1.0f, uq));
+    // flow + delta flow (x scale) and the mask, one launch (r5)
+    if (!merge) {
+      SCF_TRY(scf_resize_bilinear(it->flow_lr, it->fpred.out, it->flow_pred, (int64_t)N * 2, it->h, it->w, it->H, it->W,
+                                  scale, uq));
+      SCF_TRY(scf_resize_bilinear(it->mpred.out, nullptr, it->mask_up, (int64_t)N, it->h, it->w, it->H, it->W, 1.0f, uq));
+    } else {
+      SCF_TRY(scf_resize_bilinear_jobs(it->flow_lr, it->fpred.out, it->flow_pred, (int64_t)N * 2, scale, it->mpred.out, nullptr,
+                                       it->mask_up, (int64_t)N, 1.0f, nullptr, 1, 0, it->h, it->w, it->H, it->W, uq));
+    }
   }
   // ---- pose head (pose_head.py:201-211) ----
   for (int i = 0; i < 3; ++i) {
@@ -183,10 +200,20 @@ extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stre
                             it->trans_all, it->trans_O, N, it->fc2_O, SCF_ACT_NONE, stream));
   }
   // ---- pose update (pose.py:124-169) and the pose-induced flow (pose.py:44-88) ----
-  SCF_TRY(scf_pose_update(it->rot_all, it->trans_all, it->label, it->num_class, it->label_mode, it->R_in, it->t_in,
-                          it->d_rot, it->d_trans, it->R_out, it->t_out, N, stream));
-  SCF_TRY(scf_reproject_flow(it->depth, it->K, it->R0, it->t0, it->R_out, it->t_out, it->flow_out, N, it->H, it->W,
-                             it->invalid_flow_num, stream));
+  // one launch (r5): every block of a sample recomputes the sample's pose update; an in-place update keeps two launches
+  {
+    const int rf = !merge ? SCF_EUNSUPPORTED : scf_pose_update_reproject(it->rot_all, it->trans_all, it->label, it->num_class, it->label_mode, it->R_in,
+                                             it->t_in, it->d_rot, it->d_trans, it->R_out, it->t_out, it->depth, it->K, it->R0,
+                                             it->t0, it->flow_out, N, it->H, it->W, it->invalid_flow_num, stream);
+    if (rf == SCF_EUNSUPPORTED) {
+      SCF_TRY(scf_pose_update(it->rot_all, it->trans_all, it->label, it->num_class, it->label_mode, it->R_in, it->t_in,
+                              it->d_rot, it->d_trans, it->R_out, it->t_out, N, stream));
+      SCF_TRY(scf_reproject_flow(it->depth, it->K, it->R0, it->t0, it->R_out, it->t_out, it->flow_out, N, it->H, it->W,
+                                 it->invalid_flow_num, stream));
+    } else {
+      SCF_TRY(rf);
+    }
+  }
   if (it->overlap_up) {
     br.open = false;
     if (!fork_to(sideq, mainq, E.ev[5])) return SCF_ELAUNCH;

@@ -227,6 +227,11 @@ CONV_CASES = [
     (3, 4, 40, (3, 3), 1, (1, 1), 12, 20),
     (2, 2, 96, (5, 5), 2, (2, 2), 30, 22),
     (1, 3, 64, (7, 7), 2, (3, 3), 480, 640),
+    # more tiles than the chip holds blocks: the kernel walks several tiles per block (weights staged once, the next
+    # tile's patch under the current tile's MFMAs); one channel block / three, even / ragged tile counts per block
+    (64, 3, 64, (7, 7), 2, (3, 3), 256, 256),
+    (24, 2, 96, (5, 5), 2, (2, 2), 126, 94),
+    (37, 1, 64, (3, 3), 1, (1, 1), 44, 36),
 ]
 
 
