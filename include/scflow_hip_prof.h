@@ -71,6 +71,8 @@ enum {
                                  1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt, 5 plain */
   SCF_TUNE_ITER_MERGE = 8,    /* scf_scflow_iteration: 1 (default) = merged launches (1/8 flow + its copy, both up-samplings, pose update +
                                  re-projection), 0 = one launch each (the r4 sequence; same results) */
+  SCF_TUNE_WINO1D4_HALF = 9,  /* F(4, 5): 1 = half-domain kernel (a wave holds 4 of the 8 positions for two channel fragments: half the
+                                 input-transform work per MFMA, one exchange per block), 0 (default) = the full-domain kernel */
   SCF_TUNE_LOOKUP_PIPE = 5    /* correlation lookup: 0 = the dispatch's own choice, 1 = one group of 32 queries per block (the r3
                                  kernel), 2 / 3 = the pipelined kernel with two / three groups per block wherever it fits,
                                  4 / 5 = two / four groups per 512- / 1024-thread block (same waves, fewer workgroups) */

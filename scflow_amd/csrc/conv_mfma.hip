@@ -679,6 +679,7 @@ int scf_dma_ksplit_groups_set(int v);
 int scf_lookup_pipe_set(int v);       // corr_lookup.hip
 int scf_lookup_store_set(int v);
 int scf_iter_merge_set(int v);        // scflow_iter.hip
+int scf_wino1d4_half_set(int v);    // conv_wino1d4.hip
 
 extern "C" int scf_tune(int key, int value) {
   if (key == SCF_TUNE_WINO_VARIANT) return scf_wino_variant_set(value);
@@ -687,6 +688,7 @@ extern "C" int scf_tune(int key, int value) {
   if (key == SCF_TUNE_LOOKUP_PIPE) return scf_lookup_pipe_set(value);
   if (key == SCF_TUNE_LOOKUP_STORE) return scf_lookup_store_set(value);
   if (key == SCF_TUNE_ITER_MERGE) return scf_iter_merge_set(value);
+  if (key == SCF_TUNE_WINO1D4_HALF) return scf_wino1d4_half_set(value);
   if (key == SCF_TUNE_CONV_AUTOSLICE) {
     if (value < 0 || value > 1) return SCF_EINVAL;
     return g_autoslice.exchange(value);

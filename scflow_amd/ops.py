@@ -752,7 +752,7 @@ def conv_timing(enable: bool):
     return list(zip(_read_timers([e[0] for e in evs]), [e[1] for e in evs], [e[2] for e in evs]))
 
 
-TUNE_KEYS = {'wino_variant': 1, 'dma_force_ksplit': 2, 'dma_ksplit_groups': 3, 'wino1d4': 4, 'lookup_pipe': 5, 'lookup_store': 6, 'conv_autoslice': 7, 'iter_merge': 8}
+TUNE_KEYS = {'wino_variant': 1, 'dma_force_ksplit': 2, 'dma_ksplit_groups': 3, 'wino1d4': 4, 'lookup_pipe': 5, 'lookup_store': 6, 'conv_autoslice': 7, 'iter_merge': 8, 'wino1d4_half': 9}
 
 
 def tune(key: str, value: int) -> int:

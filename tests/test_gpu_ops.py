@@ -812,6 +812,56 @@ def test_convgru_context_hoisting(n, h, w, kind):
         close(b[:, hc:], a[:, hc:].cpu(), atol=0, what='x untouched')
 
 
+@pytest.mark.parametrize('n,h,w', [(32, 32, 32), (8, 60, 80), (6, 21, 28)])
+def test_wino1d4_half_domain_kernel(n, h, w):
+    """The half-domain F(4, 5) kernel (conv_wino1d4h_kernel, ``ops.tune('wino1d4_half', 1)``: a wave holds 4 of the 8
+    transform positions for two channel fragments, one exchange of the output shares per block; off by default -- measured
+    no faster in the step) against the full-domain kernel: plain 1x5 / 5x1 layers with two input segments, then the GRU
+    cell (both gate epilogues, the context term streamed through the accumulators of the position-0/1/2/7 waves for both
+    fragments).  Same B operands, same accumulators; the outputs differ by the association of the last adds."""
+    from scflow_amd.modules import ConvGRU
+    try:
+        ops.tune('wino1d4', 2)
+        for k, pad in (((1, 5), (0, 2)), ((5, 1), (2, 0))):
+            cin, cout, c0 = 104, 128, 40
+            x = rnd((n, cin, h, w), 310).to(DEV)
+            wt = rnd((cout, cin, *k), 311, (1.0 / (cin * 5)) ** 0.5)
+            b = rnd((cout,), 312, 0.1)
+            pc = ops.PackedConv.from_weight(wt.to(DEV), b.to(DEV), padding=pad)
+            outs = []
+            for hv in (0, 1):
+                ops.tune('wino1d4_half', hv)
+                with ops.record_conv_kernels() as ran:
+                    outs.append(ops.conv2d(pc, x[:, :c0], x[:, c0:], act=ops.ACT_RELU))
+                assert ran[0][1] == 'winograd F(4,5)', ran
+            want = torch.relu(F.conv2d(x.cpu().double(), wt.double(), b.double(), padding=pad)).float()
+            close(outs[1], want, atol=3e-5, what=f'half-domain {k}')
+            d = float((outs[0] - outs[1]).abs().max())
+            assert d <= 1e-5, d
+        torch.manual_seed(12)
+        hc, cc, xc = 128, 128, 128
+        gru = ConvGRU(hc, cc + xc, 'SeqConv').to(DEV)
+        hx = rnd((n, hc + cc + xc, h, w), 95)
+        hx[:, :hc] = torch.tanh(hx[:, :hc])
+        states = []
+        for hv in (0, 1):
+            ops.tune('wino1d4_half', hv)
+            gru.invalidate_packed()
+            a = hx.to(DEV)
+            ctx = gru.context_terms(a[:, hc:hc + cc])
+            with ops.record_conv_kernels() as ran:
+                for it in range(3):
+                    gru.forward_inplace(a, ctx, cc)
+            assert len(ran) == 12 and all(kk == 'winograd F(4,5)' for _, kk in ran), ran
+            states.append(a[:, :hc].clone())
+        d = float((states[0] - states[1]).abs().max())
+        print(f'[measured] F(4,5) half- vs full-domain kernel, GRU state after 3 iterations ({n}, {h}, {w}): max |dh| {d:.1e}')
+        assert 0.0 < d <= 1e-5, d
+    finally:
+        ops.tune('wino1d4_half', 0)
+        ops.tune('wino1d4', 1)
+
+
 @pytest.mark.parametrize('form', ['F(2,5)', 'F(4,5)'])
 @pytest.mark.parametrize('n,h,w', [(32, 32, 32), (8, 60, 80)])
 def test_sepconv_gru_winograd(n, h, w, form):
