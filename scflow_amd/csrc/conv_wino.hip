@@ -409,9 +409,15 @@ void conv_wino_kernel(ConvK p, WinoK q) {
 // NR = slots of the U / patch rings (r5).  3: chunk c + 3 is requested while chunk c is on the matrix cores and has to
 // have landed one chunk later.  4 (80 KB of LDS: still two blocks per CU): one more chunk of latency tolerance -- a
 // block whose CU partner is in its prologue / epilogue then keeps its chunk rate instead of waiting on its copies.
-template <int TW, bool PX4, int NR = 3>
+// BURST (r5, NR = 4): a chunk is ONE run of everything that is not an MFMA -- the transform of the next chunk's
+// windows (read one chunk earlier), the window reads of the chunk after that, the U reads, the copies -- followed by its
+// 16 MFMAs back to back, instead of seven gaps between MFMAs.  tools/lab/coissue.hip (profiles/r5_coissue_burst_and_
+// priorities.txt): vector-ALU / LDS / copy instructions never overlap the MFMAs of their SIMD (4.2 / 3.3 / 10 clk each on
+// top of 64 per MFMA, with any wave priorities), and every switch between the two kinds costs ~20 clk more.
+template <int TW, bool PX4, int NR = 3, bool BURST = false>
 __global__ __launch_bounds__(256 * TW, TW == 1 ? 2 : 1)
 void conv_wino_q_kernel(ConvK p, WinoK q) {
+  static_assert(!BURST || NR == 4, "the burst form reads two chunks ahead");
   extern __shared__ __attribute__((aligned(16))) float wn_lds[];
   constexpr int NW = 4 * TW, NT = 64 * NW;                      // waves, threads
   constexpr int CW = 2;
@@ -548,7 +554,8 @@ void conv_wino_q_kernel(ConvK p, WinoK q) {
   issue_u(1); issue_p(1);
   issue_u(2); issue_p(2);
   if (NR == 4) { issue_u(3); issue_p(3); }
-  scf_wait_vmcnt_imm<(NR - 2) * GRP>();               // chunks 0 and 1 have landed
+  if (BURST) scf_wait_vmcnt_imm<GRP>();               // chunks 0, 1 and 2 have landed
+  else scf_wait_vmcnt_imm<(NR - 2) * GRP>();          // chunks 0 and 1 have landed
   __syncthreads();
   const float* ua = Us + row * 512 + lane * 2;      // + fragment * 2048 + j * 128
   wn_f32x2 a0[8], a1[8], b0[2][2], b1[2][2];
@@ -556,6 +563,10 @@ void conv_wino_q_kernel(ConvK p, WinoK q) {
   for (int x = 0; x < 8; ++x) a0[x] = *reinterpret_cast<const wn_f32x2*>(ua + (x >> 2) * 2048 + (x & 3) * 128);
   win_load(0u, 0); win_transform(b0, 0);
   win_load(0u, 1); win_transform(b0, 1);
+  if (BURST) {                                       // the raw windows of chunk 1 wait in registers for the first burst
+    win_load((unsigned)(PSLOT * 4), 0);
+    win_load((unsigned)(PSLOT * 4), 1);
+  }
   __syncthreads();
 
   int s1 = 1;
@@ -567,6 +578,27 @@ void conv_wino_q_kernel(ConvK p, WinoK q) {
     __builtin_amdgcn_sched_barrier(0);
     int s3 = s1 + NR - 1;                            // the slot of the chunk in the registers: free
     s3 = s3 >= NR ? s3 - NR : s3;
+    if (BURST) {
+      int s2 = s1 + 1;                               // the slot of the chunk after the next: its windows are read now
+      s2 = s2 >= NR ? s2 - NR : s2;
+      win_transform(bn, 0);
+      win_transform(bn, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      win_load((unsigned)(s2 * PSLOT * 4), 0);
+      win_load((unsigned)(s2 * PSLOT * 4), 1);
+#pragma unroll
+      for (int x = 0; x < 8; ++x) an[x] = *reinterpret_cast<const wn_f32x2*>(uc + (x >> 2) * 2048 + (x & 3) * 128);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_u(s3);
+      issue_p(s3);
+      __builtin_amdgcn_sched_barrier(0);
+      WQ_M(0, 0) WQ_M(1, 0) WQ_M(2, 0) WQ_M(3, 0) WQ_M(4, 0) WQ_M(5, 0) WQ_M(6, 0) WQ_M(7, 0)
+      WQ_M(0, 1) WQ_M(1, 1) WQ_M(2, 1) WQ_M(3, 1) WQ_M(4, 1) WQ_M(5, 1) WQ_M(6, 1) WQ_M(7, 1)
+      scf_wait_vmcnt_imm<GRP>();                     // all but the newest chunk have landed
+      __syncthreads();
+      s1 = s1 == NR - 1 ? 0 : s1 + 1;
+      return;
+    }
     // (measured, r4: the same work as groups of 2-2-4-8 MFMAs with the non-MFMA instructions in three gaps -- what
     // tools/lab/coissue.hip suggests -- runs within +-2 % of this placement on every layer shape; not kept)
     WQ_M(0, 0)
@@ -783,11 +815,14 @@ int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* i
   int variant = g_wino_variant.load(std::memory_order_relaxed);
   if (variant == 0) variant = SCF_WINO_DEFAULT_VARIANT;
 #ifndef SCF_WINO_LAB
-  if (variant == 3) variant = 2;          // the 8-wave form is instantiated in lab builds only (measured: no faster)
+  // lab builds only (each measured, none faster -- docs/lab_notebook.md): 3 = the 8-wave form, 4 = four ring slots
+  // (r5: 14.04 -> 14.07 ms per step), 5 = four ring slots + the burst form of a chunk (r5: 14.00 -> 14.82 ms)
+  if (variant >= 3) variant = 2;
 #endif
-  if (variant == 2 || variant == 3 || variant == 4) {
+  if (variant == 2 || variant == 3 || variant == 4 || variant == 5) {
     const int TW = variant == 3 ? 2 : 1;
-    const int NR = variant == 4 ? 4 : 3;                 // ring slots (4: 80 KB of LDS, two blocks per CU still fit)
+    const int NR = variant >= 4 ? 4 : 3;                 // ring slots (4: 80 KB of LDS, two blocks per CU still fit)
+    const bool burst = variant == 5; (void)burst;
     const int npi = WQ_NPI(TW, px4), pslot = npi * 256 * TW * (px4 ? 4 : 1);
     const long long nblk = shape(2, TW, pslot);
     if (nblk > 0 && nblk * TW >= min_blocks4) {
@@ -808,6 +843,16 @@ int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* i
       }
 #endif
       if (which) *which = 1;
+#ifdef SCF_WINO_LAB
+      if (NR == 4 && burst) {
+        static std::atomic<unsigned long long> raised_qb[2];
+        const void* fnb = cfg ? (const void*)conv_wino_q_kernel<1, true, 4, true> : (const void*)conv_wino_q_kernel<1, false, 4, true>;
+        const int rcb = scf_raise_dynamic_lds(raised_qb[cfg], fnb, 80 * 1024);
+        if (rcb != SCF_OK) return rcb;
+        if (cfg) scf_launch((conv_wino_q_kernel<1, true, 4, true>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
+        else scf_launch((conv_wino_q_kernel<1, false, 4, true>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
+        return scf_launch_status();
+      }
       if (NR == 4) {
         static std::atomic<unsigned long long> raised_q4[2];
         const void* fn4 = cfg ? (const void*)conv_wino_q_kernel<1, true, 4> : (const void*)conv_wino_q_kernel<1, false, 4>;
@@ -817,6 +862,7 @@ int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* i
         else scf_launch((conv_wino_q_kernel<1, false, 4>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
         return scf_launch_status();
       }
+#endif
       const void* fn = cfg ? (const void*)conv_wino_q_kernel<1, true> : (const void*)conv_wino_q_kernel<1, false>;
       const int rc = scf_raise_dynamic_lds(raised_q[cfg], fn, 64 * 1024);
       if (rc != SCF_OK) return rc;
