@@ -91,8 +91,12 @@ ScfTimer*& scf_armed_timer() {
 extern "C" int scf_timer_create(scf_timer_t* out) {
   if (!out) return SCF_EINVAL;
   ScfTimer* t = new ScfTimer;
-  if (hipEventCreate(&t->start) != hipSuccess) { delete t; return SCF_ELAUNCH; }
-  if (hipEventCreate(&t->stop) != hipSuccess) { (void)hipEventDestroy(t->start); delete t; return SCF_ELAUNCH; }
+  // hipEventDisableSystemFence: a default event bound to a dispatch folds a system-scope release into that dispatch's end
+  // -- the timed kernel itself gets longer (tools/lab/event_overhead.hip, profiles/r5_event_overhead.txt: first wave begin
+  // -> last wave end 19.56 us with default events, 18.59 us with these; the kernel trace of the step showed 19.78 -> 20.16 us
+  // when timers were armed, notebook R5.5).  Nothing on the host reads what the timed kernels write: no fence is needed.
+  if (hipEventCreateWithFlags(&t->start, hipEventDisableSystemFence) != hipSuccess) { delete t; return SCF_ELAUNCH; }
+  if (hipEventCreateWithFlags(&t->stop, hipEventDisableSystemFence) != hipSuccess) { (void)hipEventDestroy(t->start); delete t; return SCF_ELAUNCH; }
   *out = t;
   return SCF_OK;
 }
