@@ -284,7 +284,7 @@ __device__ __forceinline__ void scf_conv_epilogue_tile(const ConvK& p, const Con
         for (int r = 0; r < 16; ++r) {
           float v = acc[i][j][r] + bv[i][r >> 2][r & 3];
           if (relu) v = v > 0.f ? v : 0.f;
-          o[(8 * (r >> 2) + (r & 3)) * e.HWo] = v;
+          scf_store1<(SCF_ST_SC1 & 4) != 0>(o + (8 * (r >> 2) + (r & 3)) * e.HWo, v);
         }
       }
     }
@@ -322,7 +322,7 @@ __device__ __forceinline__ void scf_conv_epilogue_tile(const ConvK& p, const Con
           if (p.scale) v = v * sc[r >> 2][r & 3] + sh[r >> 2][r & 3];
           v += rs[r];
           if (relu) v = v > 0.f ? v : 0.f;
-          e.out[o0 + (8 * (r >> 2) + (r & 3)) * e.HWo] = v;
+          scf_store1<(SCF_ST_SC1 & 32) != 0>(e.out + o0 + (8 * (r >> 2) + (r & 3)) * e.HWo, v);
         }
         __builtin_amdgcn_sched_barrier(0);
       }

@@ -379,7 +379,7 @@ void conv_wino_kernel(ConvK p, WinoK q) {
       if (p.scale) { v[0] = v[0] * sc[r] + sh[r]; v[1] = v[1] * sc[r] + sh[r]; }
       v[0] += rr[r][i][0]; v[1] += rr[r][i][1];
       if (relu) { v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f; }
-      *reinterpret_cast<wn_f32x2*>(e.out + off + i * p.Wo) = v;
+      scf_store2<(SCF_ST_SC1 & 8) != 0>(e.out + off + i * p.Wo, v[0], v[1]);
     }
   }
 }
@@ -721,7 +721,7 @@ void conv_wino_q_kernel(ConvK p, WinoK q) {
       if (p.scale) { v[0] = v[0] * sc[k] + sh[k]; v[1] = v[1] * sc[k] + sh[k]; }
       v[0] += rr[k][i][0]; v[1] += rr[k][i][1];
       if (relu) { v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f; }
-      *reinterpret_cast<wn_f32x2*>(e.out + off + i * p.Wo) = v;
+      scf_store2<(SCF_ST_SC1 & 8) != 0>(e.out + off + i * p.Wo, v[0], v[1]);
     }
   }
 }

@@ -124,7 +124,7 @@ __device__ __forceinline__ void w4_gru_epilogue(const ConvK& p, const ConvEpi& e
 #pragma unroll
         for (int q = 0; q < RB; ++q) {
           const int r = hb * RB + q;
-          *reinterpret_cast<scf_f32x4*>(dst + (cb + 8 * (r >> 2) + (r & 3)) * e.HWo + pix[0]) = w[q];
+          scf_store4<(SCF_ST_SC1 & 16) != 0>(dst + (cb + 8 * (r >> 2) + (r & 3)) * e.HWo + pix[0], w[q][0], w[q][1], w[q][2], w[q][3]);
         }
       }
     } else {
@@ -134,7 +134,7 @@ __device__ __forceinline__ void w4_gru_epilogue(const ConvK& p, const ConvEpi& e
 #pragma unroll
           for (int q = 0; q < RB; ++q) {
             const int r = hb * RB + q;
-            dst[(cb + 8 * (r >> 2) + (r & 3)) * e.HWo + pix[j]] = w[q][j];
+            scf_store1<(SCF_ST_SC1 & 16) != 0>(dst + (cb + 8 * (r >> 2) + (r & 3)) * e.HWo + pix[j], w[q][j]);
           }
         }
       }

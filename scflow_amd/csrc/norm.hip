@@ -87,7 +87,7 @@ __global__ __launch_bounds__(NT) void instance_norm_kernel(const float* x,      
       if (relu) {        // NaN -> 0 (v_max), like the convolution epilogue's compare+select
         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
       }
-      op[idx] = o;
+      scf_store4<(SCF_ST_SC1 & 2) != 0>(reinterpret_cast<float*>(op + idx), o.x, o.y, o.z, o.w);
     }
   }
 }

@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(ResizeJob j0, Resi
                                         ((long long)(pl % out2_group) * Hout + oy) * Wout + ox0
                                   : nullptr;
     if (VEC) {
-      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-      if (o2) *reinterpret_cast<float4*>(o2) = make_float4(v[0], v[1], v[2], v[3]);
+      scf_store4<(SCF_ST_SC1 & 1) != 0>(o, v[0], v[1], v[2], v[3]);
+      if (o2) scf_store4<(SCF_ST_SC1 & 1) != 0>(o2, v[0], v[1], v[2], v[3]);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
