@@ -115,7 +115,10 @@ template <bool SC1>
 __device__ __forceinline__ void scf_store4(float* p, float a, float b, float c, float d) {
   if constexpr (SC1) {
     const scf_st_f32x4 v = {a, b, c, d};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    // s_nop 1: a VMEM store of more than 64 bits must not be followed within two wait states by a VALU write of its data
+    // registers (gfx940+); the compiler's hazard recogniser pads its own stores but cannot see inside an asm statement --
+    // without the nop the next instruction overwrote the data before the store had read it (GRU state: inf).
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
   } else {
     *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
   }
@@ -125,7 +128,7 @@ template <bool SC1>
 __device__ __forceinline__ void scf_store2(float* p, float a, float b) {
   if constexpr (SC1) {
     const scf_st_f32x2 v = {a, b};
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
   } else {
     *reinterpret_cast<scf_st_f32x2*>(p) = scf_st_f32x2{a, b};
   }
