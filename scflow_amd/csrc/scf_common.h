@@ -99,16 +99,14 @@ __device__ __forceinline__ float scf_apply_act(float v, int act) {
 }
 
 // Output stores.  A plain store leaves its line dirty in this XCD's L2 until the release at the end of the kernel writes
-// the whole L2 back -- inside the kernel's duration, with the matrix cores idle; a write-through store (sc1) drains while the
-// kernel runs (the lookup: -2.5 us per launch).  SCF_ST_SC1 (bit mask; lab builds override it with -DSCF_ST_SC1=m) selects the
-// kernels that use it: 1 bilinear resize, 2 instance norm, 4 the convolutions' affine epilogue (bias / ReLU), 8 the
-// F(2x2, 3x3) kernels' epilogues, 16 the F(4, 5) gate epilogues, 32 the convolutions' BN / residual epilogue.
-// Measured on the batch-32 step (tools/lab/lib_ab.py, one box, three alternations, product = all plain = 13.98-14.00 ms):
-// 1|2|4 13.92-13.95, + 8 14.02-14.03 (the Winograd epilogues lose 0.07 ms: their consumers re-read the tensor from L2), + 16
-// and + 32 without 8 = 55: 13.89-13.94 ms.  The K-split epilogue, GroupNorm, the linear tail and the pose-induced flow gain
-// nothing at batch 32 and lose 0.07 ms at batch 1 (2.83 -> 2.90 ms): small grids live on L2 hits; left plain.
+// the whole L2 back -- inside the kernel's duration; a write-through store (sc1) drains while the kernel runs (the lookup uses
+// them: -2.5 us per launch).  SCF_ST_SC1 (bit mask, lab builds: -DSCF_ST_SC1=m) selects further kernels: 1 bilinear resize,
+// 2 instance norm, 4 the convolutions' affine epilogue (bias / ReLU), 8 the F(2x2, 3x3) kernels' epilogues, 16 the F(4, 5)
+// gate epilogues, 32 the convolutions' BN / residual epilogue.  Measured on the batch-32 step with identical results checked
+// (tools/lab/lib_ab.py, five MI355X boxes, mask 55 against 0): -0.07, +0.10, +0.35, +-0, -0.07 ms -- box to box it helps or
+// hurts, on the slowest box the most; the product keeps plain stores (0).
 #ifndef SCF_ST_SC1
-#define SCF_ST_SC1 55
+#define SCF_ST_SC1 0
 #endif
 typedef float scf_st_f32x4 __attribute__((ext_vector_type(4)));
 template <bool SC1>

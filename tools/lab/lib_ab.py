@@ -24,6 +24,11 @@ if os.environ.get('GRAPH') == '1':
     step = lambda: g(d)
 else:
     step = lambda: bench.run_step(model, d)
+# a timing is only worth something if the build computes the same thing: checksum of the last iteration's flow and pose
+out = bench.run_step(model, d)
+torch.cuda.synchronize()
+print(f'lib {os.environ.get("SCF_EXP_SUFFIX", "(product)"):10s} checksum: flow {float(out[0][-1].double().abs().sum()):.6e} rot {float(out[2][-1].double().sum()):.9f} '
+      f'finite {bool(torch.isfinite(out[0][-1]).all())}', flush=True)
 for rep in range(reps):
     for _ in range(3):
         step()
