@@ -134,14 +134,22 @@ extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stre
                             it->z, it->rh, stream));
   // ---- heads (:210-213) and their encoders (:216-217) ----
   SCF_TRY(scf_conv2d(&it->heads, stream));
+  // r5: with the mask branch on the side stream, the mask prediction goes with it -- [mask head -> mask encoder] beside
+  // [flow head -> delta-flow encoder] instead of both predictions in a row on the main stream
+  const bool mpred_aside = merge && it->overlap_mask;
+  if (mpred_aside) {                   // the side branch starts behind the heads' hidden layer
+    if (!fork_to(mainq, sideq, E.ev[2])) return SCF_ELAUNCH;
+    br.open = true;
+  }
   SCF_TRY(scf_conv2d(&it->fpred, stream));
-  SCF_TRY(scf_conv2d(&it->mpred, stream));
+  if (!mpred_aside) SCF_TRY(scf_conv2d(&it->mpred, stream));
   {
     scf_stream_t mq = it->overlap_mask ? it->side_stream : stream;
-    if (it->overlap_mask) {
+    if (it->overlap_mask && !mpred_aside) {
       if (!fork_to(mainq, sideq, E.ev[2])) return SCF_ELAUNCH;
       br.open = true;
     }
+    if (mpred_aside) SCF_TRY(scf_conv2d(&it->mpred, mq));
     SCF_TRY(scf_conv2d(&it->menc0, mq));
     SCF_TRY(scf_conv2d(&it->menc1, mq));
     SCF_TRY(scf_conv2d(&it->denc0, stream));
