@@ -22,8 +22,13 @@ def main():
     until = float(sys.argv[2]) if len(sys.argv) > 2 else 44.0
     model, _ = bench.build_model(8, 'cuda')
     d = bench.make_batch(batch, 1000, 'cuda')
+    step = lambda: bench.run_step(model, d)
+    if os.environ.get('GRAPH') == '1':                  # small batches: the pass as ONE hipGraph replay (configs[1])
+        from scflow_amd.graph import GraphedRefiner
+        g = GraphedRefiner(model, d)
+        step = lambda: g(d)
     for _ in range(5):
-        bench.run_step(model, d)
+        step()
     torch.cuda.synchronize()
     ready = time.time() - t0
     n = 0
@@ -33,7 +38,7 @@ def main():
         ops.lookup_timing(True, reserve=8 * 10)
     while time.time() - t0 < until:
         for _ in range(10):
-            bench.run_step(model, d)
+            step()
         torch.cuda.synchronize()
         n += 10
         if timers:
