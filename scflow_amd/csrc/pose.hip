@@ -142,7 +142,11 @@ int scf_pose_update_reproject(const float* rot_all, const float* trans_all, cons
   if (N > 65535) return SCF_EUNSUPPORTED;
   // an in-place update (R_out == R_in) would be read by the other blocks of the sample while block 0 writes it
   if (R_in == R_out || t_in == t_out) return SCF_EUNSUPPORTED;
-  const int bx = (int)(scf_cdiv((int64_t)H * W, 256) < 64 ? scf_cdiv((int64_t)H * W, 256) : 64);
+  // blocks per sample: 64 at large batches (each walks its share of the pixels); a small batch spreads a sample over up to
+  // two blocks per CU so that a pass of few samples is not 64 blocks of four pixels per thread behind one serial pose update
+  int64_t cap = 2LL * scf_cu_count() / N;
+  cap = cap < 64 ? 64 : cap;
+  const int bx = (int)(scf_cdiv((int64_t)H * W, 256) < cap ? scf_cdiv((int64_t)H * W, 256) : cap);
   const PoseUpdateArgs pu = {rot_all, trans_all, (const long long*)label, num_class, label_mode, R_in, t_in,
                              d_rot, d_trans, R_out, t_out};
   scf_launch(reproject_flow_kernel, dim3(bx, N), dim3(256), 0, scf_stream(stream), depth, K,

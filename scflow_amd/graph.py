@@ -9,6 +9,8 @@ graph (``torch.cuda.CUDAGraph`` = hipGraph on ROCm) and replayed with a single l
 
 Shapes are static per instance; inputs are copied into persistent device buffers before each
 replay and the outputs are persistent too (clone them if they must outlive the next call).
+A caller that produces its inputs on the device writes them straight into ``static_in[name]`` (the
+buffers the graph reads) and calls the instance without arguments: no copies, one graph launch.
 """
 from __future__ import annotations
 
