@@ -299,13 +299,19 @@ def test_c_iteration_is_bit_identical(golden_dir, n, masked, hoist):
     assert m.decoder.c_iteration
     a = run()
     a2 = run()
+    # the r4 launch sequence of the C iteration (no merged launches, both predictions on the main stream): same bits
+    ops.tune('iter_merge', 0)
+    try:
+        a3 = run()
+    finally:
+        ops.tune('iter_merge', 1)
     m.decoder.c_iteration = False
     b = run()
     torch.cuda.synchronize()
-    for sa, sa2, sb in zip(a, a2, b):
+    for sa, sa2, sa3, sb in zip(a, a2, a3, b):
         assert len(sa) == len(sb) == 3
-        for ta, ta2, tb in zip(sa, sa2, sb):
-            assert ta.shape == tb.shape and torch.equal(ta, tb) and torch.equal(ta, ta2)
+        for ta, ta2, ta3, tb in zip(sa, sa2, sa3, sb):
+            assert ta.shape == tb.shape and torch.equal(ta, tb) and torch.equal(ta, ta2) and torch.equal(ta, ta3)
 
 
 def test_non_contiguous_images_at_batch_1(golden_dir, model):
@@ -360,6 +366,14 @@ def test_hipgraph_replay_matches_eager(golden_dir, model):
         for ws, gs in zip(want, got):
             for wt, gt in zip(ws, gs):
                 assert torch.equal(wt, gt)
+    # inputs written straight into the graph's input buffers, replay without arguments
+    for k in g.static_in:
+        g.static_in[k].copy_(b[k])
+    got = g()
+    want = model.get_pose(b['render_images'], b['real_images'], b['ref_rotation'], b['ref_translation'], b['depth'],
+                          b['internel_k'], b['label'])
+    torch.cuda.synchronize()
+    assert all(torch.equal(wt, gt) for ws, gs in zip(want, got) for wt, gt in zip(ws, gs))
     # small batches run independent branches on a second stream (ops.side_stream): repeated
     # replays and eager runs must keep reproducing the same bits (this caught a buffer that was
     # allocated after its fork point and recycled from still-running main-stream temporaries)
