@@ -68,13 +68,18 @@ def test_tune_knobs_validate_their_values():
         assert lib.scf_tune(ops.TUNE_KEYS['lookup_pipe'], 7) < 0 and lib.scf_tune(ops.TUNE_KEYS['lookup_store'], 6) < 0
         assert ops.tune('lookup_pipe', 2) == 0 and ops.tune('lookup_pipe', 0) == 2
         assert ops.tune('lookup_store', 4) == 0 and ops.tune('lookup_store', 0) == 4
+        # r5: merged launches of the iteration (default on), half-domain F(4, 5) kernel (default off): 0 / 1 only
+        assert ops.tune('iter_merge', 0) == 1 and ops.tune('iter_merge', 1) == 0
+        assert ops.tune('wino1d4_half', 1) == 0 and ops.tune('wino1d4_half', 0) == 1
+        assert lib.scf_tune(ops.TUNE_KEYS['iter_merge'], 2) < 0 and lib.scf_tune(ops.TUNE_KEYS['wino1d4_half'], -1) < 0
         # ops.tune never hands an error code back as a "previous value"
         with pytest.raises(ValueError):
             ops.tune('no_such_knob', 1)
         with pytest.raises(_lib.ScflowHipError):
             ops.tune('wino1d4', 7)
     finally:                                          # a failed assertion must not leave a knob off its default
-        for key, default in (('wino1d4', 1), ('wino_variant', 0), ('lookup_pipe', 0), ('lookup_store', 0)):
+        for key, default in (('wino1d4', 1), ('wino_variant', 0), ('lookup_pipe', 0), ('lookup_store', 0), ('iter_merge', 1),
+                             ('wino1d4_half', 0)):
             lib.scf_tune(ops.TUNE_KEYS[key], default)
 
 
