@@ -47,6 +47,36 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 LOOKUP_BYTES_PER_QUERY = 2904  # 4*(10*10*4) read + 8 flow + 4*(9*9*4) write
 
 
+# Counter summaries under profiles/ (rocprofv3 --pmc passes are separate runs) are attached to the line ONLY when they
+# were measured on the kernel sources of this tree: tools/summarize_pmc.py / summarize_mfma.py record sha256 of the
+# files below at collection time, kernel_source_hashes() is compared at bench time.  A content
+# hash, not `git rev-parse HEAD:scflow_amd/csrc`: the GPU box holds a snapshot without .git.
+LOOKUP_SOURCES = ('corr_lookup.hip', 'scf_common.h', 'scf_dma.h')
+CONV_SOURCES = ('conv_wino.hip', 'conv_wino1d.hip', 'conv_wino1d4.hip', 'conv_dma.hip', 'conv_mfma.hip', 'conv_taps.hip',
+                'conv_thin.hip', 'conv_kernels.h', 'fc.hip', 'corr_gemm.hip', 'scf_common.h', 'scf_dma.h')
+
+
+def kernel_source_hashes(files):
+    import hashlib
+    out = {}
+    for f in files:
+        try:
+            out[f] = hashlib.sha256(open(os.path.join(ROOT, 'scflow_amd', 'csrc', f), 'rb').read()).hexdigest()[:16]
+        except OSError:
+            out[f] = None
+    return out
+
+
+def _fresh(summary, files):
+    """(True, None) when ``summary`` (a profiles/*.json dict) was measured on today's sources, else (False, why)."""
+    have = summary.get('kernel_source_hashes') if isinstance(summary, dict) else None
+    if not have:
+        return False, 'the summary records no kernel_source_hashes (collected before r6)'
+    now = kernel_source_hashes(files)
+    changed = sorted(f for f in files if have.get(f) != now[f])
+    return (not changed), (f'sources changed since the counter pass: {changed}' if changed else None)
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -63,8 +93,11 @@ def parse_args(argv=None):
     ap.add_argument('--precision', choices=['f32', 'f16x3'], default='f32',
                     help='convolution arithmetic: exact fp32 MFMA, or split-fp16 3xMFMA '
                          '(fp32 accumulate, ~22 mantissa bits; see DESIGN.md)')
-    ap.add_argument('--no-alt', action='store_true', help='skip the second timed loop in the other '
-                    'convolution precision')
+    ap.add_argument('--alt', action='store_true',
+                    help='also time the step with the direct kernels on every layer (alt_direct) and in the other '
+                         'convolution precision (alt_precision: split-fp16, narrower than the reference\'s fp32 -- never a '
+                         'headline).  Off by default since r6: the two loops cost ~8 s of the default run')
+    ap.add_argument('--no-alt', action='store_true', help='(default since r6; kept so that old command lines still parse)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-batch1', action='store_true')
     ap.add_argument('--no-config4', action='store_true')
@@ -209,6 +242,9 @@ def _latest_mfma_pmc():
         d = json.load(open(path))
     except (OSError, ValueError):
         return None
+    ok, why = _fresh(d, CONV_SOURCES)
+    if not ok:
+        return {'stale': f'profiles/{os.path.basename(path)} NOT attached: {why}'}
     return {'source': f'profiles/{os.path.basename(path)}: ' + str(d.get('source', '')),
             'all_matrix_kernels': d.get('all_matrix_kernels', {}).get('mfma_busy_vs_chip_peak'),
             'kernels': [{'kernel': k['kernel'], 'launches': k['launches'], 'mean_duration_us': k['mean_duration_us'],
@@ -269,7 +305,7 @@ class BlockTimer:
         return blocks, done
 
 
-def config4_block(device: str, reps_min_s: float = 2.0):
+def config4_block(device: str, pmc4=None, reps_min_s: float = 2.0):
     """BASELINE configs[4]: 480x640 crops, 12 iterations, batch 8 on the pose-free
     RAFTRefinerFlowMask route (the SCFlow pose head is hard-wired to 256x256)."""
     import torch
@@ -307,6 +343,26 @@ def config4_block(device: str, reps_min_s: float = 2.0):
     cb_us = sum(cbs) / len(cbs)
     cb_fl = 2.0 * 256 * (h * w) ** 2 * n
     pyr_mib = sum(n * h * w * (h >> l) * (w >> l) * 4 for l in range(4)) / 2 ** 20
+    # what the kernel MOVES (PMC traffic of the committed counter pass, attached only when measured on these sources)
+    # against the same time: the algorithmic 2904 B / query prices a 10 x 10 window at 400 B, the memory system
+    # delivers 128-byte lines
+    moved = {'frac_of_moved_bytes': None, 'moved_bytes_per_launch': None,
+             'traffic_stale': True if pmc4 is None else None}
+    if pmc4 and pmc4.get('traffic_bytes_per_launch'):
+        tb = pmc4['traffic_bytes_per_launch']
+        moved = {'moved_bytes_per_launch': tb, 'traffic': tb,
+                 'traffic_over_algorithmic': round(tb / (LOOKUP_BYTES_PER_QUERY * q), 3),
+                 'moved_gbs': round(tb / lk_us / 1e3, 1),
+                 'frac_of_moved_bytes': round(tb / lk_us / 1e3 / HBM_PEAK_GBS, 4),
+                 'fetch_bytes_per_launch': pmc4.get('fetch_bytes_per_launch'),
+                 'write_bytes_per_launch': pmc4.get('write_bytes_per_launch')}
+    moved['line_granularity_floor'] = {
+        'wanted_bytes_per_level_window': 400, 'bytes_per_level_window_at_128B_lines': 884,
+        'note': 'a 10 x 10 float window on 8 x 4-float (128-byte) tiles touches (1 + 9/8)(1 + 9/4) = 6.9 lines = 884 B for the '
+                '400 B the algorithmic figure counts; no 32-float tile shape does better (16 x 2: 8.6 lines; row-major rows '
+                'of 80 floats: 10-20).  The 933 MiB pyramid does not fit the 256 MiB Infinity Cache, so every line comes from '
+                'HBM: frac (algorithmic bytes) is bounded by wanted / moved, frac_of_moved_bytes is what the memory system '
+                'delivers (the guide quotes ~6.3 TB/s = 0.79 of spec as achievable by a copy)'}
     return {
         'workload': 'BASELINE configs[4]: RAFTRefinerFlowMask.get_flow, batch=8 synthetic 480x640 '
                     'pairs, 12 GRU iters, corr radius 4, 4 levels (pose-free route: the SCFlow pose '
@@ -316,7 +372,7 @@ def config4_block(device: str, reps_min_s: float = 2.0):
         'roofline': {'kernel': 'corr_lookup_kernel', 'bound': 'hbm', 'achieved': round(gbs, 1),
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
                      'avg_launch_us': round(lk_us, 2), 'launches_timed': len(lk),
-                     'algorithmic_bytes_per_launch': LOOKUP_BYTES_PER_QUERY * q, 'queries': q},
+                     'algorithmic_bytes_per_launch': LOOKUP_BYTES_PER_QUERY * q, 'queries': q, **moved},
         'roofline_corr_build': {'bound': 'mfma', 'achieved': round(cb_fl / cb_us / 1e6, 1),
                                 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                 'frac': round(cb_fl / cb_us / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
@@ -485,7 +541,7 @@ def main():
             del fa, fb, lv0
         except Exception as exc:          # pragma: no cover - reported, not fatal
             print(f'[bench] secondary measurement failed: {exc!r}', file=sys.stderr)
-        if not args.no_alt and args.precision == 'f32' and args.conv_algo == 'winograd':
+        if args.alt and args.precision == 'f32' and args.conv_algo == 'winograd':
             ops.set_conv_winograd(False)
             blocks_d, _, _ = timed('f32')
             ops.set_conv_winograd(True)
@@ -495,7 +551,7 @@ def main():
                           'note': 'the same step with the direct kernels on every layer (ops.set_conv_winograd(False)): '
                                   'fp32 fma chains in the summation order of the reference; parity of both paths: '
                                   'tests/test_gpu_refiner.py (not measured by this run)'}
-        if not args.no_alt:
+        if args.alt:
             other = 'f16x3' if args.precision == 'f32' else 'f32'
             blocks_alt, lk_alt, _ = timed(other)
             dt_alt = _median(blocks_alt)
@@ -555,8 +611,14 @@ def main():
     if rank == 0 and not standin:
         pmc = {}
         pmc_path = os.path.join(ROOT, 'profiles', 'lookup_pmc.json')
-        if os.path.exists(pmc_path) and args.batch == 32:      # PMC passes are separate rocprofv3 runs
-            pmc = json.load(open(pmc_path))
+        pmc_all, pmc_stale = {}, None
+        if os.path.exists(pmc_path):      # PMC passes are separate rocprofv3 runs
+            pmc_all = json.load(open(pmc_path))
+            ok, why = _fresh(pmc_all, LOOKUP_SOURCES)
+            if not ok:
+                pmc_all, pmc_stale = {}, why
+        if args.batch == 32:
+            pmc = pmc_all
         q = args.batch * 32 * 32
         avg_us = sum(lookup_us) / max(len(lookup_us), 1)
         achieved = LOOKUP_BYTES_PER_QUERY * q / (avg_us * 1e-6) / 1e9 if lookup_us else None
@@ -570,6 +632,9 @@ def main():
             'avg_launch_us': round(avg_us, 2), 'launches_timed': len(lookup_us),
             'median_launch_us': round(_median(lookup_us), 2) if lookup_us else None,
             'algorithmic_bytes_per_launch': LOOKUP_BYTES_PER_QUERY * q}
+        if pmc_stale:       # never repeat a counter figure of other kernel sources
+            result['roofline'].update(traffic=None, traffic_stale=True, traffic_source=f'profiles/lookup_pmc.json NOT attached: {pmc_stale}')
+        result['_pmc_config4'] = pmc_all.get('config4')
         rk = pmc.get('rocprof_kernel_trace')
         if rk:      # committed `rocprofv3 --kernel-trace --stats` pass of this command (profiles/)
             result['roofline']['rocprof_avg_launch_us'] = rk['avg_us']
@@ -662,7 +727,10 @@ def main():
                         '0.6: 6 per 2 outputs instead of 10; F(4,5) launches 0.4: 8 per 4 outputs instead of 20) / sum of the launch durations (HIP start/stop events bound to '
                         'each launch)'}
             mp = _latest_mfma_pmc()
-            if mp and args.batch == 32:       # SQ counter pass of this command (own rocprofv3 run), committed under profiles/
+            if mp and mp.get('stale'):
+                result['roofline_conv']['mfma_busy'] = None
+                result['roofline_conv']['mfma_busy_stale'] = mp['stale']
+            elif mp and args.batch == 32:       # SQ counter pass of this command (own rocprofv3 run), committed under profiles/
                 result['roofline_conv']['mfma_busy'] = mp
             # GRU context hoisting: the context channels' part of the SepConvGRU
             # convolutions runs once per pair instead of once per iteration.  `achieved` counts the
@@ -730,7 +798,7 @@ def main():
     if rank == 0 and world == 1 and not standin and not args.no_config4:
         try:
             ops.set_conv_precision(args.precision)
-            result['config4'] = config4_block(device)
+            result['config4'] = config4_block(device, result.get('_pmc_config4'))
         except Exception as exc:      # pragma: no cover
             print(f'[bench] config4 block failed: {exc!r}', file=sys.stderr)
 
@@ -744,6 +812,7 @@ def main():
         except Exception as exc:      # pragma: no cover
             print(f'[bench] cpu baseline failed: {exc!r}', file=sys.stderr)
     if rank == 0:
+        result.pop('_pmc_config4', None)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

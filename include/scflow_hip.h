@@ -55,7 +55,7 @@ enum {
  * SCF_ABI_MAJOR before its first call; structs additionally carry no size field,
  * so a mismatch must be refused, not worked around. */
 #define SCF_ABI_MAJOR 5
-#define SCF_VERSION (SCF_ABI_MAJOR * 100 + 0)
+#define SCF_VERSION (SCF_ABI_MAJOR * 100 + 1)   /* .1: label_mode is a bit set (SCF_POSE_*) */
 int scf_version(void);
 const char* scf_error_string(int code);
 /* number of HIP devices visible (>=0) or SCF_ENODEVICE */
@@ -210,7 +210,9 @@ int scf_conv2d(const scf_conv_desc* desc, scf_stream_t stream);
  * workspace, followed by one combine launch that adds them in slice order and applies the descriptor's whole epilogue (any
  * kind, GRU gates included).  Same result as the single launch up to the re-association of the partial sums;
  * deterministic; applies to every entry point that launches convolutions on that stream (scf_sepconv_gru*,
- * scf_scflow_iteration).  Needs N * Cout * Ho * Wo * slices floats; launches that need more stay unsliced. */
+ * scf_scflow_iteration).  Needs N * Cout * Ho * Wo * slices floats; launches that need more stay unsliced.
+ * The registry is keyed by the raw stream handle: clear the entry (ptr = NULL) BEFORE destroying the stream, a later
+ * stream that gets the same handle would inherit it. */
 int scf_conv_workspace(scf_stream_t stream, float* ptr, int64_t floats);
 
 /* Host-side weight packers (plain CPU loops, run once per checkpoint): w is a HOST pointer to a
@@ -422,12 +424,17 @@ int scf_fc_splitk(const scf_fc_desc* desc, scf_stream_t stream);
  * Pose head tail + pose update.  replaces pose_head.py:207-210 (class select) and
  * get_pose_from_delta_pose, models/utils/pose.py:124-149 (+ :153-169 ortho6d).
  * rot_all (N, num_class*6), trans_all (N, num_class*3) are the two linear heads' outputs.
- * label_mode 0 reproduces the reference (every sample uses class label[0]);
- * label_mode 1 uses label[n].   Outputs: d_rot (N,6), d_trans (N,3), R_out (N,3,3),
- * t_out (N,3).  R_out/t_out may alias R_in/t_in.
+ * label_mode is a bit set (any other bit: SCF_EINVAL):
+ *   0                          the reference's inference path: every sample is decoded with class label[0]
+ *                              (index_select(...)[:, 0], pose_head.py:209-210), depth_transform='exp' (pose.py:137-138)
+ *   SCF_POSE_LABEL_PER_SAMPLE  sample n uses label[n]
+ *   SCF_POSE_DEPTH_LINEAR      the other depth_transform branch, pose.py:139-141: t_z' = t_z * (d_z + 1)
+ * Outputs: d_rot (N,6), d_trans (N,3), R_out (N,3,3), t_out (N,3).  R_out/t_out may alias R_in/t_in.
  * A label outside [0, num_class) is CLAMPED (a kernel cannot raise; the reference's index_select
  * does): validate labels on the host (SCFlowRefiner.forward_single_pass does).
  * --------------------------------------------------------------------------------- */
+#define SCF_POSE_LABEL_PER_SAMPLE 1
+#define SCF_POSE_DEPTH_LINEAR 2
 int scf_pose_update(const float* rot_all, const float* trans_all, const int64_t* label,
                     int num_class, int label_mode, const float* R_in, const float* t_in,
                     float* d_rot, float* d_trans, float* R_out, float* t_out, int N,

@@ -59,8 +59,9 @@ int scf_conv_log_enable(int capacity);
 /* measurement knobs (A/B runs of kernel variants from bench.py / tools): returns the previous value, or
  * SCF_EINVAL for an unknown key.  0 always means "the dispatch's own choice". */
 enum {
-  SCF_TUNE_WINO_VARIANT = 1,  /* F(2x2,3x3): 1 = pair kernel, 2 / 3 = quarter-domain kernel with 4 / 8 waves, 4 = quarter-domain kernel,
-                                 4 waves, four ring slots (80 KB of LDS) */
+  SCF_TUNE_WINO_VARIANT = 1,  /* F(2x2,3x3): 1 = pair kernel, 2 = quarter-domain kernel (4 waves; the default where it fits).  3 (8 waves),
+                                 4 (four ring slots, 80 KB of LDS) and 5 (4 + burst form of a chunk) are compiled into -DSCF_WINO_LAB
+                                 builds only: the product library answers SCF_EINVAL for them */
   SCF_TUNE_DMA_FORCE_KSPLIT = 2, /* 1: the LDS-DMA kernel takes its K-split tile (32 channels x 32 pixels per block) on every grid */
   SCF_TUNE_DMA_KSPLIT_GROUPS = 3, /* 1: K-split blocks keep one wave group (no intra-block split of the chunk chain) */
   SCF_TUNE_WINO1D4 = 4,       /* 1 (default): 1x5 / 5x1 layers that carry an F(4, 5) packing use it on large grids; 0: F(2, 5);
@@ -75,7 +76,8 @@ enum {
                                  input-transform work per MFMA, one exchange per block), 0 (default) = the full-domain kernel */
   SCF_TUNE_LOOKUP_PIPE = 5    /* correlation lookup: 0 = the dispatch's own choice, 1 = one group of 32 queries per block (the r3
                                  kernel), 2 / 3 = the pipelined kernel with two / three groups per block wherever it fits,
-                                 4 / 5 = two / four groups per 512- / 1024-thread block (same waves, fewer workgroups) */
+                                 4 / 5 / 6 = two / four / three groups per 512- / 1024- / 768-thread block (same waves, fewer
+                                 workgroups; 6 is the form measured on configs[4]: 32.5 vs 30.3 us, notebook R5.6) */
 };
 int scf_tune(int key, int value);
 int scf_conv_log_read(scf_conv_log_entry* out, int max_entries);

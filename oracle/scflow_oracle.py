@@ -187,7 +187,7 @@ def xhead(h: Tensor, sd: SD, p: str, kind: str) -> Tensor:
 
 
 def multiclass_pose_head(x: Tensor, label: Tensor, sd: SD, p: str, num_class: int = 21,
-                         rot_dim: int = 6, num_groups: int = 32) -> Tuple[Tensor, Tensor]:
+                         rot_dim: int = 6, num_groups: int = 32, label_mode: int = 0) -> Tuple[Tensor, Tensor]:
     """head/pose_head.py:201-211.  Three 3x3 stride-2 convs (no bias) each
     followed by GroupNorm(32) + ReLU (:148-160), flatten, FC 2048->1024->256
     with ReLU (:166-172), two linear heads, view (N, num_class, .) and
@@ -195,7 +195,10 @@ def multiclass_pose_head(x: Tensor, label: Tensor, sd: SD, p: str, num_class: in
 
     Reference quirk reproduced as-is:
     index_select with an N-vector yields (N, N, .) and ``[:, 0]`` keeps the
-    entry for ``label[0]`` -> every sample is decoded with class label[0]."""
+    entry for ``label[0]`` -> every sample is decoded with class label[0].
+    ``label_mode=1`` is NOT the reference: it is the per-sample selection the
+    ``index_select`` was evidently meant to be (sample n -> class label[n]), the
+    checker for ``MultiClassPoseHead.label_mode = 1`` of the HIP path."""
     for i in range(3):
         x = F.conv2d(x, sd[f'{p}conv_layers.{i}.conv.weight'], None, stride=2, padding=1)
         x = F.group_norm(x, num_groups, sd[f'{p}conv_layers.{i}.gn.weight'],
@@ -208,6 +211,9 @@ def multiclass_pose_head(x: Tensor, label: Tensor, sd: SD, p: str, num_class: in
     r = F.linear(x, sd[p + 'rotation_pred.weight'], sd[p + 'rotation_pred.bias'])
     t = t.view(-1, num_class, 3)
     r = r.view(-1, num_class, rot_dim)
+    if label_mode:
+        idx = torch.arange(t.shape[0])
+        return r[idx, label], t[idx, label]
     t = torch.index_select(t, 1, label)[:, 0, :]
     r = torch.index_select(r, 1, label)[:, 0, :]
     return r, t
@@ -227,12 +233,16 @@ def rotation_from_ortho6d(o6: Tensor) -> Tensor:
 
 
 def pose_from_delta_pose(d_rot: Tensor, d_trans: Tensor, rot: Tensor, trans: Tensor,
-                         weight: float = 10.) -> Tuple[Tensor, Tensor]:
-    """utils/pose.py:124-149, ortho6d + depth_transform='exp' branch
-    (scflow.py:68; decoder default 'exp' scflow_decoder.py:60):
-    R' = R_delta @ R; z' = z / exp(dz); x' = z' * (dx / 10 + x / z), same y."""
+                         weight: float = 10., depth_transform: str = 'exp') -> Tuple[Tensor, Tensor]:
+    """utils/pose.py:124-149, ortho6d branch (scflow.py:68; decoder default
+    depth_transform 'exp' scflow_decoder.py:60):
+    R' = R_delta @ R; z' = z / exp(dz)  ('exp', :137-138)  or  z * (dz + 1)
+    (any other value, :139-141); x' = z' * (dx / 10 + x / z), same y."""
     r_new = torch.bmm(rotation_from_ortho6d(d_rot), rot)
-    vz = trans[:, 2] / torch.exp(d_trans[:, 2])
+    if depth_transform == 'exp':
+        vz = trans[:, 2] / torch.exp(d_trans[:, 2])
+    else:
+        vz = trans[:, 2] * (d_trans[:, 2] + 1)
     vx = vz * torch.addcdiv(d_trans[:, 0] / weight, trans[:, 0], trans[:, 2])
     vy = vz * torch.addcdiv(d_trans[:, 1] / weight, trans[:, 1], trans[:, 2])
     return r_new, torch.stack([vx, vy, vz], dim=-1)
@@ -275,9 +285,10 @@ def scflow_decoder(feat_render: Tensor, feat_real: Tensor, h_feat: Tensor, cxt_f
                    internel_k: Tensor, label: Tensor, init_flow: Tensor, sd: SD, *,
                    prefix: str = 'decoder.', iters: int = 8, num_levels: int = 4,
                    radius: int = 4, invalid_flow_num: float = 0.,
-                   mask_flow: bool = False, mask_corr: bool = False):
+                   mask_flow: bool = False, mask_corr: bool = False,
+                   depth_transform: str = 'exp', label_mode: int = 0):
     """decoder/scflow_decoder.py:150-251 (inference: the detach_* flags only
-    affect autograd)."""
+    affect autograd).  ``label_mode=1``: see ``multiclass_pose_head`` (not the reference)."""
     p = prefix
     pyramid = correlation_pyramid(feat_render, feat_real, num_levels)           # :172
     rot, trans = ref_rotation, ref_translation
@@ -307,12 +318,13 @@ def scflow_decoder(feat_render: Tensor, feat_real: Tensor, h_feat: Tensor, cxt_f
         mf = conv_act(mask, sd, p + 'mask_encoder.0', padding=1)                # :217
         mf = conv_act(mf, sd, p + 'mask_encoder.1', padding=1)
         d_rot, d_trans = multiclass_pose_head(torch.cat([h_feat, df, mf], dim=1), label,
-                                              sd, p + 'pose_pred.')             # :218-219
+                                              sd, p + 'pose_pred.', label_mode=label_mode)   # :218-219
         flow_pred = scale * F.interpolate(flow + d_flow, scale_factor=(scale, scale),
                                           mode='bilinear', align_corners=True)  # :222-224
         up_mask = F.interpolate(mask, scale_factor=(scale, scale), mode='bilinear',
                                 align_corners=True)                             # :226-227
-        rot, trans = pose_from_delta_pose(d_rot, d_trans, rot, trans)           # :230-236
+        rot, trans = pose_from_delta_pose(d_rot, d_trans, rot, trans,
+                                          depth_transform=depth_transform)      # :230-236
         flow = flow_from_pose_and_points(rot, trans, internel_k, pts2d, pts3d, H, W,
                                          invalid_num=invalid_flow_num)          # :239-243
         outs['rotation'].append(rot)
@@ -343,7 +355,8 @@ def extract_feat(render_images: Tensor, real_images: Tensor, sd: SD, *, h_channe
 def get_pose(render_images: Tensor, real_images: Tensor, ref_rotation: Tensor,
              ref_translation: Tensor, depth: Tensor, internel_k: Tensor, label: Tensor,
              sd: SD, *, iters: int = 8, init_flow: Tensor | None = None,
-             mask_flow: bool = False, mask_corr: bool = False):
+             mask_flow: bool = False, mask_corr: bool = False,
+             depth_transform: str = 'exp', label_mode: int = 0):
     """refiner/scflow_refiner.py:112-142 ``SCFlowRefiner.get_pose``
     (invalid_flow_num = 0 at inference, :142); ``mask_flow`` / ``mask_corr``: the decoder's
     constructor switches (scflow_decoder.py:199-205, both False in configs/refine_models/scflow.py)."""
@@ -353,7 +366,8 @@ def get_pose(render_images: Tensor, real_images: Tensor, ref_rotation: Tensor,
         init_flow = torch.zeros((n, 2, H, W), dtype=torch.float32)
     return scflow_decoder(fr, fl, h, c, ref_rotation, ref_translation, depth, internel_k,
                           label, init_flow, sd, iters=iters, invalid_flow_num=0.,
-                          mask_flow=mask_flow, mask_corr=mask_corr)
+                          mask_flow=mask_flow, mask_corr=mask_corr,
+                          depth_transform=depth_transform, label_mode=label_mode)
 
 
 def end_point_error(flow_a: Tensor, flow_b: Tensor, valid: Tensor | None = None) -> float:

@@ -718,7 +718,10 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   k.tiles_x = (k.Wo + FC - 1) / FC;
   k.mblocks = (frags_m + WM - 1) / WM;
   k.slice_blocks = (int)(nblk / S);
-  if (S > 1 && k.nchunk < S) return SCF_EUNSUPPORTED;        // every slice owns at least one chunk
+  // every slice owns at least one chunk: slice i starts at chunk i * ceil(nchunk / S), so the LAST one is empty as soon
+  // as (S - 1) * ceil(nchunk / S) >= nchunk (5 chunks in 4 slices: 2 2 1 0) -- such a launch would run blocks that only
+  // store zeros for the consumer to add; the caller asks again with fewer slices (ops.conv_kslices_for)
+  if (S > 1 && (long long)(S - 1) * ((k.nchunk + S - 1) / S) >= k.nchunk) return SCF_EUNSUPPORTED;
   if (info) { info[0] = WM; info[1] = ksp ? ngroups : WN; info[2] = (int)nblk; info[3] = k.T * G * 4 * WM * WN / (ksp ? 4 : 1); }
   if (dry_run) return SCF_OK;
 #define SCF_GO(...) return px4 ? launch_dma<__VA_ARGS__, true>(k, (int)nblk, ldsb, st)            \

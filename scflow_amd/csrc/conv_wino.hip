@@ -761,7 +761,14 @@ extern "C" int scf_pack_conv_weight_wino(const float* w, int32_t cout, int32_t c
 // measurement knob (scflow_hip_prof.h: scf_tune(SCF_TUNE_WINO_VARIANT, v)): 0 = the dispatch's own choice,
 // 1 = pair kernel, 2 = quarter-domain kernel with 4 waves, 3 = quarter-domain kernel with 8 waves
 static std::atomic<int> g_wino_variant{0};
-int scf_wino_variant_set(int v) { return g_wino_variant.exchange(v); }
+int scf_wino_variant_set(int v) {
+#ifndef SCF_WINO_LAB
+  if (v < 0 || v > 2) return SCF_EINVAL;      // 3 / 4 / 5 exist in -DSCF_WINO_LAB builds only: refuse instead of silently running 2
+#else
+  if (v < 0 || v > 5) return SCF_EINVAL;
+#endif
+  return g_wino_variant.exchange(v);
+}
 
 // Tile selection + launch; SCF_EUNSUPPORTED -> the caller goes on to the direct kernels.
 // info (optional): {16 transform positions, fragments per block, blocks, LDS bytes}.

@@ -136,7 +136,8 @@ int scf_pose_update_reproject(const float* rot_all, const float* trans_all, cons
                               int label_mode, const float* R_in, const float* t_in, float* d_rot, float* d_trans,
                               float* R_out, float* t_out, const float* depth, const float* K, const float* R0,
                               const float* t0, float* flow, int N, int H, int W, float invalid_num, scf_stream_t stream) {
-  if (!rot_all || !trans_all || !label || !R_in || !t_in || !d_rot || !d_trans || !R_out || !t_out || num_class <= 0)
+  if (!rot_all || !trans_all || !label || !R_in || !t_in || !d_rot || !d_trans || !R_out || !t_out || num_class <= 0 ||
+      (label_mode & ~(SCF_POSE_LABEL_PER_SAMPLE | SCF_POSE_DEPTH_LINEAR)))
     return SCF_EINVAL;
   if (!depth || !K || !R0 || !t0 || !flow || N <= 0 || H <= 0 || W <= 0) return SCF_EINVAL;
   if (N > 65535) return SCF_EUNSUPPORTED;
@@ -188,12 +189,12 @@ extern "C" int scf_unproject_depth(const float* depth, const float* K, const flo
 }
 
 // class select (pose_head.py:207-210) + ortho6d -> R (pose.py:153-169) + pose compose
-// (pose.py:124-149, depth_transform='exp', weight=10) of ONE sample.  One function (never inlined) for the stand-alone
+// (pose.py:124-149, both depth_transform branches, weight=10) of ONE sample.  One function (never inlined) for the stand-alone
 // kernel and for the fused pose-update + re-projection launch: the same instructions, so the same bits.
 __device__ __noinline__ void pose_update_one(const float* __restrict__ rot_all, const float* __restrict__ trans_all,
                                              const long long* __restrict__ label, int num_class, int label_mode,
                                              const float* R_in, const float* t_in, int n, PoseOut* o) {
-  long long cls = label_mode ? label[n] : label[0];
+  long long cls = (label_mode & SCF_POSE_LABEL_PER_SAMPLE) ? label[n] : label[0];
   if (cls < 0) cls += num_class;                 // torch.index_select rejects these; stay in range
   if (cls < 0) cls = 0;
   if (cls >= num_class) cls = num_class - 1;
@@ -218,7 +219,8 @@ __device__ __noinline__ void pose_update_one(const float* __restrict__ rot_all, 
     for (int c = 0; c < 3; ++c)
       o->R[r * 3 + c] = Rd[r * 3 + 0] * Rs[0 * 3 + c] + Rd[r * 3 + 1] * Rs[1 * 3 + c] +
                         Rd[r * 3 + 2] * Rs[2 * 3 + c];
-  const float vz = ts[2] / expf(dtr[2]);
+  // pose.py:137-141: 'exp' -> tz / exp(dz); any other depth_transform -> tz * (dz + 1)
+  const float vz = (label_mode & SCF_POSE_DEPTH_LINEAR) ? ts[2] * (dtr[2] + 1.f) : ts[2] / expf(dtr[2]);
   const float vx = vz * (dtr[0] / 10.f + ts[0] / ts[2]);
   const float vy = vz * (dtr[1] / 10.f + ts[1] / ts[2]);
   o->t[0] = vx;
@@ -252,7 +254,7 @@ extern "C" int scf_pose_update(const float* rot_all, const float* trans_all, con
                                float* d_rot, float* d_trans, float* R_out, float* t_out, int N,
                                scf_stream_t stream) {
   if (!rot_all || !trans_all || !label || !R_in || !t_in || !d_rot || !d_trans || !R_out || !t_out ||
-      N <= 0 || num_class <= 0)
+      N <= 0 || num_class <= 0 || (label_mode & ~(SCF_POSE_LABEL_PER_SAMPLE | SCF_POSE_DEPTH_LINEAR)))
     return SCF_EINVAL;
   scf_launch(pose_update_kernel, dim3((N + 63) / 64), dim3(64), 0, scf_stream(stream),
                      rot_all, trans_all, (const long long*)label, num_class, label_mode, R_in, t_in,

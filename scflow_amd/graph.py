@@ -26,6 +26,10 @@ _INPUTS = ('render_images', 'real_images', 'ref_rotation', 'ref_translation', 'd
 
 class GraphedRefiner:
     def __init__(self, model, example: Dict[str, torch.Tensor], warmup: int = 2) -> None:
+        if warmup < 1:
+            # the eager pass packs the weights, creates the cached constants (ops.constant refuses to be first called
+            # inside a capture), the side streams and the per-shape dispatch plans: none of that may happen in the graph
+            raise ValueError('GraphedRefiner needs at least one eager warm-up pass (warmup >= 1)')
         self.model = model
         self.static_in = {k: example[k].clone().contiguous() for k in _INPUTS}
         # warm-up and capture run on ONE private stream: the side stream that belongs to it

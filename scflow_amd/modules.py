@@ -148,7 +148,7 @@ class ConvBlock(HipModule):
         if self.act != ACT_RELU:
             raise NotImplementedError('GN is fused with ReLU only')
         # small grids: K split across blocks, the normalisation adds the partial tensors (ops.conv_kslices)
-        ks = ops.conv_kslices(self.packed, x0.shape[0], x0.shape[2], x0.shape[3])
+        ks = ops.conv_kslices_for(self.packed, x0, x1)
         y = ops.conv2d(self.packed, x0, x1, kslices=ks)
         return ops.group_norm_relu(y, self.gn.weight, self.gn.bias, self.groups, self.gn.eps, out=out)
 
@@ -476,7 +476,8 @@ class MultiClassPoseHead(HipModule):
         self.rotation_pred = nn.Linear(256, 6 * num_class)
         self.translation_pred = nn.Linear(256, 3 * num_class)
         # reference label selection uses label[0] for the whole batch (pose_head.py:209-210,
-        # SURVEY.md 8 a8); label_mode=1 selects per sample instead.
+        # SURVEY.md 8 a8); label_mode=1 selects per sample instead (what index_select was meant to do;
+        # oracle.multiclass_pose_head(label_mode=1), tests/test_gpu_refiner.py::test_label_mode_per_sample).
         self.label_mode = 0
         # fc1 / fc2 / heads as split-K MFMA GEMMs with the last GroupNorm folded in (scf_fc_splitk); False = one
         # scf_linear launch per layer after a separate GroupNorm (A/B measurements, parity tests)
@@ -512,7 +513,7 @@ class MultiClassPoseHead(HipModule):
         if s1:
             last = self.conv_layers[2]
             # GroupNorm + ReLU: applied by fc1's operand load, which also adds the partial tensors of a K-sliced launch
-            ks = ops.conv_kslices(last.packed, x.shape[0], x.shape[2], x.shape[3])
+            ks = ops.conv_kslices_for(last.packed, x)
             y = ops.conv2d(last.packed, x, kslices=ks)
             hw = y.shape[-2] * y.shape[-1]
             feat = y.shape[-3] * hw
@@ -560,8 +561,9 @@ class SCFlowDecoder(HipModule):
         if net_type != 'Basic':
             raise NotImplementedError("SCFlowDecoder: net_type='Basic'")
         self.mask_flow, self.mask_corr = bool(mask_flow), bool(mask_corr)      # scflow_decoder.py:199-205
-        if depth_transform != 'exp':
-            raise NotImplementedError("depth_transform='exp' only")
+        # pose.py:137-141: 'exp' -> t_z / exp(d_z); ANY other value takes the reference's else branch t_z * (d_z + 1)
+        self.depth_transform = depth_transform
+        self.detach_depth_for_xy = detach_depth_for_xy      # autograd only (pose.py:142-147): no effect at inference
         self.net_type, self.num_levels, self.radius, self.iters = net_type, num_levels, radius, iters
         self.h_channels = self._h_channels[net_type]
         self.cxt_channels = self._cxt_channels[net_type]
@@ -585,6 +587,10 @@ class SCFlowDecoder(HipModule):
         # the launch sequence of an iteration issued by ONE C call (scf_scflow_iteration) instead of
         # ~33 Python-sequenced ones: same kernels, same order, same bits; False = sequence from here
         self.c_iteration = True
+
+    def pose_flags(self) -> int:
+        """the ``label_mode`` bit set of ``scf_pose_update`` (scflow_hip.h: SCF_POSE_*)."""
+        return (self.pose_pred.label_mode & 1) | (0 if self.depth_transform == 'exp' else 2)
 
     def _pack_sources(self):
         a, b = self.flow_pred.layers[0].conv, self.mask_pred.layers[0].conv
@@ -666,7 +672,7 @@ class SCFlowDecoder(HipModule):
             rot_all, trans_all = self.pose_pred.features(hv, dm)                   # :218-219
             d_rot, d_trans, rot, trans = ops.pose_update(                          # :230-236
                 rot_all, trans_all, label, self.pose_pred.num_class, rot, trans,
-                self.pose_pred.label_mode)
+                self.pose_flags())
             flow = ops.reproject_flow(depth, internel_k, rot0, trans0, rot, trans,  # :239-243
                                       invalid_flow_num)
             br.join()
@@ -745,7 +751,7 @@ def _scflow_forward_c(self, pyramid, tiled, hx, ctx, rot0, trans0, depth, intern
     for i, blk in enumerate(ph.conv_layers):
         if blk.groups is None or blk.act != ACT_RELU:
             raise NotImplementedError('pose head: conv + GroupNorm + ReLU blocks')
-        ks = ops.conv_kslices(blk.packed, x0.shape[0], x0.shape[2], x0.shape[3])
+        ks = ops.conv_kslices_for(blk.packed, x0, x1)
         d_, y = ops.conv_desc(blk.packed, x0, x1, kslices=ks)       # ks > 1: (ks, N, C, h, w) partial tensors
         g = torch.empty_like(y[0] if ks > 1 else y)
         it.pose[i] = d_
@@ -769,7 +775,7 @@ def _scflow_forward_c(self, pyramid, tiled, hx, ctx, rot0, trans0, depth, intern
                                                         ta.data_ptr(), ta.shape[1])
     if not label.is_cuda or label.dtype != torch.int64 or not label.is_contiguous():
         raise _lib_error('label must be a contiguous int64 GPU tensor')
-    it.label, it.num_class, it.label_mode = label.data_ptr(), ph.num_class, ph.label_mode
+    it.label, it.num_class, it.label_mode = label.data_ptr(), ph.num_class, self.pose_flags()
     for name, t in (('depth', depth), ('internel_k', internel_k), ('ref_rotation', rot0), ('ref_translation', trans0),
                     ('init_flow', init_flow)):
         ops._dense(t, name)

@@ -26,7 +26,7 @@ from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_GRU_Q, CONV_G
 Tensor = torch.Tensor
 
 __all__ = ['record_conv_kernels', 'PackedConv', 'conv_desc', 'gru_passes', 'scflow_iteration', 'side_stream_handle', 'pyramid_layout', 'untile_level', 'level_storage_shape', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision', 'set_conv_winograd', 'get_conv_winograd', 'pack_conv_weight_wino', 'pack_conv_weight_wino1d', 'pack_conv_weight_wino1d4',
-           'get_conv_precision', 'set_conv_kslices', 'conv_kslices', 'constant', 'register_conv_workspace', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
+           'get_conv_precision', 'set_conv_kslices', 'conv_kslices', 'conv_kslices_for', 'constant', 'clear_constants', 'register_conv_workspace', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
            'instance_norm', 'group_norm_relu', 'linear', 'fc_splitk', 'fc_slices', 'pose_update', 'reproject_flow',
            'unproject_depth', 'linear_pair', 'resize_bilinear', 'convex_upsample', 'avgpool2x2', 'copy_channels',
            'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_TANH', 'CONV_PLAIN', 'CONV_GRU_ZR',
@@ -50,7 +50,10 @@ _KWS_FLOATS = 1 << 20       # the rule slices only launches of <= 256 K-split bl
 
 
 def register_conv_workspace(enable: bool = True) -> None:
-    """register (or clear) a 4 MB K-slice workspace for the CURRENT stream of the current device."""
+    """register (or clear) a 4 MB K-slice workspace for the CURRENT stream of the current device.
+    The library keys its registry by the raw ``hipStream_t``: CLEAR the registration (``enable=False`` on that stream)
+    before destroying a stream -- a new stream that is handed the same handle would otherwise inherit the workspace and
+    could share it with another live stream."""
     dev = _cur_dev()
     handle = _raw_stream(dev)
     if enable:
@@ -597,7 +600,13 @@ _CONV_EVENTS = None
 # ---- read-only constant tensors (the all-zero initial flow, the all-ones first-iteration mask): filled ONCE per
 #      (device, shape, value) and handed out again -- a steady-state step then launches no fill kernel.  Kernels only
 #      READ them (init_flow feeds the first 1/8 down-sampling, the ones map the first mask multiply); callers that
-#      want to write must not ask here. ----
+#      want to write must not ask here.
+#      Lifetime rules: entries are NEVER evicted -- a captured hipGraph holds only the raw pointer of the
+#      tensor it read, so dropping one would hand its memory to the allocator while replays still read it
+#      (``clear_constants`` is explicit and for processes that hold no graph); a constant is never CREATED while a
+#      stream is capturing (its fill would be a node of that graph's private pool and eager callers would be handed an
+#      unfilled tensor from the cache): create it in a warm-up pass; and the creating stream is synchronised once after
+#      the fill, so a consumer on any other stream (side branches, a later capture stream) reads a finished tensor. ----
 _CONSTANTS = {}
 
 
@@ -605,10 +614,19 @@ def constant(shape, value: float, device) -> Tensor:
     key = (str(torch.device(device)), tuple(int(d) for d in shape), float(value))
     t = _CONSTANTS.get(key)
     if t is None:
-        if len(_CONSTANTS) > 64:
-            _CONSTANTS.clear()
-        t = _CONSTANTS[key] = torch.full(key[1], float(value), dtype=torch.float32, device=device)
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.ScflowHipError(
+                f'ops.constant{key[1]}: first use inside a stream capture -- run one eager warm-up pass of the same '
+                f'shapes before capturing (scflow_amd.GraphedRefiner does, warmup >= 1)')
+        t = torch.full(key[1], float(value), dtype=torch.float32, device=device)
+        torch.cuda.current_stream(t.device).synchronize()
+        _CONSTANTS[key] = t
     return t
+
+
+def clear_constants() -> None:
+    """drop the cached constant tensors.  ONLY when no captured graph that read one of them will be replayed again."""
+    _CONSTANTS.clear()
 
 
 # ---- K split across blocks for bias-free conv + GroupNorm blocks on small grids (the pose head's stride-2 layers) ----
@@ -617,20 +635,22 @@ _CONV_KSLICES = True
 
 def set_conv_kslices(on: bool) -> bool:
     """False: ``conv_kslices`` answers 1 (every convolution contracts its whole K inside one block: the r4 arithmetic
-    order); returns the previous setting."""
+    order); returns the previous setting.  Independent of the library's own automatic slicing of small grids
+    (``tune('conv_autoslice', ..)``, which needs a registered workspace and is off unless a caller registers one)."""
     global _CONV_KSLICES
     prev, _CONV_KSLICES = _CONV_KSLICES, bool(on)
-    _lib.load().scf_tune(TUNE_KEYS['conv_autoslice'], int(bool(on)))      # ... and the library's own slicing of small grids
     return prev
 
 
 def conv_kslices(pc: 'PackedConv', n: int, h: int, w: int) -> int:
-    """slice count for ``conv2d(pc, x, kslices=...)`` of a bias-free layer whose consumer adds partial tensors.
+    """WANTED slice count for ``conv2d(pc, x, kslices=...)`` of a bias-free layer whose consumer adds partial tensors
+    (``conv_kslices_for`` = this, checked against the library for the actual tensors).
     A launch with few blocks is a serial chain of one memory round trip per staged channel chunk; S slices are S times
     the blocks and 1 / S of that chain.  Rule from ``tools/lab/kslice_sweep.py`` on the MI355X (kb = blocks of the
     32-channel x 32-pixel tile): kb < 128 -> 4 (11.8 -> 6.1 us, 18.0 -> 8.3), 128 <= kb < 512 -> 2 (4 can tip the
     launch onto the pixel-split tile: 11.9 -> 16.4 us), kb >= 512 -> 4 (64.2 -> 44.6, 31.8 -> 28.4); never more
-    slices than 32-channel chunks."""
+    slices than 32-channel chunks.  NB the count depends on the batch size, so a sample's bits may differ between
+    batch sizes (the partial sums re-associate); ``set_conv_kslices(False)`` is the batch-invariant setting."""
     if not _CONV_KSLICES or pc.bias is not None or pc.scale is not None or (pc.wp4 is None and pc.wp4s is None):
         return 1
     if _CONV_PRECISION == 'f16x3' and pc.wp16 is not None:
@@ -639,6 +659,34 @@ def conv_kslices(pc: 'PackedConv', n: int, h: int, w: int) -> int:
     kb = n * ((ho * wo + 31) // 32) * ((pc.cout + 31) // 32)
     s = 2 if 128 <= kb < 512 else 4
     return max(1, min(s, pc.cin // 32))
+
+
+def conv_kslices_for(pc: 'PackedConv', x0: Tensor, x1: Optional[Tensor] = None) -> int:
+    """``conv_kslices`` validated by the library: an explicit ``k_slices`` launch only exists on the LDS-DMA
+    dispatch, which refuses some layers outright (other strides than 1 / 2, a channel concat that splits a chunk, an
+    ``S`` that leaves a slice without chunks, ...) -- the same layer unsliced would simply have run on another kernel.
+    ``scf_conv2d_query`` is asked with the real descriptor, S halves until it says yes (1 = unsliced always works);
+    the answer is cached per (shape, channel split, S)."""
+    n, _, h, w = x0.shape
+    s = conv_kslices(pc, n, h, w)
+    if s <= 1:
+        return 1
+    c1 = 0 if x1 is None else x1.shape[1]
+    key = ('ks', n, h, w, x0.shape[1], c1, s, _CONV_PRECISION, _CONV_WINOGRAD)
+    if pc.plans is None:
+        pc.plans = {}
+    ok = pc.plans.get(key)
+    if ok is None:
+        lib = _lib.load()
+        info = (C.c_int32 * 4)()
+        ok = s
+        while ok > 1:
+            d, _ = conv2d(pc, x0, x1, kslices=ok, _launch=False)
+            if lib.scf_conv2d_query(C.byref(d), info) == 0:
+                break
+            ok //= 2
+        pc.plans[key] = ok = max(ok, 1)
+    return ok
 
 
 def _gru_passes(packs):
@@ -757,10 +805,11 @@ TUNE_KEYS = {'wino_variant': 1, 'dma_force_ksplit': 2, 'dma_ksplit_groups': 3, '
 
 def tune(key: str, value: int) -> int:
     """measurement knob of the library (``scf_tune``, scflow_hip_prof.h): returns the previous value.
-    ``'wino_variant'``: 0 = the dispatch's choice, 1 = pair kernel, 2 / 3 = quarter-domain kernel (4 / 8 waves);
+    ``'wino_variant'``: 0 = the dispatch's choice, 1 = pair kernel, 2 = quarter-domain kernel (3 / 4 / 5 exist in lab builds
+    of the library only; the product library refuses them);
     ``'wino1d4'``: 1 = F(4, 5) where the dispatch prefers it (default), 0 = never, 2 = on every grid it supports;
     ``'lookup_pipe'``: 0 = the dispatch's choice, 1 = one group per block (r3 kernel), 2 / 3 = pipelined kernel with
-    that many groups per block, 4 / 5 = two / four groups per block (same waves, fewer workgroups).  Unknown keys raise ``ValueError``; a value the library refuses raises
+    that many groups per block, 4 / 5 / 6 = two / four / three groups per block (same waves, fewer workgroups).  Unknown keys raise ``ValueError``; a value the library refuses raises
     ``RuntimeError`` (the return value is always a previous setting, never an error code)."""
     if key not in TUNE_KEYS:
         raise ValueError(f'unknown tune key {key!r}; known: {sorted(TUNE_KEYS)}')

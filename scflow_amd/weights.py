@@ -28,12 +28,14 @@ def _gen(seed: int, key: str) -> torch.Generator:
 
 
 def fill_state_dict(shapes: Mapping[str, Sequence[int]], seed: int = 0,
-                    num_class: int = 21) -> Dict[str, torch.Tensor]:
-    """``shapes``: key -> shape (e.g. ``{k: v.shape for k, v in sd.items()}``)."""
+                    num_class: int = 21, shared_encoder: bool = True) -> Dict[str, torch.Tensor]:
+    """``shapes``: key -> shape (e.g. ``{k: v.shape for k, v in sd.items()}``).
+    ``shared_encoder=False``: ``real_encoder.*`` gets its own values (``seperate_encoder=True``,
+    base_refiner.py:33-35) instead of aliasing ``render_encoder.*``."""
     out: Dict[str, torch.Tensor] = {}
     for key in sorted(shapes):
         shape = tuple(int(s) for s in shapes[key])
-        g = _gen(seed, key.replace('real_encoder.', 'render_encoder.'))  # shared encoder
+        g = _gen(seed, key.replace('real_encoder.', 'render_encoder.') if shared_encoder else key)
         leaf = key.rsplit('.', 1)[-1]
         if leaf == 'num_batches_tracked':
             out[key] = torch.zeros(shape, dtype=torch.long)

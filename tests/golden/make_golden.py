@@ -330,6 +330,67 @@ def main_poseerr():
     print('pose_error.npz')
 
 
+@torch.no_grad()
+def main_options():
+    """round 6: constructor options of the path that the default fixtures do not exercise.
+    * ``pose_math_linear.npz``: ``get_pose_from_delta_pose`` with a depth_transform other than 'exp'
+      (pose.py:139-141) -- pure torch.
+    * ``refiner_options.npz``: the reference refiner with ``seperate_encoder=True`` (two feature
+      encoders with their OWN weights, base_refiner.py:33-35) and the decoder's
+      ``depth_transform='linear'``; N = 2, 2 iterations, 256 x 256.
+    * ``refiner_512x640.npz``: the reference refiner at 512 x 640 with the pose head's
+      ``feat_size=(64, 80)`` (pose_head.py:121,147,162 -- the only SCFlowDecoder route to a large
+      map); N = 1, 2 iterations."""
+    inp = make_inputs(3, 32, 32, seed=5)
+    d_rot = torch.tensor([1., 0., 0., 0., 1., 0.]).repeat(3, 1) + rnd((3, 6), 31, 0.05)
+    d_tr = rnd((3, 3), 32, 0.05)
+    r_new, t_new = get_pose_from_delta_pose(d_rot, d_tr, inp['ref_rotation'], inp['ref_translation'],
+                                            depth_transform='linear', detach_depth_for_xy=True)
+    save('pose_math_linear.npz', STUBS, rot=inp['ref_rotation'], trans=inp['ref_translation'],
+         d_rot=d_rot, d_trans=d_tr, rot_new=r_new, trans_new=t_new)
+
+    names = ['flow_from_pose', 'flow_from_pred', 'rotation', 'translation', 'mask',
+             'delta_rotation', 'delta_translation']
+
+    def run(cfg, n, H, W, iters, seed, shared):
+        model = build_from_cfg(cfg, REFINERS).eval()
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict(fill_state_dict(shapes, seed=0, shared_encoder=shared), strict=True)
+        ii = make_inputs(n, H, W, seed=seed)
+        model.decoder.iters = iters
+        outs = model.get_pose(ii['render_images'], ii['real_images'], ii['ref_rotation'],
+                              ii['ref_translation'], ii['depth'], ii['internel_k'], ii['label'])
+        arrays = {}
+        for nm, seq in zip(names, outs):
+            st = torch.stack(list(seq))
+            if st.dim() == 5:
+                st = st[..., ::4, ::4]
+            arrays[nm] = st
+        return shapes, ii, arrays
+
+    base = dict(runpy.run_path(_refshim.REFERENCE_ROOT + '/configs/refine_models/scflow.py')['model'])
+    base['renderer'] = None
+    base['pose_loss_cfg'] = base['flow_loss_cfg']
+
+    cfg = dict(base, seperate_encoder=True)
+    cfg['decoder'] = dict(cfg['decoder'], depth_transform='linear')
+    shapes, ii, arrays = run(cfg, 2, 256, 256, 2, 31, False)
+    assert not torch.equal(fill_state_dict(shapes, 0, shared_encoder=False)['real_encoder.conv1.weight'],
+                           fill_state_dict(shapes, 0, shared_encoder=False)['render_encoder.conv1.weight'])
+    save('refiner_options.npz', SHIM, iters=2, input_seed=31, weight_seed=0, n=2, label=ii['label'],
+         seperate_encoder=1, depth_transform=np.array('linear'), **arrays)
+
+    cfg = dict(base)
+    cfg['decoder'] = dict(cfg['decoder'])
+    cfg['decoder']['pose_head_cfg'] = dict(cfg['decoder']['pose_head_cfg'], feat_size=(64, 80))
+    shapes, ii, arrays = run(cfg, 1, 512, 640, 2, 33, True)
+    with open(os.path.join(HERE, 'state_dict_keys_512x640.json'), 'w') as f:
+        json.dump({'pinned_under': SHIM,
+                   'shapes': {k: list(v) for k, v in shapes.items() if 'pose_pred.fc_layers.0' in k}}, f, indent=0)
+    save('refiner_512x640.npz', SHIM, iters=2, input_seed=33, weight_seed=0, n=1, label=ii['label'],
+         feat_size=np.array([64, 80]), **arrays)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'poseerr':
         main_poseerr()
@@ -339,5 +400,7 @@ if __name__ == '__main__':
         main_next()
     elif len(sys.argv) > 1 and sys.argv[1] == 'gtflow':
         main_gtflow()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'options':
+        main_options()
     else:
         main()

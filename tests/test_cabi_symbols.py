@@ -64,6 +64,11 @@ def test_tune_knobs_validate_their_values():
         assert ops.tune('wino1d4', 2) == 0
         assert ops.tune('wino1d4', 1) == 2
         assert ops.tune('wino_variant', 0) == 0
+        # r6: the lab-only variants are refused by the product library instead of silently running variant 2;
+        # lookup_pipe = 6 (three groups per block) is documented and accepted
+        assert lib.scf_tune(ops.TUNE_KEYS['wino_variant'], 3) < 0 and lib.scf_tune(ops.TUNE_KEYS['wino_variant'], 4) < 0
+        assert ops.tune('wino_variant', 2) == 0 and ops.tune('wino_variant', 0) == 2
+        assert ops.tune('lookup_pipe', 6) == 0 and ops.tune('lookup_pipe', 0) == 6
         # the lookup knobs (r5): pipelined variant 0..3, store policy 0..5
         assert lib.scf_tune(ops.TUNE_KEYS['lookup_pipe'], 7) < 0 and lib.scf_tune(ops.TUNE_KEYS['lookup_store'], 6) < 0
         assert ops.tune('lookup_pipe', 2) == 0 and ops.tune('lookup_pipe', 0) == 2

@@ -1033,6 +1033,36 @@ def test_pose_update_and_label_quirk(golden_dir):
     close(o1[0], want, atol=0, what='per-sample label mode')
 
 
+def test_pose_update_linear_depth_transform(golden_dir):
+    """pose.py:139-141 (depth_transform other than 'exp'): SCF_POSE_DEPTH_LINEAR, alone and with the per-sample label
+    bit; a bit outside the set is refused."""
+    g = np.load(os.path.join(golden_dir, 'pose_math_linear.npz'))
+    n, nc = 3, 21
+    rot_all, tr_all = rnd((n, nc * 6), 60), rnd((n, nc * 3), 61, 0.05)
+    label = torch.tensor([2, 5, 7])
+    d_rot, d_tr = torch.from_numpy(g['d_rot']), torch.from_numpy(g['d_trans'])
+    for i in range(n):
+        rot_all.view(n, nc, 6)[i, 2] = d_rot[i]                 # label_mode bit 0 clear: class label[0] = 2 for all
+        tr_all.view(n, nc, 3)[i, 2] = d_tr[i]
+    R, t = torch.from_numpy(g['rot']), torch.from_numpy(g['trans'])
+    a = lambda *x: [v.to(DEV) for v in x]
+    o = ops.pose_update(*a(rot_all, tr_all, label), nc, *a(R, t), 2)
+    close(o[2], torch.from_numpy(g['rot_new']), atol=2e-6, what='R (linear)')
+    close(o[3], torch.from_numpy(g['trans_new']), atol=2e-4, what='t (linear)')
+    o_exp = ops.pose_update(*a(rot_all, tr_all, label), nc, *a(R, t), 0)
+    assert float((o_exp[3] - o[3]).abs().max()) > 1e-2
+    # both bits: sample i decoded with class label[i], linear depth
+    for i in range(n):
+        rot_all.view(n, nc, 6)[i, int(label[i])] = d_rot[i]
+        tr_all.view(n, nc, 3)[i, int(label[i])] = d_tr[i]
+        if i:
+            tr_all.view(n, nc, 3)[i, 2] = 9.0                   # poison what label[0] would select
+    o3 = ops.pose_update(*a(rot_all, tr_all, label), nc, *a(R, t), 3)
+    close(o3[3], torch.from_numpy(g['trans_new']), atol=2e-4, what='t (linear, per-sample label)')
+    with pytest.raises(Exception):
+        ops.pose_update(*a(rot_all, tr_all, label), nc, *a(R, t), 4)
+
+
 def test_reproject_and_unproject(golden_dir):
     g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, 'pose_math.npz')).items()
          if v.dtype.kind == 'f'}

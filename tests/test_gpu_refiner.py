@@ -616,3 +616,136 @@ def test_same_pair_at_batch_1_and_batch_32(golden_dir, model):
     assert worst <= 1e-3
     close(full[2][-1][:1], alone[2][-1].cpu(), atol=2e-5, what='rotation: batch 32 vs batch 1')
     close(full[3][-1][:1], alone[3][-1].cpu(), atol=1e-2, rtol=2e-5, what='translation (mm): batch 32 vs batch 1')
+
+
+# ------------------------------------------------------------------------------------------------
+# round 6: constructor options of the reference path (VERDICT r5 "missing" 2 / 3)
+# ------------------------------------------------------------------------------------------------
+_NAMES = ['flow_from_pose', 'flow_from_pred', 'rotation', 'translation', 'mask', 'delta_rotation', 'delta_translation']
+
+
+def _vs_fixture_and_oracle(model, g, inp, want, tol, what):
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    got = model.get_pose(d['render_images'], d['real_images'], d['ref_rotation'], d['ref_translation'], d['depth'],
+                         d['internel_k'], d['label'])
+    for nm, seq in zip(_NAMES, got):
+        st = torch.stack(list(seq))
+        if g is not None:
+            close(st[..., ::4, ::4] if st.dim() == 5 else st, g[nm], atol=tol[nm], what=f'{what} vs reference fixture: {nm}')
+    valid = inp['depth'] > 0
+    for it in range(len(got[0])):
+        epe_pose = oracle.end_point_error(got[0][it].cpu(), want[0][it], valid)
+        epe_pred = oracle.end_point_error(got[1][it].cpu(), want[1][it])
+        print(f'[measured] {what} iter {it}: EPE vs oracle {epe_pose:.2e} / {epe_pred:.2e} px')
+        assert epe_pose <= 1e-3 and epe_pred <= 1e-3, f'{what} iter {it}: EPE {epe_pose:.2e} / {epe_pred:.2e}'
+    return got
+
+
+def test_separate_encoders_and_linear_depth_transform(golden_dir):
+    """``seperate_encoder=True`` (base_refiner.py:33-35: render / real encoders with their OWN weights -- the two-pass
+    branch of ``extract_feat``) + the decoder's ``depth_transform='linear'`` (pose.py:139-141): N = 2, 2 iterations,
+    against the reference built with exactly these options (refiner_options.npz) and against the oracle."""
+    g = _g(golden_dir, 'refiner_options.npz')
+    cfg = scflow_amd.scflow_model_cfg()
+    cfg['seperate_encoder'] = True
+    cfg['decoder']['depth_transform'] = 'linear'
+    m = scflow_amd.build_refiner(cfg)
+    assert m.render_encoder is not m.real_encoder
+    sd = scflow_amd.fill_state_dict(_shapes(golden_dir), seed=0, shared_encoder=False)
+    assert not torch.equal(sd['real_encoder.conv1.weight'], sd['render_encoder.conv1.weight'])
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    iters = int(g['iters'])
+    m.decoder.iters = iters
+    inp = scflow_amd.make_inputs(int(g['n']), 256, 256, seed=int(g['input_seed']))
+    import bench
+    torch.set_num_threads(bench.host_cores())
+    with torch.no_grad():
+        want = oracle.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'], inp['ref_translation'],
+                               inp['depth'], inp['internel_k'], inp['label'], sd, iters=iters, depth_transform='linear')
+    tol = dict(flow_from_pose=3e-4, flow_from_pred=2.5e-4, rotation=6e-7, translation=1e-3, mask=6e-6,
+               delta_rotation=4e-7, delta_translation=8e-7)
+    _vs_fixture_and_oracle(m, g, inp, want, tol, 'separate encoders + linear depth')
+    # the option is live: the 'exp' decoder gives another translation on the same weights
+    cfg['decoder']['depth_transform'] = 'exp'
+    m2 = scflow_amd.build_refiner(cfg)
+    m2.load_state_dict(sd, strict=True)
+    m2 = m2.to(DEV)
+    m2.decoder.iters = iters
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    other = m2.get_pose(d['render_images'], d['real_images'], d['ref_rotation'], d['ref_translation'], d['depth'],
+                        d['internel_k'], d['label'])
+    assert float((other[3][-1].cpu() - g['translation'][-1]).abs().max()) > 1e-2
+
+
+def test_scflow_512x640_with_feat_size(golden_dir):
+    """SCFlow at 512 x 640 with the pose head's ``feat_size=(64, 80)`` (pose_head.py:121,147,162; fc1 = 10240 -> 1024):
+    the only SCFlowDecoder route to a large map.  N = 1, 2 iterations, against the reference fixture and
+    the oracle; without feat_size the same map is refused loudly."""
+    g = _g(golden_dir, 'refiner_512x640.npz')
+    shapes = dict(_shapes(golden_dir))
+    shapes.update(json.load(open(os.path.join(golden_dir, 'state_dict_keys_512x640.json')))['shapes'])
+    cfg = scflow_amd.scflow_model_cfg()
+    cfg['decoder']['pose_head_cfg']['feat_size'] = (64, 80)
+    m = scflow_amd.build_refiner(cfg)
+    sd = scflow_amd.fill_state_dict(shapes, seed=0)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    iters = int(g['iters'])
+    m.decoder.iters = iters
+    inp = scflow_amd.make_inputs(1, 512, 640, seed=int(g['input_seed']))
+    import bench
+    torch.set_num_threads(bench.host_cores())
+    with torch.no_grad():
+        want = oracle.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'], inp['ref_translation'],
+                               inp['depth'], inp['internel_k'], inp['label'], sd, iters=iters)
+    tol = dict(flow_from_pose=4e-4, flow_from_pred=3e-4, rotation=6e-7, translation=1e-3, mask=6e-6,
+               delta_rotation=4e-7, delta_translation=8e-7)
+    _vs_fixture_and_oracle(m, g, inp, want, tol, 'SCFlow 512x640')
+    plain = scflow_amd.build_refiner(scflow_amd.scflow_model_cfg()).to(DEV)
+    plain.decoder.iters = 1
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    with pytest.raises(Exception):          # fc1 expects 2048 features, the 8 x 10 maps give 10240 (the reference raises too)
+        plain.get_pose(d['render_images'], d['real_images'], d['ref_rotation'], d['ref_translation'], d['depth'],
+                       d['internel_k'], d['label'])
+
+
+@pytest.mark.parametrize('n', [3, 32])
+def test_label_mode_per_sample(golden_dir, model, n):
+    """``pose_pred.label_mode = 1``: sample n is decoded with class label[n].  Mixed labels,
+    N = 3 and N = 32 (other tiles / K slices): the pose head alone against oracle.multiclass_pose_head(label_mode=1),
+    then two refinement iterations end to end against oracle.get_pose(label_mode=1); mode 0 on the same inputs stays
+    the reference's label[0] decoding and differs."""
+    sd = scflow_amd.fill_state_dict(_shapes(golden_dir), seed=0)
+    inp = scflow_amd.make_inputs(n, 256, 256, seed=40 + n)
+    assert len(set(inp['label'].tolist())) > 1
+    head = model.decoder.pose_pred
+    x = torch.randn((n, 224, 32, 32), generator=torch.Generator().manual_seed(5))
+    want_r, want_t = oracle.multiclass_pose_head(x, inp['label'], sd, 'decoder.pose_pred.', label_mode=1)
+    ref_r, _ = oracle.multiclass_pose_head(x, inp['label'], sd, 'decoder.pose_pred.')
+    iters0 = model.decoder.iters
+    try:
+        head.label_mode = 1
+        r, t = head(x.to(DEV), inp['label'].to(DEV))
+        close(r, want_r, atol=1e-6, what=f'pose head rot, label_mode 1, N={n}')
+        close(t, want_t, atol=1e-6, what=f'pose head trans, label_mode 1, N={n}')
+        assert float((r.cpu() - ref_r).abs().max()) > 1e-4
+        iters = 2
+        model.decoder.iters = iters
+        import bench
+        torch.set_num_threads(bench.host_cores())       # the box: 256 logical CPUs behind a 16-CPU quota
+        with torch.no_grad():
+            want = oracle.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'], inp['ref_translation'],
+                                   inp['depth'], inp['internel_k'], inp['label'], sd, iters=iters, label_mode=1)
+        got = _vs_fixture_and_oracle(model, None, inp, want, None, f'label_mode 1, N={n}')
+        close(got[5][-1], want[5][-1], atol=2e-6, what='delta rotation (per-sample class)')
+        close(got[2][-1], want[2][-1], atol=2e-5, what='rotation')
+        close(got[3][-1], want[3][-1], atol=1e-2, rtol=2e-5, what='translation (mm)')
+        head.label_mode = 0
+        d = {k: v.to(DEV) for k, v in inp.items()}
+        quirk = model.get_pose(d['render_images'], d['real_images'], d['ref_rotation'], d['ref_translation'], d['depth'],
+                               d['internel_k'], d['label'])
+        assert float((quirk[5][-1] - got[5][-1]).abs().max()) > 1e-4
+    finally:
+        head.label_mode = 0
+        model.decoder.iters = iters0

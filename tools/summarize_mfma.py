@@ -71,6 +71,11 @@ out = {'tag': tag, 'source': 'rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_C
        'all_matrix_kernels': {'total_us': round(tot, 1),
                               'mfma_busy_vs_chip_peak': round(busy_tot / (SIMDS * tot * 1e-6 * PEAK_HZ), 4)},
        'kernels': rows}
+import os as _os
+import sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+import bench as _bench      # kernel_source_hashes: bench.py attaches this summary only while these files are unchanged
+out['kernel_source_hashes'] = _bench.kernel_source_hashes(_bench.CONV_SOURCES)
 json.dump(out, open(out_json, 'w'), indent=1)
 print(f"{'kernel':70s} {'n':>5s} {'mean us':>9s} {'MFMA busy / chip peak':>22s} {'/ active clk':>12s} {'clk GHz':>8s}")
 for r in rows:

@@ -121,5 +121,10 @@ if stats_csv:
                                                'min_us': round(float(r['MinNs']) / 1e3, 2),
                                                'max_us': round(float(r['MaxNs']) / 1e3, 2),
                                                'note': 'all launches of the kernel in the traced run (batch-32 steps AND the configs[4] block)'}
+import os as _os
+import sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+import bench as _bench      # kernel_source_hashes: bench.py attaches this summary only while these files are unchanged
+out['kernel_source_hashes'] = _bench.kernel_source_hashes(_bench.LOOKUP_SOURCES)
 json.dump(out, open(out_json, 'w'), indent=1)
 print(json.dumps(out, indent=1))
