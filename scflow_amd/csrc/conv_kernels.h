@@ -264,6 +264,46 @@ __device__ __forceinline__ void scf_conv_epilogue_tile(const ConvK& p, const Con
   // tile is issued BEFORE the first store.  Loads and stores share the in-order vmcnt counter on
   // gfx9, so a bias load issued after a store cannot be consumed until that store has been
   // acknowledged by memory (~2k cycles) -- per 4-row group in the generic path below.
+  // r6: the same schedule for the transcendental activations and for a split at a fragment boundary (the context
+  // encoder's head: tanh | relu at channel 128, raft_encoder.py / scflow_refiner.py:104-110) -- the activation is then
+  // uniform per 32-channel fragment and runs on the hardware exp / rcp units (scf_fast_tanh / scf_fast_sigmoid, |error|
+  // <= 3e-7).  On the per-group generic path below (libm tanhf, a store-acknowledge wait per 4 rows) that launch cost
+  // 54 us against 29 us for the same layer with a plain epilogue (tools/lab/r6_quick.py ctxsplit).
+  if (kind == SCF_EPI_GENERAL && !e.res && !p.scale && !use_div && m0 + WM * 32 <= p.Cout &&
+      ((uintptr_t)p.bias & 15) == 0 && (p.act_split <= 0 || (p.act_split & 31) == 0)) {
+    scf_f32x4 bv[WM][4];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        bv[i][g] = p.bias ? *reinterpret_cast<const scf_f32x4*>(p.bias + m0 + i * 32 + 8 * g + 4 * half)
+                          : scf_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      if (pix[j] < 0) continue;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int a = (p.act_split > 0 && m0 + i * 32 >= p.act_split) ? p.act2 : p.act;      // wave-uniform
+        float* o = e.out + (m0 + i * 32 + 4 * half) * e.HWo + pix[j];
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv[i][r >> 2][r & 3];
+        if (a == SCF_ACT_TANH) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = scf_fast_tanh(v[r]);
+        } else if (a == SCF_ACT_SIGMOID) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = scf_fast_sigmoid(v[r]);
+        } else if (a == SCF_ACT_RELU) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scf_store1<(SCF_ST_SC1 & 4) != 0>(o + (8 * (r >> 2) + (r & 3)) * e.HWo, v[r]);
+      }
+    }
+    return;
+  }
   if (kind == SCF_EPI_AFFINE && !e.res && !p.scale && p.act_split <= 0 && !use_div &&
       m0 + WM * 32 <= p.Cout && ((uintptr_t)p.bias & 15) == 0) {
     scf_f32x4 bv[WM][4];
