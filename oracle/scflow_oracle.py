@@ -166,14 +166,19 @@ def motion_encoder(corr: Tensor, flow: Tensor, sd: SD, p: str) -> Tensor:
 
 
 def sepconv_gru(h: Tensor, x: Tensor, sd: SD, p: str) -> Tensor:
-    """decoder/raft_decoder.py:235-253 'SeqConv': pass 0 uses (1,5)/pad(0,2)
-    kernels, pass 1 (5,1)/pad(2,0) (:180-181)."""
-    for i, pad in enumerate(((0, 2), (2, 0))):
+    """decoder/raft_decoder.py:235-253.  'SeqConv': pass 0 uses (1,5)/pad(0,2)
+    kernels, pass 1 (5,1)/pad(2,0) (:180-181); 'Conv': one pass of 3x3/pad 1.  The
+    passes and their 'same' paddings are read off the state dict (conv_z.{i} shapes)."""
+    i = 0
+    while f'{p}conv_z.{i}.conv.weight' in sd:
+        kh, kw = sd[f'{p}conv_z.{i}.conv.weight'].shape[-2:]
+        pad = (kh // 2, kw // 2)
         hx = torch.cat([h, x], dim=1)
         z = conv_act(hx, sd, f'{p}conv_z.{i}', padding=pad, act='sigmoid')
         r = conv_act(hx, sd, f'{p}conv_r.{i}', padding=pad, act='sigmoid')
         q = conv_act(torch.cat([r * h, x], dim=1), sd, f'{p}conv_q.{i}', padding=pad, act='tanh')
         h = (1 - z) * h + z * q
+        i += 1
     return h
 
 
@@ -356,7 +361,7 @@ def get_pose(render_images: Tensor, real_images: Tensor, ref_rotation: Tensor,
              ref_translation: Tensor, depth: Tensor, internel_k: Tensor, label: Tensor,
              sd: SD, *, iters: int = 8, init_flow: Tensor | None = None,
              mask_flow: bool = False, mask_corr: bool = False,
-             depth_transform: str = 'exp', label_mode: int = 0):
+             depth_transform: str = 'exp', label_mode: int = 0, radius: int = 4):
     """refiner/scflow_refiner.py:112-142 ``SCFlowRefiner.get_pose``
     (invalid_flow_num = 0 at inference, :142); ``mask_flow`` / ``mask_corr``: the decoder's
     constructor switches (scflow_decoder.py:199-205, both False in configs/refine_models/scflow.py)."""
@@ -366,7 +371,7 @@ def get_pose(render_images: Tensor, real_images: Tensor, ref_rotation: Tensor,
         init_flow = torch.zeros((n, 2, H, W), dtype=torch.float32)
     return scflow_decoder(fr, fl, h, c, ref_rotation, ref_translation, depth, internel_k,
                           label, init_flow, sd, iters=iters, invalid_flow_num=0.,
-                          mask_flow=mask_flow, mask_corr=mask_corr,
+                          mask_flow=mask_flow, mask_corr=mask_corr, radius=radius,
                           depth_transform=depth_transform, label_mode=label_mode)
 
 

@@ -340,7 +340,8 @@ def main_options():
       ``depth_transform='linear'``; N = 2, 2 iterations, 256 x 256.
     * ``refiner_512x640.npz``: the reference refiner at 512 x 640 with the pose head's
       ``feat_size=(64, 80)`` (pose_head.py:121,147,162 -- the only SCFlowDecoder route to a large
-      map); N = 1, 2 iterations."""
+      map); N = 1, 2 iterations.
+    * ``refiner_conv_gru_r3.npz``: decoder ``gru_type='Conv'`` and ``radius=3``; N = 2, 2 iterations."""
     inp = make_inputs(3, 32, 32, seed=5)
     d_rot = torch.tensor([1., 0., 0., 0., 1., 0.]).repeat(3, 1) + rnd((3, 6), 31, 0.05)
     d_tr = rnd((3, 3), 32, 0.05)
@@ -379,6 +380,16 @@ def main_options():
                            fill_state_dict(shapes, 0, shared_encoder=False)['render_encoder.conv1.weight'])
     save('refiner_options.npz', SHIM, iters=2, input_seed=31, weight_seed=0, n=2, label=ii['label'],
          seperate_encoder=1, depth_transform=np.array('linear'), **arrays)
+
+    # the non-separable GRU (gru_type='Conv': one pass of 3x3 gates, raft_decoder.py:178-181) on a radius-3 lookup
+    # (4 x 49 = 196 correlation channels into the motion encoder)
+    cfg = dict(base)
+    cfg['decoder'] = dict(cfg['decoder'], gru_type='Conv', radius=3)
+    shapes, ii, arrays = run(cfg, 2, 256, 256, 2, 35, True)
+    with open(os.path.join(HERE, 'state_dict_keys_conv_gru_r3.json'), 'w') as f:
+        json.dump({'pinned_under': SHIM, 'shapes': {k: list(v) for k, v in shapes.items()}}, f, indent=0)
+    save('refiner_conv_gru_r3.npz', SHIM, iters=2, input_seed=35, weight_seed=0, n=2, label=ii['label'],
+         gru_type=np.array('Conv'), radius=3, **arrays)
 
     cfg = dict(base)
     cfg['decoder'] = dict(cfg['decoder'])

@@ -710,6 +710,32 @@ def test_scflow_512x640_with_feat_size(golden_dir):
                        d['internel_k'], d['label'])
 
 
+def test_conv_gru_and_radius3(golden_dir):
+    """decoder ``gru_type='Conv'`` (the non-separable GRU: one pass of 3x3 gate convolutions, raft_decoder.py:178-181) on a
+    ``radius=3`` lookup (4 x 49 = 196 correlation channels: the radius-generic lookup kernel and a 196 -> 256 1x1): N = 2,
+    2 iterations against the reference built with these options and against the oracle."""
+    g = _g(golden_dir, 'refiner_conv_gru_r3.npz')
+    shapes = json.load(open(os.path.join(golden_dir, 'state_dict_keys_conv_gru_r3.json')))['shapes']
+    cfg = scflow_amd.scflow_model_cfg()
+    cfg['decoder']['gru_type'] = 'Conv'
+    cfg['decoder']['radius'] = 3
+    m = scflow_amd.build_refiner(cfg)
+    sd = scflow_amd.fill_state_dict(shapes, seed=0)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    iters = int(g['iters'])
+    m.decoder.iters = iters
+    inp = scflow_amd.make_inputs(int(g['n']), 256, 256, seed=int(g['input_seed']))
+    import bench
+    torch.set_num_threads(bench.host_cores())
+    with torch.no_grad():
+        want = oracle.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'], inp['ref_translation'],
+                               inp['depth'], inp['internel_k'], inp['label'], sd, iters=iters, radius=3)
+    tol = dict(flow_from_pose=3e-4, flow_from_pred=2.5e-4, rotation=6e-7, translation=1e-3, mask=6e-6,
+               delta_rotation=4e-7, delta_translation=8e-7)
+    _vs_fixture_and_oracle(m, g, inp, want, tol, 'Conv GRU, radius 3')
+
+
 @pytest.mark.parametrize('n', [3, 32])
 def test_label_mode_per_sample(golden_dir, model, n):
     """``pose_pred.label_mode = 1``: sample n is decoded with class label[n].  Mixed labels,

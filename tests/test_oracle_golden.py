@@ -214,6 +214,14 @@ def test_refiner_512x640_feat_size(golden_dir):
     _refiner_fixture(golden_dir, 'refiner_512x640.npz', keys, 512, 640)
 
 
+def test_refiner_conv_gru_radius3(golden_dir):
+    """decoder gru_type='Conv' (one pass of 3x3 gates, raft_decoder.py:178-181) + radius=3 (196 correlation channels)."""
+    keys = json.load(open(os.path.join(golden_dir, 'state_dict_keys_conv_gru_r3.json')))['shapes']
+    assert keys['decoder.gru.conv_z.0.conv.weight'] == [128, 384, 3, 3] and 'decoder.gru.conv_z.1.conv.weight' not in keys
+    assert keys['decoder.encoder.corr_net.0.conv.weight'][1] == 4 * 49
+    _refiner_fixture(golden_dir, 'refiner_conv_gru_r3.npz', keys, 256, 256, radius=3)
+
+
 def test_label_mode_per_sample_is_index_select_done_right(golden_dir):
     """oracle.multiclass_pose_head(label_mode=1) -- NOT the reference -- decodes sample n with class label[n]:
     equal, row by row, to the reference path called with that sample's label for the whole batch."""
