@@ -87,24 +87,30 @@ void fc_splitk_kernel(FcK p) {
     xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n0 + r < p.N && 4 * c4 < Ks) xv[i] = *reinterpret_cast<const float4*>(p.x + (long long)(n0 + r) * p.K + ks0 + 4 * c4);
   }
-  // the producer's other partial buffers, in slice order (two slices of loads in flight)
-  for (int s = 1; s < p.parts; s += 2) {
-    float4 u0[NLD], u1[NLD];
-    const bool two = s + 1 < p.parts;
+  // the producer's other partial buffers, added in slice order.  r6: FOUR slices of loads in flight per round trip (two
+  // before): a launch of this kernel is a chain of memory round trips and nothing else -- fc2 reads fc1's eight slices
+  // (four round trips -> two), the heads fc2's four (two -> one), fc1 a K-sliced convolution's two or four (-> one).
+  // The adds keep their order (slice s, s + 1, s + 2, s + 3), so the sums keep their bits.
+  for (int s = 1; s < p.parts; s += 4) {
+    float4 u[4][NLD];
+    const int left = p.parts - s;                 // 1 ... : slices s .. s + min(left, 4) - 1 exist
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int e = tid + 256 * i, r = e / KQ, c4 = e - r * KQ;
-      u0[i] = u1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n0 + r < p.N && 4 * c4 < Ks) {
-        const float* xp = p.x + (long long)(n0 + r) * p.K + ks0 + 4 * c4 + (long long)s * p.part_stride;
-        u0[i] = *reinterpret_cast<const float4*>(xp);
-        if (two) u1[i] = *reinterpret_cast<const float4*>(xp + p.part_stride);
+      const bool in = n0 + r < p.N && 4 * c4 < Ks;
+      const float* xp = p.x + (long long)(n0 + r) * p.K + ks0 + 4 * c4 + (long long)s * p.part_stride;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in && j < left) u[j][i] = *reinterpret_cast<const float4*>(xp + (long long)j * p.part_stride);
       }
     }
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      xv[i].x += u0[i].x; xv[i].y += u0[i].y; xv[i].z += u0[i].z; xv[i].w += u0[i].w;
-      if (two) { xv[i].x += u1[i].x; xv[i].y += u1[i].y; xv[i].z += u1[i].z; xv[i].w += u1[i].w; }
+    for (int j = 0; j < 4; ++j) {
+      if (j < left) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) { xv[i].x += u[j][i].x; xv[i].y += u[j][i].y; xv[i].z += u[j][i].z; xv[i].w += u[j][i].w; }
+      }
     }
   }
 #pragma unroll
