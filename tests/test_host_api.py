@@ -100,6 +100,25 @@ def test_unsupported_options_fail_loudly():
     x = torch.zeros(1, 3, 64, 64)
     with pytest.raises(scflow_amd._lib.ScflowHipError):
         model.extract_feat(x, x)               # CPU tensors: no fallback
+    # r6: options that are built now construct (pose.py:137-141, base_refiner.py:33-35, pose_head.py:121-162,
+    # raft_decoder.py:178-181); what still needs the renderer / kornia refuses with the reason
+    cfg = scflow_amd.scflow_model_cfg()
+    cfg['seperate_encoder'] = True
+    cfg['decoder'].update(depth_transform='linear', gru_type='Conv', radius=3)
+    cfg['decoder']['pose_head_cfg']['feat_size'] = (64, 80)
+    m = scflow_amd.build_refiner(cfg)
+    assert m.render_encoder is not m.real_encoder and m.decoder.pose_flags() == 2
+    assert m.decoder.pose_pred.fc_layers[0][0].in_features == 128 * 80
+    m.decoder.pose_pred.label_mode = 1
+    assert m.decoder.pose_flags() == 3
+    cfg = scflow_amd.scflow_model_cfg()
+    cfg['test_cfg'] = dict(iters=8, cycles=2)                  # re-rendering between cycles: base_refiner.py:250-258
+    with pytest.raises(NotImplementedError, match='cycles'):
+        scflow_amd.build_refiner(cfg).forward(dict(), None)
+    cfg = scflow_amd.scflow_model_cfg()
+    cfg['decoder']['pose_head_cfg']['rotation_mode'] = 'quaternion'       # kornia branch, pose.py:132-133
+    with pytest.raises(NotImplementedError):
+        scflow_amd.build_refiner(cfg)
 
 
 def test_checkpoint_ingestion(tmp_path, golden_dir):
