@@ -591,7 +591,15 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
         _CONV_EVENTS.append((tm, 2.0 * pc.cin * pc.kh * pc.kw * pc.cout * ho * wo * n,
                              f'{pc.cin}->{pc.cout} {pc.kh}x{pc.kw}/s{pc.stride} @{ho}x{wo} N{n}' + tag))
         return out
-    _lib.check(_lib.load().scf_conv2d(C.byref(d), _stream()), 'scf_conv2d')
+    rc = _lib.load().scf_conv2d(C.byref(d), _stream())
+    if rc == -2 and x1 is not None and sliced is None:
+        # SCF_EUNSUPPORTED with two input segments: every kernel needs the segment boundary on a channel-chunk boundary
+        # (C0 % 8 / 16 / 32 == 0 by packing) -- a layer of the path never violates it, an arbitrary caller may (found by
+        # tools/lab/conv_fuzz.py: 1x1 layers with C0 = 8 / 16).  Materialise the concatenation once and run the same
+        # layer on one segment: still the HIP kernels, one extra copy.
+        return conv2d(pc, torch.cat([x0, x1], 1), None, out, res=res, act=act, act2=act2, act_split=act_split, mode=mode,
+                      gru_h=gru_h, gru_aux=gru_aux, gru_z=gru_z)
+    _lib.check(rc, 'scf_conv2d')
     return out
 
 
