@@ -191,3 +191,10 @@ def test_conv2d_two_segments_off_chunk_boundary(n, cin, cout, c0, hw):
     want = torch.relu(F.conv2d(x, w, b))
     assert float((got.cpu() - want).abs().max()) <= 2e-5
     assert torch.equal(got, ops.conv2d(pc, xd, act=ops.ACT_RELU))
+
+
+@pytest.mark.parametrize('seed', [31, 32])
+def test_convgru_random_sweep(seed):
+    """40 random ConvGRU cells per seed (state 32..128, input 32..258 channels, both GRU types, maps 4..80 wide, with / without
+    the hoisted context term) through scf_sepconv_gru[_ctx] against the oracle (tools/lab/gru_fuzz.py; 150 cases ran clean)."""
+    assert _lab('gru_fuzz').run(40, seed, verbose=False) == 0
