@@ -789,3 +789,38 @@ def test_batch_sizes_between_the_pinned_ones(n):
     spec.loader.exec_module(mod)
     worst = mod.run([n], verbose=False)
     print(f'[measured] batch {n}: worst per-pair EPE vs oracle {worst:.2e} px')
+
+
+def test_edge_case_inputs_vs_oracle(golden_dir, model):
+    """inputs at the edges of what the pose-induced flow step handles (pose.py:44-88): a sample with NO foreground pixel
+    (depth == 0 everywhere: its flow_from_pose is the invalid number everywhere, the pose head still runs), a sample whose
+    object covers the WHOLE frame, the last class id, and a non-zero initial flow -- against the oracle, 2 iterations."""
+    sd = scflow_amd.fill_state_dict(_shapes(golden_dir), seed=0)
+    inp = scflow_amd.make_inputs(3, 256, 256, seed=77)
+    inp['depth'][1] = 0.0
+    inp['depth'][2] = 700.0 + 50.0 * torch.rand((256, 256), generator=torch.Generator().manual_seed(3))
+    inp['label'] = torch.tensor([20, 0, 20])
+    init_flow = 2.0 * torch.randn((3, 2, 256, 256), generator=torch.Generator().manual_seed(4))
+    import bench
+    torch.set_num_threads(bench.host_cores())
+    iters0 = model.decoder.iters
+    model.decoder.iters = 2
+    try:
+        with torch.no_grad():
+            want = oracle.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'], inp['ref_translation'],
+                                   inp['depth'], inp['internel_k'], inp['label'], sd, iters=2, init_flow=init_flow.clone())
+        d = {k: v.to(DEV) for k, v in inp.items()}
+        got = model.get_pose(d['render_images'], d['real_images'], d['ref_rotation'], d['ref_translation'], d['depth'],
+                             d['internel_k'], d['label'], init_flow=init_flow.to(DEV))
+    finally:
+        model.decoder.iters = iters0
+    for it in range(2):
+        assert float(got[0][it][1].abs().max()) == 0.0                       # no foreground: invalid_flow_num = 0 everywhere
+        for s_ in range(3):
+            e0 = float((got[0][it][s_].cpu() - want[0][it][s_]).abs().max())
+            e1 = float((got[1][it][s_].cpu() - want[1][it][s_]).abs().max())
+            print(f'[measured] edge inputs iter {it} sample {s_}: max |d flow_from_pose| {e0:.2e}, |d flow_from_pred| {e1:.2e} px')
+            assert e0 <= 2e-3 and e1 <= 1e-3
+    close(got[2][-1], want[2][-1], atol=2e-5, what='rotation (edge inputs)')
+    close(got[3][-1], want[3][-1], atol=1e-2, rtol=2e-5, what='translation (edge inputs)')
+    close(got[4][-1], want[4][-1], atol=2e-4, what='mask (edge inputs)')
