@@ -115,7 +115,12 @@ def _opt(t: Optional[Tensor], name: str) -> Optional[int]:
 _SIDE = {}      # (device, main stream handle) -> that stream's side stream
 
 
-OVERLAP_BRANCHES = {'context', 'flow', 'mask', 'upsample'}      # tools/lab switches these off one by one
+# r6 (tools/lab/b1_branches.py, every subset of the four branches as hipGraph replays, profiles/r6_b1_branch_subsets.txt): a
+# replay pays ~1.2 us per NODE as soon as the graph holds a real parallel branch (0.33-0.36 ms at 285 nodes, whatever the number
+# of fork / join edges: tools/lab/graph_fork_penalty.py), each branch then buys 0.16-0.17 ms back -- except 'upsample' (the two
+# full-resolution outputs beside the pose head), which costs 0.05 ms more than it saves: off by default since r6 (batch 1:
+# 2.71 -> 2.65 ms, batch 2: 3.25 -> 3.20, batch 4: 4.33 -> 4.30).
+OVERLAP_BRANCHES = {'context', 'flow', 'mask'}      # + 'upsample': tools/lab switches these on / off one by one
 OVERLAP_MAX_PIXELS = {'context': 4 * 256 * 256, 'flow': 4 * 256 * 256, 'mask': 4 * 256 * 256, 'upsample': 4 * 256 * 256}
 
 
