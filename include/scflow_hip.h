@@ -55,7 +55,7 @@ enum {
  * SCF_ABI_MAJOR before its first call; structs additionally carry no size field,
  * so a mismatch must be refused, not worked around. */
 #define SCF_ABI_MAJOR 5
-#define SCF_VERSION (SCF_ABI_MAJOR * 100 + 1)   /* .1: label_mode is a bit set (SCF_POSE_*) */
+#define SCF_VERSION (SCF_ABI_MAJOR * 100 + 2)   /* .1: label_mode is a bit set (SCF_POSE_*); .2: scf_conv2d_pair, overlap_* = 2 */
 int scf_version(void);
 const char* scf_error_string(int code);
 /* number of HIP devices visible (>=0) or SCF_ENODEVICE */
@@ -214,6 +214,13 @@ int scf_conv2d(const scf_conv_desc* desc, scf_stream_t stream);
  * The registry is keyed by the raw stream handle: clear the entry (ptr = NULL) BEFORE destroying the stream, a later
  * stream that gets the same handle would inherit it. */
 int scf_conv_workspace(scf_stream_t stream, float* ptr, int64_t floats);
+
+/* r6: two INDEPENDENT convolutions (no data flows between them) as ONE launch where both fall to the same small-grid kernel
+ * instantiation (the K-split LDS-DMA tile, the thin-input kernel): blocks [0, nA) run a, the rest b.  Sub-chip grids
+ * (batch 1-4: a layer is 8-64 blocks on 256 CUs) then run side by side without a second stream -- on this runtime a hipGraph
+ * replay pays ~1.2 us per node once the graph holds a parallel branch.  Any other pair: the two launches one after the
+ * other.  Results are those of scf_conv2d(a) and scf_conv2d(b), bit for bit, in both cases. */
+int scf_conv2d_pair(const scf_conv_desc* a, const scf_conv_desc* b, scf_stream_t stream);
 
 /* Host-side weight packers (plain CPU loops, run once per checkpoint): w is a HOST pointer to a
  * contiguous (Cout, Cin, KH, KW) fp32 tensor -- a torch Conv2d weight as stored in the reference's

@@ -74,6 +74,8 @@ enum {
                                  re-projection), 0 = one launch each (the r4 sequence; same results) */
   SCF_TUNE_WINO1D4_HALF = 9,  /* F(4, 5): 1 = half-domain kernel (a wave holds 4 of the 8 positions for two channel fragments: half the
                                  input-transform work per MFMA, one exchange per block), 0 (default) = the full-domain kernel */
+  SCF_TUNE_CONV_PAIR = 10,    /* scf_conv2d_pair: 0 (default) = one launch when both layers take the same small-grid instantiation and their
+                                 grids are resident on the chip together, 1 = always two launches */
   SCF_TUNE_LOOKUP_PIPE = 5    /* correlation lookup: 0 = the dispatch's own choice, 1 = one group of 32 queries per block (the r3
                                  kernel), 2 / 3 = the pipelined kernel with two / three groups per block wherever it fits,
                                  4 / 5 / 6 = two / four / three groups per 512- / 1024- / 768-thread block (same waves, fewer

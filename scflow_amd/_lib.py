@@ -157,6 +157,7 @@ SIGNATURES = {
     'scf_timer_arm': (C.c_int, [_fp]),
     'scf_timer_elapsed_us': (C.c_int, [_fp, C.POINTER(C.c_float)]),
     'scf_conv2d': (C.c_int, [C.POINTER(ConvDesc), _fp]),
+    'scf_conv2d_pair': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _fp]),
     'scf_conv2d_query': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int32)]),
     'scf_tune': (C.c_int, [C.c_int, C.c_int]),
     'scf_conv_log_enable': (C.c_int, [C.c_int]),

@@ -125,8 +125,10 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) { scf_wait_vmcnt_le(n); }
 //         double buffer, so a block's serial chain of "one memory round trip per chunk" is 1 / NG as long -- the
 //         split of K across more waves of the SAME block (the partial sums already meet in LDS at the end), for
 //         grids with at most one block per CU (batch 1: a launch was 8 ... 16 such round trips whatever it computed).
+// The kernel's body as a function of (its arguments, its block index, its grid size): conv_dma_kernel runs it with the launch's
+// own blockIdx / gridDim, conv_dma_pair_kernel (r6, below) runs TWO independent layers' grids in one launch.
 template <int WM, int WN, int NST = 2, bool KSP = false, bool PX4 = false, int NG = 1>
-__global__ __launch_bounds__(256 * NG, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel(ConvK p) {
+__device__ __forceinline__ void conv_dma_body(ConvK p, const int bid, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   static_assert(!KSP || (WM == 1 && WN == 1), "K-split tile is one 32x32 fragment");
   static_assert(NG == 1 || (KSP && NST == 2), "wave groups: K-split tile, double buffer");
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256 * NG, (KSP || NST > 2) ? 1 : 2) void conv_dma_k
   // block-uniform tile coordinates, pinned to SGPRs (the integer divisions are expanded on the
   // vector ALU and would otherwise leave n / m0 / the tile origin -- and every pointer derived
   // from them -- in VGPRs)
-  int lb = scf_xcd_remap(blockIdx.x, gridDim.x);
+  int lb = scf_xcd_remap(bid, nblk);
   // K split across blocks (r5): slice ksl contracts chunks [cb, cb + nch) and stores raw partial sums into its own
   // output tensor; the consumer adds the slices in order.  kslices <= 1: one slice = everything.
   int cb = 0, nch = p.nchunk;
@@ -505,6 +507,22 @@ __global__ __launch_bounds__(256 * NG, (KSP || NST > 2) ? 1 : 2) void conv_dma_k
   CTRACE(3);
 }
 
+template <int WM, int WN, int NST = 2, bool KSP = false, bool PX4 = false, int NG = 1>
+__global__ __launch_bounds__(256 * NG, (KSP || NST > 2) ? 1 : 2) void conv_dma_kernel(ConvK p) {
+  conv_dma_body<WM, WN, NST, KSP, PX4, NG>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// r6: TWO independent small-grid layers in ONE launch (blocks [0, nba) run layer a, the rest layer b; K-split tile only).
+// At batch 1-4 a layer fills a fraction of the chip and two independent layers used to run side by side on two streams;
+// a hipGraph replay on this runtime pays ~1.2 us per node as soon as the graph holds a parallel branch
+// (tools/lab/graph_fork_penalty.py), so the concurrency moves INTO the launch: no cross-queue dependency, one dispatch,
+// the same arithmetic per layer (a block cannot tell which launch form it runs in: bit-identical outputs).
+template <bool PX4, int NG>
+__global__ __launch_bounds__(256 * NG, 1) void conv_dma_pair_kernel(ConvK pa, ConvK pb, int nba) {
+  if ((int)blockIdx.x < nba) conv_dma_body<1, 1, 2, true, PX4, NG>(pa, (int)blockIdx.x, nba);
+  else conv_dma_body<1, 1, 2, true, PX4, NG>(pb, (int)blockIdx.x - nba, (int)gridDim.x - nba);
+}
+
 #define SCF_DMA_LDS_DEEP (144 * 1024)  // tiny grids (one block per CU): 32-channel chunks of 3x3 layers
 
 template <int WM, int WN, int NST = 2, bool KSP = false, bool PX4 = false, int NG = 1>
@@ -539,7 +557,7 @@ int scf_dma_force_ksplit_set(int v) { return g_force_ksp.exchange(v); }
 static std::atomic<int> g_ksp_groups{0};
 int scf_dma_ksplit_groups_set(int v) { return g_ksp_groups.exchange(v); }
 
-int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st) {
+int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st, ScfLaunchCap* cap) {
   if ((!k.wp4 && !k.wp4s) || (k.stride != 1 && k.stride != 2) || k.w_ns != 0) return SCF_EUNSUPPORTED;
   // K split across blocks: S slices are S times the blocks (grid-size decisions below see N * S samples) and 1 / S of
   // every block's chunk chain
@@ -723,6 +741,11 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   // store zeros for the consumer to add; the caller asks again with fewer slices (ops.conv_kslices_for)
   if (S > 1 && (long long)(S - 1) * ((k.nchunk + S - 1) / S) >= k.nchunk) return SCF_EUNSUPPORTED;
   if (info) { info[0] = WM; info[1] = ksp ? ngroups : WN; info[2] = (int)nblk; info[3] = k.T * G * 4 * WM * WN / (ksp ? 4 : 1); }
+  if (cap) {                // r6: hand the launch back instead of issuing it (scf_conv2d_pair)
+    cap->k = k; cap->nblk = (int)nblk; cap->ldsb = ldsb;
+    cap->variant = ksp ? (ngroups == 2 ? 2 : 0) + (px4 ? 1 : 0) : -1;      // K-split tile: {NG 1 | 2} x {dword | x4 patch staging}
+    return SCF_OK;
+  }
   if (dry_run) return SCF_OK;
 #define SCF_GO(...) return px4 ? launch_dma<__VA_ARGS__, true>(k, (int)nblk, ldsb, st)            \
                                : launch_dma<__VA_ARGS__, false>(k, (int)nblk, ldsb, st)
@@ -734,6 +757,39 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   SCF_CASE(2, 2) SCF_CASE(3, 1) SCF_CASE(2, 1) SCF_CASE(1, 1)
 #undef SCF_CASE
 #undef SCF_GO
+  return SCF_EUNSUPPORTED;
+}
+
+
+// r6: two captured K-split launches of the same instantiation as one launch (see conv_dma_pair_kernel)
+template <bool PX4, int NG>
+static int launch_dma_pair(const ScfLaunchCap& a, const ScfLaunchCap& b, size_t lds_bytes, hipStream_t st) {
+  if (lds_bytes > 64 * 1024) {
+    static std::atomic<unsigned long long> raised{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return SCF_ELAUNCH;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(raised.load(std::memory_order_relaxed) & bit)) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_pair_kernel<PX4, NG>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, SCF_DMA_LDS_DEEP) != hipSuccess)
+        return SCF_ELAUNCH;
+      raised.fetch_or(bit, std::memory_order_relaxed);
+    }
+  }
+  scf_launch((conv_dma_pair_kernel<PX4, NG>), dim3((unsigned)(a.nblk + b.nblk)), dim3(256 * NG), lds_bytes, st, a.k, b.k, a.nblk);
+  return scf_launch_status();
+}
+
+int scf_conv_dma_pair_launch(const ScfLaunchCap& a, const ScfLaunchCap& b, hipStream_t st) {
+  if (a.variant < 0 || a.variant != b.variant || a.nblk <= 0 || b.nblk <= 0) return SCF_EUNSUPPORTED;
+  const size_t lds = a.ldsb > b.ldsb ? a.ldsb : b.ldsb;
+  if (lds > SCF_DMA_LDS_DEEP) return SCF_EUNSUPPORTED;
+  switch (a.variant) {
+    case 0: return launch_dma_pair<false, 1>(a, b, lds, st);
+    case 1: return launch_dma_pair<true, 1>(a, b, lds, st);
+    case 2: return launch_dma_pair<false, 2>(a, b, lds, st);
+    case 3: return launch_dma_pair<true, 2>(a, b, lds, st);
+  }
   return SCF_EUNSUPPORTED;
 }
 

@@ -400,16 +400,31 @@ __device__ __forceinline__ void scf_conv_epilogue_tile(const ConvK& p, const Con
 // falls back to fp32).  info (optional): {WM, WN, blocks, MFMAs per wave per chunk}.
 int scf_conv_f16x3_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st);
 
+// r6: what a dispatch WOULD launch (filled instead of launching when a capture is passed): two captures of the same kernel
+// instantiation run as ONE launch (scf_conv_*_pair_launch: blocks [0, a.nblk) = layer a, the rest layer b).
+struct ScfLaunchCap {
+  ConvK k;
+  int nblk = 0;
+  size_t ldsb = 0;
+  int variant = -1;           // kernel instantiation id (family-specific); -1 = not pairable (pixel-split tiles, persistent, ...)
+  const float* wt = nullptr;  // taps: the packing
+  int Kp = 0, PWp = 0;        // taps
+  alignas(8) unsigned char aux[96] = {};      // Winograd: the kernel's second argument (WinoK)
+};
 // conv_taps.hip: Cin <= 4 layers, contraction over taps x channels (wt = the [Kp][Mld] taps packing).
-int scf_conv_taps_dispatch(ConvK k, const float* wt, int N, bool dry_run, int* info, hipStream_t st);
+int scf_conv_taps_dispatch(ConvK k, const float* wt, int N, bool dry_run, int* info, hipStream_t st, ScfLaunchCap* cap = nullptr);
+int scf_conv_taps_pair_launch(const ScfLaunchCap& a, const ScfLaunchCap& b, hipStream_t st);      // SCF_EUNSUPPORTED: not the same instantiation
 // conv_wino.hip: 3x3 / stride-1 / pad-1 layers with an affine epilogue in the Winograd F(2x2, 3x3) form
 // (wu = the G g G^T packing).  info: {16, fragments per block, blocks, LDS bytes}.
-int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* info, hipStream_t st, int* which = nullptr);
+int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* info, hipStream_t st, int* which = nullptr, ScfLaunchCap* cap = nullptr);
+int scf_conv_wino_pair_launch(const ScfLaunchCap& a, const ScfLaunchCap& b, hipStream_t st);      // quarter-domain kernel only
 // conv_wino1d.hip: 1x5 / 5x1 stride-1 'same' layers, any epilogue kind, in the Winograd F(2, 5) form (wu = the G g packing).
 int scf_conv_wino1d_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* info, hipStream_t st);
 // conv_wino1d4.hip: the same layers in the F(4, 5) form (wu = its own G g packing), grids of more than CUs / 2 blocks only.
 int scf_conv_wino1d4_dispatch(ConvK k, const float* wu, int N, bool any_grid, bool dry_run, int* info, hipStream_t st);
 // conv_thin.hip: Cout <= 4 layers on the vector ALUs.
-int scf_conv_thin_dispatch(ConvK k, int N, bool dry_run, hipStream_t st);
+int scf_conv_thin_dispatch(ConvK k, int N, bool dry_run, hipStream_t st, ScfLaunchCap* cap = nullptr);
+int scf_conv_thin_pair_launch(const ScfLaunchCap& a, const ScfLaunchCap& b, hipStream_t st);
 // conv_dma.hip: same contract for the stride-1 LDS-DMA fp32 kernel.
-int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st);
+int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st, ScfLaunchCap* cap = nullptr);
+int scf_conv_dma_pair_launch(const ScfLaunchCap& a, const ScfLaunchCap& b, hipStream_t st);

@@ -545,6 +545,7 @@ static bool want_f16x3(const scf_conv_desc* d) {
   return d->wp_f16 != nullptr && !d->out_tile8x4 && d->w_nstride == 0 && d->KH * d->KW > 1 && d->C0 + d->C1 >= 16;
 }
 
+static std::atomic<int> g_pair_mode{0};  // SCF_TUNE_CONV_PAIR
 static std::atomic<int> g_wino1d4{1};    // SCF_TUNE_WINO1D4: 0 = F(2, 5) also where an F(4, 5) packing is given (A/B measurements), 2 = F(4, 5) on every grid
 
 static bool want_dma(const scf_conv_desc* d) {      // a layer opts in by carrying the LDS-DMA packing
@@ -693,6 +694,10 @@ extern "C" int scf_tune(int key, int value) {
     if (value < 0 || value > 1) return SCF_EINVAL;
     return g_autoslice.exchange(value);
   }
+  if (key == SCF_TUNE_CONV_PAIR) {
+    if (value < 0 || value > 1) return SCF_EINVAL;
+    return g_pair_mode.exchange(value);
+  }
   if (key == SCF_TUNE_WINO1D4) {
     if (value < 0 || value > 2) return SCF_EINVAL;
     return g_wino1d4.exchange(value);
@@ -717,21 +722,92 @@ extern "C" int scf_conv_log_read(scf_conv_log_entry* out, int max_entries) {
   return n;
 }
 
+static void conv_log_push(const scf_conv_desc* d, int which);
 extern "C" int scf_conv2d(const scf_conv_desc* d, scf_stream_t stream) {
   int which = 0;
   const int rc = conv2d_launch(d, stream, &which);
-  if (rc == SCF_OK && g_log_cap.load(std::memory_order_relaxed) > 0) {
-    std::lock_guard<std::mutex> lk(g_log_mu);
-    if ((int)g_log.size() < g_log_cap.load()) {
-      scf_conv_log_entry e;
-      e.kernel = which; e.Cin = d->C0 + d->C1; e.Cout = d->Cout; e.KH = d->KH; e.KW = d->KW; e.stride = d->stride;
-      e.Ho = (d->H + 2 * d->pad_h - d->KH) / d->stride + 1;
-      e.Wo = (d->W + 2 * d->pad_w - d->KW) / d->stride + 1;
-      e.N = d->N; e.mode = d->mode;
-      g_log.push_back(e);
+  if (rc == SCF_OK) conv_log_push(d, which);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------
+// r6: two INDEPENDENT convolutions as one launch where both fall to the same small-grid kernel instantiation (the K-split
+// LDS-DMA tile, the thin-input kernel): blocks [0, nA) run a, the rest b -- the branch-level concurrency of batch 1-4 without a
+// second stream (conv_dma_pair_kernel).  Anything else: the two launches one after the other.  Same results either way.
+// ---------------------------------------------------------------------------------
+static void conv_log_push(const scf_conv_desc* d, int which) {
+  if (g_log_cap.load(std::memory_order_relaxed) <= 0) return;
+  std::lock_guard<std::mutex> lk(g_log_mu);
+  if ((int)g_log.size() >= g_log_cap.load()) return;
+  scf_conv_log_entry e;
+  e.kernel = which; e.Cin = d->C0 + d->C1; e.Cout = d->Cout; e.KH = d->KH; e.KW = d->KW; e.stride = d->stride;
+  e.Ho = (d->H + 2 * d->pad_h - d->KH) / d->stride + 1;
+  e.Wo = (d->W + 2 * d->pad_w - d->KW) / d->stride + 1;
+  e.N = d->N; e.mode = d->mode;
+  g_log.push_back(e);
+}
+
+// the family that WOULD take d (same precedence as conv2d_launch) with its launch captured, or -1 when it is not a pairable one
+static int conv2d_capture(const scf_conv_desc* d, scf_stream_t stream, ScfLaunchCap* cap) {
+  ConvPlan pl;
+  if (conv_plan(d, &pl) != SCF_OK) return -1;
+  int32_t info[4];
+  if (d->k_slices > 1) {
+    if (!want_dma(d)) return -1;
+    return (scf_conv_dma_dispatch(pl.k, d->N, true, info, nullptr, cap) == SCF_OK && cap->variant >= 0) ? SCF_KERNEL_DMA : -1;
+  }
+  if (scf_conv_thin_dispatch(pl.k, d->N, true, nullptr, cap) == SCF_OK) return SCF_KERNEL_THIN;
+  if (d->wp_taps) {
+    const int rp = scf_conv_taps_dispatch(pl.k, d->wp_taps, d->N, true, info, nullptr, cap);
+    if (rp == SCF_OK) return cap->variant >= 1 ? SCF_KERNEL_TAPS : -1;
+    if (rp != SCF_EUNSUPPORTED) return -1;
+  }
+  if (d->wp_wino) {
+    int quarter = 0;
+    if (scf_conv_wino_dispatch(pl.k, d->wp_wino, d->N, true, info, nullptr, &quarter, cap) == SCF_OK)
+      return (quarter && cap->variant >= 10) ? SCF_KERNEL_WINO_Q : -1;
+  }
+  if (d->wp_wino1d4 && g_wino1d4.load(std::memory_order_relaxed) &&
+      scf_conv_wino1d4_dispatch(pl.k, d->wp_wino1d4, d->N, g_wino1d4.load(std::memory_order_relaxed) == 2, true, info, nullptr) == SCF_OK)
+    return -1;
+  if (d->wp_wino1d && scf_conv_wino1d_dispatch(pl.k, d->wp_wino1d, d->N, true, info, nullptr) == SCF_OK) return -1;
+  if (want_f16x3(d) && scf_conv_f16x3_dispatch(pl.k, d->N, true, info, nullptr) == SCF_OK) return -1;
+  if (want_dma(d)) {
+    float* ws = nullptr;
+    int64_t ws_floats = 0;
+    if (g_autoslice.load(std::memory_order_relaxed) && kws_lookup(scf_stream(stream), &ws, &ws_floats)) return -1;
+    if (scf_conv_dma_dispatch(pl.k, d->N, true, info, nullptr, cap) == SCF_OK) return cap->variant >= 0 ? SCF_KERNEL_DMA : -1;
+  }
+  return -1;
+}
+
+extern "C" int scf_conv2d_pair(const scf_conv_desc* a, const scf_conv_desc* b, scf_stream_t stream) {
+  if (!a || !b) return SCF_EINVAL;
+  ScfLaunchCap ca, cb;
+  const int fa = conv2d_capture(a, stream, &ca);
+  if (fa >= 0) {
+    const int fb = conv2d_capture(b, stream, &cb);
+    // one launch only while both grids are resident together: past that the merged launch is a second round of blocks and
+    // loses (batch 2, corr1 384 + flow1 128 blocks of 100+ KB: +11 us per pair, profiles/r6_b1_pairs.txt)
+    // blocks that can be resident at once: thin-input and quarter-domain Winograd blocks fit two per CU, K-split blocks too while
+    // their ring stays under half the LDS (the 32-channel-chunk packing of tiny grids takes up to 144 KB: one per CU)
+    const size_t lmax = ca.ldsb > cb.ldsb ? ca.ldsb : cb.ldsb;
+    long long slots = (long long)scf_cu_count() * ((fa == SCF_KERNEL_DMA && lmax > 80 * 1024) ? 1 : 2);
+    if (g_pair_mode.load(std::memory_order_relaxed) == 1) slots = 0;      // scf_tune(SCF_TUNE_CONV_PAIR, 1): never one launch
+    if (fb == fa && (long long)ca.nblk + cb.nblk <= slots) {
+      const int rc = fa == SCF_KERNEL_WINO_Q ? scf_conv_wino_pair_launch(ca, cb, scf_stream(stream))
+                   : fa == SCF_KERNEL_THIN ? scf_conv_thin_pair_launch(ca, cb, scf_stream(stream)) : fa == SCF_KERNEL_TAPS ? scf_conv_taps_pair_launch(ca, cb, scf_stream(stream))
+                                           : scf_conv_dma_pair_launch(ca, cb, scf_stream(stream));
+      if (rc == SCF_OK) {
+        conv_log_push(a, fa);
+        conv_log_push(b, fb);
+        return SCF_OK;
+      }
+      if (rc != SCF_EUNSUPPORTED) return rc;
     }
   }
-  return rc;
+  const int r1 = scf_conv2d(a, stream);
+  return r1 != SCF_OK ? r1 : scf_conv2d(b, stream);
 }
 
 // ---------------------------------------------------------------------------------

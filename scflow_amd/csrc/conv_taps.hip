@@ -24,15 +24,18 @@
 
 typedef float ct_f32x16 __attribute__((ext_vector_type(16)));
 
+// (the kernel's body as a function of its arguments, block index and grid size: conv_taps_pair_kernel below runs two layers' grids
+// in one launch, r6)
 template <int WM>
-__global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvK p, const float* __restrict__ wt, int Kp, int PWp) {
+__device__ __forceinline__ void conv_taps_body(const ConvK& p, const float* __restrict__ wt, const int Kp, const int PWp, const int bid,
+                                               const int nblk) {
   extern __shared__ __attribute__((aligned(16))) float ct_lds[];
   constexpr int BM = WM * 32;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, half = lane >> 5;
 
-  const int lb = scf_xcd_remap(blockIdx.x, gridDim.x);
+  const int lb = scf_xcd_remap(bid, nblk);
   const int mblk = __builtin_amdgcn_readfirstlane(lb % p.mblocks);
   const int tile = __builtin_amdgcn_readfirstlane(lb / p.mblocks);
   const int m0 = mblk * BM;
@@ -162,6 +165,19 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvK p, const float*
     pix[0] = (oy < p.Ho && ox < p.Wo) ? oy * p.Wo + ox : -1;
   }
   scf_conv_epilogue_tile<WM, 1>(p, epi, acc, m0, half, pix, p.out_div != 1.0f);
+}
+
+template <int WM>
+__global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvK p, const float* __restrict__ wt, int Kp, int PWp) {
+  conv_taps_body<WM>(p, wt, Kp, PWp, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// r6: two independent thin-input layers (the delta-flow and mask encoders' first layers) in one launch; see conv_dma_pair_kernel
+template <int WM>
+__global__ __launch_bounds__(256, 2) void conv_taps_pair_kernel(ConvK pa, const float* __restrict__ wta, int Kpa, int PWpa, ConvK pb,
+                                                                const float* __restrict__ wtb, int Kpb, int PWpb, int nba) {
+  if ((int)blockIdx.x < nba) conv_taps_body<WM>(pa, wta, Kpa, PWpa, (int)blockIdx.x, nba);
+  else conv_taps_body<WM>(pb, wtb, Kpb, PWpb, (int)blockIdx.x - nba, (int)gridDim.x - nba);
 }
 
 #define CT_MAXU 12      // patch cells per lane the gather table keeps in registers (256 * 12 floats per patch)
@@ -358,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_persist_kernel(ConvK p, cons
 }
 
 // Tile selection + launch; SCF_EUNSUPPORTED -> the caller goes on to the channel-chunked kernels.
-int scf_conv_taps_dispatch(ConvK k, const float* wt, int N, bool dry_run, int* info, hipStream_t st) {
+int scf_conv_taps_dispatch(ConvK k, const float* wt, int N, bool dry_run, int* info, hipStream_t st, ScfLaunchCap* cap) {
   if (!wt || k.Cin > 4 || k.in1 || k.w_ns != 0 || k.out_tile || (k.Mld & 3) || ((uintptr_t)wt & 15)) return SCF_EUNSUPPORTED;
   const int FC = 1 << k.fc_log2, FR = 32 / FC, TR = 4 * FR;
   const int frags_m = (k.Cout + 31) / 32;
@@ -386,7 +402,7 @@ int scf_conv_taps_dispatch(ConvK k, const float* wt, int N, bool dry_run, int* i
   const long long nblk = tiles * k.mblocks;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
   if (info) { info[0] = WM; info[1] = 1; info[2] = (int)nblk; info[3] = Kp / 2 * WM; }
-  if (dry_run) return SCF_OK;
+  if (dry_run && !cap) return SCF_OK;
   // more tiles than the chip holds blocks (by LDS with two patch buffers, at most three per CU): the persistent kernel,
   // a block walks tiles slot, slot + nslots, ... of its channel block
   const size_t ldsb = lds_for(WM, 2);
@@ -397,6 +413,11 @@ int scf_conv_taps_dispatch(ConvK k, const float* wt, int N, bool dry_run, int* i
     const long long cap = per_cu * scf_cu_count() / k.mblocks * k.mblocks;
     if (cap >= k.mblocks && nblk > cap) grid = cap;
   }
+  if (cap) {                               // r6: hand the launch back instead of issuing it (scf_conv2d_pair)
+    cap->k = k; cap->nblk = (int)nblk; cap->ldsb = ldsb1; cap->wt = wt; cap->Kp = Kp; cap->PWp = PWp;
+    cap->variant = grid == nblk ? WM : -1;      // the one-tile-per-block kernel only
+    return SCF_OK;
+  }
   if (grid == nblk) {                      // one tile per block
     if (WM == 2) scf_launch((conv_taps_kernel<2>), dim3((unsigned)nblk), dim3(256), ldsb1, st, k, wt, Kp, PWp);
     else scf_launch((conv_taps_kernel<1>), dim3((unsigned)nblk), dim3(256), ldsb1, st, k, wt, Kp, PWp);
@@ -404,5 +425,17 @@ int scf_conv_taps_dispatch(ConvK k, const float* wt, int N, bool dry_run, int* i
   }
   if (WM == 2) scf_launch((conv_taps_persist_kernel<2>), dim3((unsigned)grid), dim3(256), ldsb, st, k, wt, Kp, PWp, (int)tiles);
   else scf_launch((conv_taps_persist_kernel<1>), dim3((unsigned)grid), dim3(256), ldsb, st, k, wt, Kp, PWp, (int)tiles);
+  return scf_launch_status();
+}
+
+int scf_conv_taps_pair_launch(const ScfLaunchCap& a, const ScfLaunchCap& b, hipStream_t st) {
+  if (a.variant < 1 || a.variant != b.variant || a.nblk <= 0 || b.nblk <= 0) return SCF_EUNSUPPORTED;
+  const size_t lds = a.ldsb > b.ldsb ? a.ldsb : b.ldsb;
+  if (lds > 64 * 1024) return SCF_EUNSUPPORTED;
+  const unsigned grid = (unsigned)(a.nblk + b.nblk);
+  if (a.variant == 2)
+    scf_launch((conv_taps_pair_kernel<2>), dim3(grid), dim3(256), lds, st, a.k, a.wt, a.Kp, a.PWp, b.k, b.wt, b.Kp, b.PWp, a.nblk);
+  else
+    scf_launch((conv_taps_pair_kernel<1>), dim3(grid), dim3(256), lds, st, a.k, a.wt, a.Kp, a.PWp, b.k, b.wt, b.Kp, b.PWp, a.nblk);
   return scf_launch_status();
 }

@@ -19,14 +19,16 @@
 // UNROLL (K = 3): channels whose loads are in flight together per thread -- 2 on full grids (126 registers: two
 // blocks per CU; 18.7 -> 13.4 us at batch 32), 4 on grids of at most one block per CU (a lone block is a chain of
 // memory round trips: 15.2 -> 7.6 us at batch 1; 16.2 us at batch 32)
+// (body as a function of the arguments and the block index: conv_thin_pair_kernel below runs the flow and the mask prediction of an
+// iteration -- two different instantiations -- as one launch, r6)
 template <int K, int CO, int UNROLL = 2>
-__global__ __launch_bounds__(32 * SCF_THIN_NCG) void conv_thin_kernel(ConvK p) {
+__device__ __forceinline__ void conv_thin_body(const ConvK& p, const int bid) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int PY = 2;                        // output rows per thread
   constexpr int NCG = SCF_THIN_NCG, NT = 32 * NCG;
   constexpr int T = K * K, R = K / 2, NR = PY + K - 1;
   const int tid = threadIdx.x, col = tid & 31, cg = tid >> 5;
-  const int b = blockIdx.x;
+  const int b = bid;
   const int txi = b % p.tiles_x;
   const int t2 = b / p.tiles_x;
   const int tyi = t2 % p.tiles_y;
@@ -174,6 +176,19 @@ __global__ __launch_bounds__(32 * SCF_THIN_NCG) void conv_thin_kernel(ConvK p) {
   }
 }
 
+template <int K, int CO, int UNROLL = 2>
+__global__ __launch_bounds__(32 * SCF_THIN_NCG) void conv_thin_kernel(ConvK p) {
+  conv_thin_body<K, CO, UNROLL>(p, (int)blockIdx.x);
+}
+
+// r6: the two prediction layers of an iteration (flow: 3x3 256 -> 2, mask: 1x1 256 -> 1; they read disjoint halves of the heads'
+// hidden tensor) as ONE launch on grids that leave most of the chip idle (batch 1-4): blocks [0, nba) run a, the rest b
+template <int KA, int COA, int UA, int KB, int COB, int UB>
+__global__ __launch_bounds__(32 * SCF_THIN_NCG) void conv_thin_pair_kernel(ConvK pa, ConvK pb, int nba) {
+  if ((int)blockIdx.x < nba) conv_thin_body<KA, COA, UA>(pa, (int)blockIdx.x);
+  else conv_thin_body<KB, COB, UB>(pb, (int)blockIdx.x - nba);
+}
+
 template <int K, int CO>
 static int launch_thin(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t st) {
   // UNROLL 0 = every tap its own load (K = 1; K = 3 on maps wider than one 32-column tile: its own instantiation, 76
@@ -188,7 +203,7 @@ static int launch_thin(const ConvK& k, int nblk, size_t lds_bytes, hipStream_t s
 }
 
 // SCF_EUNSUPPORTED -> not a thin layer (the caller goes on to the MFMA kernels).
-int scf_conv_thin_dispatch(ConvK k, int N, bool dry_run, hipStream_t st) {
+int scf_conv_thin_dispatch(ConvK k, int N, bool dry_run, hipStream_t st, ScfLaunchCap* cap) {
   if (!k.wthin || k.Cout > 4 || k.stride != 1 || k.KH != k.KW || (k.KH != 1 && k.KH != 3)) return SCF_EUNSUPPORTED;
   if (k.pad_h != k.KH / 2 || k.pad_w != k.KW / 2) return SCF_EUNSUPPORTED;
   if (k.in1 || k.w_ns != 0 || k.mode != SCF_CONV_PLAIN || k.res || k.scale || k.act_split > 0 ||
@@ -204,9 +219,22 @@ int scf_conv_thin_dispatch(ConvK k, int N, bool dry_run, hipStream_t st) {
   k.tiles_y = (k.Ho + 1) / 2;
   const long long nblk = (long long)N * k.tiles_x * k.tiles_y;
   if (nblk > 0x7fffffffLL) return SCF_EUNSUPPORTED;
+  if (cap) {                // r6: hand the launch back (scf_conv2d_pair); variant = K * 100 + CO * 10 + UNROLL of launch_thin's choice
+    cap->k = k; cap->nblk = (int)nblk; cap->ldsb = lds;
+    cap->variant = k.KH * 100 + CO * 10 + ((k.KH != 3 || k.tiles_x != 1) ? 0 : nblk <= scf_cu_count() ? 4 : 2);
+    return SCF_OK;
+  }
   if (dry_run) return SCF_OK;
 #define SCF_CASE(K_, C_) if (k.KH == K_ && CO == C_) return launch_thin<K_, C_>(k, (int)nblk, lds, st);
   SCF_CASE(3, 1) SCF_CASE(3, 2) SCF_CASE(3, 4) SCF_CASE(1, 1) SCF_CASE(1, 2) SCF_CASE(1, 4)
 #undef SCF_CASE
   return SCF_EUNSUPPORTED;
+}
+
+// the one heterogeneous pair the refiner has: flow prediction (3x3, 2 outputs, small-grid unroll) | mask prediction (1x1, 1 output)
+int scf_conv_thin_pair_launch(const ScfLaunchCap& a, const ScfLaunchCap& b, hipStream_t st) {
+  if (a.variant != 324 || b.variant != 110 || a.nblk <= 0 || b.nblk <= 0) return SCF_EUNSUPPORTED;
+  const size_t lds = a.ldsb > b.ldsb ? a.ldsb : b.ldsb;
+  scf_launch((conv_thin_pair_kernel<3, 2, 4, 1, 1, 0>), dim3((unsigned)(a.nblk + b.nblk)), dim3(32 * SCF_THIN_NCG), lds, st, a.k, b.k, a.nblk);
+  return scf_launch_status();
 }

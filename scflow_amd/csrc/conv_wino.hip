@@ -414,9 +414,10 @@ void conv_wino_kernel(ConvK p, WinoK q) {
 // 16 MFMAs back to back, instead of seven gaps between MFMAs.  tools/lab/coissue.hip (profiles/r5_coissue_burst_and_
 // priorities.txt): vector-ALU / LDS / copy instructions never overlap the MFMAs of their SIMD (4.2 / 3.3 / 10 clk each on
 // top of 64 per MFMA, with any wave priorities), and every switch between the two kinds costs ~20 clk more.
+// (the kernel's body as a function of its arguments, block index and grid size: conv_wino_q_pair_kernel below runs two layers' grids
+// in one launch, r6)
 template <int TW, bool PX4, int NR = 3, bool BURST = false>
-__global__ __launch_bounds__(256 * TW, TW == 1 ? 2 : 1)
-void conv_wino_q_kernel(ConvK p, WinoK q) {
+__device__ __forceinline__ void conv_wino_q_body(const ConvK& p, const WinoK& q, const int bid, const int nblk) {
   static_assert(!BURST || NR == 4, "the burst form reads two chunks ahead");
   extern __shared__ __attribute__((aligned(16))) float wn_lds[];
   constexpr int NW = 4 * TW, NT = 64 * NW;                      // waves, threads
@@ -431,7 +432,7 @@ void conv_wino_q_kernel(ConvK p, WinoK q) {
   const int tw = TW == 2 ? wave >> 2 : 0, row = wave & 3;
   const int half = lane >> 5, l32 = lane & 31;
 
-  int lb = scf_xcd_remap(blockIdx.x, gridDim.x);
+  int lb = scf_xcd_remap(bid, nblk);
   const int mb = __builtin_amdgcn_readfirstlane(lb % q.mblocks);
   lb /= q.mblocks;
   const int xs = __builtin_amdgcn_readfirstlane(lb % q.sx);
@@ -726,6 +727,22 @@ void conv_wino_q_kernel(ConvK p, WinoK q) {
   }
 }
 
+template <int TW, bool PX4, int NR = 3, bool BURST = false>
+__global__ __launch_bounds__(256 * TW, TW == 1 ? 2 : 1)
+void conv_wino_q_kernel(ConvK p, WinoK q) {
+  conv_wino_q_body<TW, PX4, NR, BURST>(p, q, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// r6: two independent layers' grids in one launch (blocks [0, nba) = layer a, the rest layer b): at batch 1-4 the context
+// encoder's 64 -> 64 layers (128 blocks per image) ride in the feature encoder's launches (256 blocks for a pair of images)
+// instead of running after them or on a second stream (see conv_dma_pair_kernel)
+template <bool PX4>
+__global__ __launch_bounds__(256, 2)
+void conv_wino_q_pair_kernel(ConvK pa, WinoK qa, ConvK pb, WinoK qb, int nba) {
+  if ((int)blockIdx.x < nba) conv_wino_q_body<1, PX4>(pa, qa, (int)blockIdx.x, nba);
+  else conv_wino_q_body<1, PX4>(pb, qb, (int)blockIdx.x - nba, (int)gridDim.x - nba);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Host side: packing and launch
 // ---------------------------------------------------------------------------------------------------
@@ -772,7 +789,7 @@ int scf_wino_variant_set(int v) {
 
 // Tile selection + launch; SCF_EUNSUPPORTED -> the caller goes on to the direct kernels.
 // info (optional): {16 transform positions, fragments per block, blocks, LDS bytes}.
-int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* info, hipStream_t st, int* which) {
+int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* info, hipStream_t st, int* which, ScfLaunchCap* cap) {
   if (which) *which = 0;      // 1: the quarter-domain kernel took the launch
   if (!wu || k.KH != 3 || k.KW != 3 || k.stride != 1 || k.pad_h != 1 || k.pad_w != 1) return SCF_EUNSUPPORTED;
   if (k.w_ns != 0 || k.out_tile || k.mode != SCF_CONV_PLAIN || k.out_div != 1.0f || k.act_split > 0) return SCF_EUNSUPPORTED;
@@ -837,6 +854,14 @@ int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* i
       if (ldsf < (size_t)TW * 4 * 3072) ldsf = (size_t)TW * 4 * 3072;      // the output exchange reuses the rings
       const size_t ldsb = ldsf * sizeof(float);
       if (info) { info[0] = 16; info[1] = 2 * TW; info[2] = (int)nblk; info[3] = (int)ldsb; }
+      if (cap) {              // r6: hand the launch back (scf_conv2d_pair): the product's 4-wave, 3-slot form only
+        static_assert(sizeof(WinoK) <= sizeof(cap->aux), "ScfLaunchCap::aux holds a WinoK");
+        cap->k = k; cap->nblk = (int)nblk; cap->ldsb = ldsb;
+        memcpy(cap->aux, &q, sizeof(WinoK));
+        cap->variant = (TW == 1 && NR == 3) ? 10 + cfg : -1;
+        if (which) *which = 1;
+        return SCF_OK;
+      }
       if (dry_run) return SCF_OK;
       static std::atomic<unsigned long long> raised_q[4];
 #ifdef SCF_WINO_LAB
@@ -889,6 +914,7 @@ int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* i
   const size_t ldsb = (size_t)(3 * CW * 2048 + 3 * npi * (px4 ? 1024 : 256)) * sizeof(float);
   if (ldsb > 80 * 1024) return SCF_EUNSUPPORTED;
   if (info) { info[0] = 16; info[1] = CW * TW; info[2] = (int)nblk; info[3] = (int)ldsb; }     // positions, fragments per block
+  if (cap) { cap->variant = -1; return SCF_OK; }
   if (dry_run) return SCF_OK;
   {                                  // more than 64 KB of dynamic LDS needs the attribute, once per kernel and device
     static std::atomic<unsigned long long> raised[2];
@@ -898,5 +924,22 @@ int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* i
   }
   if (cfg) scf_launch((conv_wino_kernel<1, 2, true>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
   else scf_launch((conv_wino_kernel<1, 2, false>), dim3((unsigned)nblk), dim3(256), ldsb, st, k, q);
+  return scf_launch_status();
+}
+
+int scf_conv_wino_pair_launch(const ScfLaunchCap& a, const ScfLaunchCap& b, hipStream_t st) {
+  if (a.variant < 10 || a.variant != b.variant || a.nblk <= 0 || b.nblk <= 0) return SCF_EUNSUPPORTED;
+  const size_t lds = a.ldsb > b.ldsb ? a.ldsb : b.ldsb;
+  WinoK qa, qb;
+  memcpy(&qa, a.aux, sizeof(WinoK));
+  memcpy(&qb, b.aux, sizeof(WinoK));
+  const int cfg = a.variant - 10;
+  static std::atomic<unsigned long long> raised[2];
+  const void* fn = cfg ? (const void*)conv_wino_q_pair_kernel<true> : (const void*)conv_wino_q_pair_kernel<false>;
+  const int rc = scf_raise_dynamic_lds(raised[cfg], fn, 64 * 1024);
+  if (rc != SCF_OK) return rc;
+  const unsigned grid = (unsigned)(a.nblk + b.nblk);
+  if (cfg) scf_launch((conv_wino_q_pair_kernel<true>), dim3(grid), dim3(256), lds, st, a.k, qa, b.k, qb, a.nblk);
+  else scf_launch((conv_wino_q_pair_kernel<false>), dim3(grid), dim3(256), lds, st, a.k, qa, b.k, qb, a.nblk);
   return scf_launch_status();
 }

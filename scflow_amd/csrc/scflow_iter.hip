@@ -71,7 +71,10 @@ extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stre
       it->N <= 0 || it->H <= 0 || it->W <= 0 || it->h <= 0 || it->w <= 0 || it->npass <= 0 || it->npass > 2)
     return SCF_EINVAL;
   if ((it->mask_flow || it->mask_corr) && !it->mask_prev) return SCF_EINVAL;
-  const bool any_overlap = it->overlap_flow || it->overlap_mask || it->overlap_up;
+  // overlap_* : 0 = in order, 1 = the branch on the side stream, 2 (r6) = the branch's convolutions ride in the main branch's
+  // launches (scf_conv2d_pair): same kernels, same results, no second stream
+  const bool pair_flow = it->overlap_flow == 2, pair_mask = it->overlap_mask == 2;
+  const bool any_overlap = it->overlap_flow == 1 || it->overlap_mask == 1 || it->overlap_up == 1;
   if (any_overlap && !it->side_stream) return SCF_EINVAL;
   hipStream_t mainq = scf_stream(stream), sideq = scf_stream(it->side_stream);
   IterEvents* Ep = any_overlap ? iter_events() : nullptr;
@@ -95,7 +98,7 @@ extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stre
     SCF_TRY(scf_mul_mask(it->flow_lr, (int64_t)2 * hw, it->mask_prev, it->flow_masked, (int64_t)2 * hw, N, 2, hw, stream));
     flow_enc = it->flow_masked;
   }
-  if (it->overlap_flow) {
+  if (it->overlap_flow == 1) {
     if (!fork_to(mainq, sideq, E.ev[0])) return SCF_ELAUNCH;
     br.open = true;
   }
@@ -110,14 +113,19 @@ extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stre
                          (int64_t)it->corr_channels * hw, N, it->corr_channels, hw, stream));
   // ---- motion encoder (raft_decoder.py:152-166): flow branch beside the correlation branch ----
   {
-    scf_stream_t fq = it->overlap_flow ? it->side_stream : stream;
+    scf_stream_t fq = it->overlap_flow == 1 ? it->side_stream : stream;
     scf_conv_desc f0 = it->flow0;
     f0.in0 = flow_enc;
     SCF_TRY(scf_conv2d(&f0, fq));
-    SCF_TRY(scf_conv2d(&it->flow1, fq));
-    SCF_TRY(scf_conv2d(&it->corr0, stream));
-    SCF_TRY(scf_conv2d(&it->corr1, stream));
-    if (it->overlap_flow) {
+    if (pair_flow) {            // flow1 (3x3 128 -> 64) beside corr1 (3x3 256 -> 192): both K-split launches
+      SCF_TRY(scf_conv2d(&it->corr0, stream));
+      SCF_TRY(scf_conv2d_pair(&it->corr1, &it->flow1, stream));
+    } else {
+      SCF_TRY(scf_conv2d(&it->flow1, fq));
+      SCF_TRY(scf_conv2d(&it->corr0, stream));
+      SCF_TRY(scf_conv2d(&it->corr1, stream));
+    }
+    if (it->overlap_flow == 1) {
       br.open = false;
       if (!fork_to(sideq, mainq, E.ev[1])) return SCF_ELAUNCH;
     }
@@ -136,16 +144,23 @@ extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stre
   SCF_TRY(scf_conv2d(&it->heads, stream));
   // r5: with the mask branch on the side stream, the mask prediction goes with it -- [mask head -> mask encoder] beside
   // [flow head -> delta-flow encoder] instead of both predictions in a row on the main stream
-  const bool mpred_aside = merge && it->overlap_mask;
+  const bool mpred_aside = merge && it->overlap_mask == 1;
   if (mpred_aside) {                   // the side branch starts behind the heads' hidden layer
     if (!fork_to(mainq, sideq, E.ev[2])) return SCF_ELAUNCH;
     br.open = true;
   }
-  SCF_TRY(scf_conv2d(&it->fpred, stream));
-  if (!mpred_aside) SCF_TRY(scf_conv2d(&it->mpred, stream));
-  {
-    scf_stream_t mq = it->overlap_mask ? it->side_stream : stream;
-    if (it->overlap_mask && !mpred_aside) {
+  if (pair_mask) {              // the two predictions read disjoint halves of the hidden tensor: one launch on small grids
+    SCF_TRY(scf_conv2d_pair(&it->fpred, &it->mpred, stream));
+  } else {
+    SCF_TRY(scf_conv2d(&it->fpred, stream));
+    if (!mpred_aside) SCF_TRY(scf_conv2d(&it->mpred, stream));
+  }
+  if (pair_mask) {              // [delta-flow encoder | mask encoder] layer by layer in shared launches
+    SCF_TRY(scf_conv2d_pair(&it->denc0, &it->menc0, stream));
+    SCF_TRY(scf_conv2d_pair(&it->denc1, &it->menc1, stream));
+  } else {
+    scf_stream_t mq = it->overlap_mask == 1 ? it->side_stream : stream;
+    if (it->overlap_mask == 1 && !mpred_aside) {
       if (!fork_to(mainq, sideq, E.ev[2])) return SCF_ELAUNCH;
       br.open = true;
     }
@@ -154,15 +169,15 @@ extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stre
     SCF_TRY(scf_conv2d(&it->menc1, mq));
     SCF_TRY(scf_conv2d(&it->denc0, stream));
     SCF_TRY(scf_conv2d(&it->denc1, stream));
-    if (it->overlap_mask) {
+    if (it->overlap_mask == 1) {
       br.open = false;
       if (!fork_to(sideq, mainq, E.ev[3])) return SCF_ELAUNCH;
     }
   }
   // ---- full-resolution outputs (:222-227): they feed nothing, beside the pose head ----
   {
-    scf_stream_t uq = it->overlap_up ? it->side_stream : stream;
-    if (it->overlap_up) {
+    scf_stream_t uq = it->overlap_up == 1 ? it->side_stream : stream;
+    if (it->overlap_up == 1) {
       if (!fork_to(mainq, sideq, E.ev[4])) return SCF_ELAUNCH;
       br.open = true;
     }
@@ -222,7 +237,7 @@ extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stre
       SCF_TRY(rf);
     }
   }
-  if (it->overlap_up) {
+  if (it->overlap_up == 1) {
     br.open = false;
     if (!fork_to(sideq, mainq, E.ev[5])) return SCF_ELAUNCH;
   }

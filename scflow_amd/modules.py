@@ -267,6 +267,33 @@ class RAFTEncoder(HipModule):
                           act_split=head_split)
 
 
+def raft_encoder_pair(fe: 'RAFTEncoder', xf: Tensor, ce: 'RAFTEncoder', xc: Tensor, out_c: Optional[Tensor] = None,
+                      head_act: int = ACT_NONE, head_act2: int = ACT_NONE, head_split: int = 0) -> Tuple[Tensor, Tensor]:
+    """the feature encoder (InstanceNorm) on ``xf`` and the context encoder (BatchNorm, folded) on ``xc`` -- two independent
+    passes over layers of identical geometry -- walked TOGETHER, every pair of convolutions through ``ops.conv2d_pair``: at
+    batch 1-4 the context encoder's launches ride in the feature encoder's wherever both grids fit the chip (r6; before: one
+    after the other, or side by side on a second stream).  Same kernels per layer as the two separate passes, same bits."""
+    if fe.kind != 'IN' or ce.kind != 'BN':
+        raise ValueError('raft_encoder_pair: (InstanceNorm feature encoder, BatchNorm context encoder)')
+    pf, pc = fe.packed, ce.packed
+    yf, yc = ops.conv2d_pair((pf['stem'], xf), (pc['stem'], xc, dict(act=ACT_RELU)))
+    ops.instance_norm(yf, relu=True, out=yf)
+    for name in fe.res_layers:
+        for bf, bc in zip(getattr(fe, name), getattr(ce, name)):
+            qf, qc = bf.packed, bc.packed
+            tf_, tc_ = ops.conv2d_pair((qf['c1'], yf), (qc['c1'], yc, dict(act=ACT_RELU)))
+            ops.instance_norm(tf_, relu=True, out=tf_)
+            if 'ds' in qf:
+                if_, ic_ = ops.conv2d_pair((qf['ds'], yf), (qc['ds'], yc))
+                ops.instance_norm(if_, out=if_)
+            else:
+                if_, ic_ = yf, yc
+            uf_, yc = ops.conv2d_pair((qf['c2'], tf_), (qc['c2'], tc_, dict(res=ic_, act=ACT_RELU)))
+            yf = ops.instance_norm(uf_, res=if_, relu=True, out=uf_)
+    return ops.conv2d_pair((pf['head'], yf), (pc['head'], yc, dict(out=out_c, act=head_act, act2=head_act2,
+                                                                  act_split=head_split)))
+
+
 # =============================================================== decoder
 class CorrelationPyramid(HipModule):
     """decoder/raft_decoder.py:19-58."""
@@ -633,7 +660,7 @@ class SCFlowDecoder(HipModule):
         ov_flow, ov_mask, ov_up = (ops.small_work(n, H, W, b) for b in ('flow', 'mask', 'upsample'))
         if self.c_iteration and ops._CONV_EVENTS is None:
             return self._forward_c(pyramid, tiled, hx, ctx, rot0, trans0, depth, internel_k, label, init_flow,
-                                   invalid_flow_num, (ov_flow, ov_mask, ov_up))
+                                   invalid_flow_num, tuple(ops.branch_mode(n, H, W, b) for b in ('flow', 'mask', 'upsample')))
         # occlusion mask of the previous iteration (ones before the first: the 1/8 bilinear
         # down-sampling of a ones map, :188-190), used only with mask_flow / mask_corr
         mask = ops.constant((n, 1, h, w), 1.0, dev) if (self.mask_flow or self.mask_corr) else None
@@ -781,8 +808,8 @@ def _scflow_forward_c(self, pyramid, tiled, hx, ctx, rot0, trans0, depth, intern
         ops._dense(t, name)
     it.depth, it.K, it.R0, it.t0 = depth.data_ptr(), internel_k.data_ptr(), rot0.data_ptr(), trans0.data_ptr()
     it.invalid_flow_num = float(invalid_flow_num)
-    it.overlap_flow, it.overlap_mask, it.overlap_up = (int(b) for b in overlap)
-    it.side_stream = ops.side_stream_handle() if any(overlap) else None
+    it.overlap_flow, it.overlap_mask, it.overlap_up = (int(b) for b in overlap)      # 0 in order / 1 side stream / 2 merged launches
+    it.side_stream = ops.side_stream_handle() if any(int(b) == 1 for b in overlap) else None
     outs = ([], [], [], [], [], [], [])
     flow, rot, trans = init_flow, rot0, trans0
     for i in range(iters):

@@ -26,7 +26,7 @@ from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, CONV_GRU_Q, CONV_G
 Tensor = torch.Tensor
 
 __all__ = ['record_conv_kernels', 'PackedConv', 'conv_desc', 'gru_passes', 'scflow_iteration', 'side_stream_handle', 'pyramid_layout', 'untile_level', 'level_storage_shape', 'sepconv_gru', 'pack_conv_weight', 'pack_conv_weight_f16x3', 'set_conv_precision', 'set_conv_winograd', 'get_conv_winograd', 'pack_conv_weight_wino', 'pack_conv_weight_wino1d', 'pack_conv_weight_wino1d4',
-           'get_conv_precision', 'set_conv_kslices', 'conv_kslices', 'conv_kslices_for', 'constant', 'clear_constants', 'register_conv_workspace', 'choose_kc', 'conv2d', 'corr_build', 'corr_lookup',
+           'get_conv_precision', 'set_conv_kslices', 'conv_kslices', 'conv_kslices_for', 'constant', 'clear_constants', 'register_conv_workspace', 'choose_kc', 'conv2d', 'conv2d_pair', 'corr_build', 'corr_lookup',
            'instance_norm', 'group_norm_relu', 'linear', 'fc_splitk', 'fc_slices', 'pose_update', 'reproject_flow',
            'unproject_depth', 'linear_pair', 'resize_bilinear', 'convex_upsample', 'avgpool2x2', 'copy_channels',
            'ACT_NONE', 'ACT_RELU', 'ACT_SIGMOID', 'ACT_TANH', 'CONV_PLAIN', 'CONV_GRU_ZR',
@@ -115,13 +115,28 @@ def _opt(t: Optional[Tensor], name: str) -> Optional[int]:
 _SIDE = {}      # (device, main stream handle) -> that stream's side stream
 
 
-# r6 (tools/lab/b1_branches.py, every subset of the four branches as hipGraph replays, profiles/r6_b1_branch_subsets.txt): a
-# replay pays ~1.2 us per NODE as soon as the graph holds a real parallel branch (0.33-0.36 ms at 285 nodes, whatever the number
-# of fork / join edges: tools/lab/graph_fork_penalty.py), each branch then buys 0.16-0.17 ms back -- except 'upsample' (the two
-# full-resolution outputs beside the pose head), which costs 0.05 ms more than it saves: off by default since r6 (batch 1:
-# 2.71 -> 2.65 ms, batch 2: 3.25 -> 3.20, batch 4: 4.33 -> 4.30).
-OVERLAP_BRANCHES = {'context', 'flow', 'mask'}      # + 'upsample': tools/lab switches these on / off one by one
+# r6 (tools/lab/b1_branches.py: every subset of the four branches as hipGraph replays; tools/lab/graph_fork_penalty.py; tools/lab/
+# b1_pairs.py; profiles/r6_b1_branch_subsets.txt, profiles/r6_b1_pairs.txt): on this runtime a replay pays ~1.2 us per NODE as soon
+# as the graph holds a real parallel branch (0.33-0.36 ms at 285 nodes, whatever the number of fork / join edges; eager two-stream
+# execution pays about the same in event waits), each branch then buys 0.16-0.17 ms back ('upsample': -0.05).  Since r6 the flow and
+# mask branches and the context encoder ride in the main branch's launches instead (PAIR_BRANCHES: scf_conv2d_pair, two small-grid
+# layers in one launch) and NO branch uses the side stream by default: batch 1 2.71 -> 2.56 ms, batch 2 3.25 -> 3.12, batch 4
+# 4.33 -> 4.24 (identical results).  The streams stay available: ops.OVERLAP_BRANCHES = {'context', 'flow', 'mask'[, 'upsample']}, ops.PAIR_BRANCHES = set().
+OVERLAP_BRANCHES = set()
 OVERLAP_MAX_PIXELS = {'context': 4 * 256 * 256, 'flow': 4 * 256 * 256, 'mask': 4 * 256 * 256, 'upsample': 4 * 256 * 256}
+
+
+# r6: branches whose convolutions ride in the main branch's launches (scf_conv2d_pair: two small-grid layers, one launch) instead
+# of running on the side stream -- the C iteration only (SCFlowDecoder.c_iteration); takes precedence over OVERLAP_BRANCHES
+PAIR_BRANCHES = {'context', 'flow', 'mask'}
+
+
+def branch_mode(n: int, h: int, w: int, branch: str) -> int:
+    """0 = in order, 1 = side stream, 2 = merged launches, for the C iteration's ``overlap_*`` fields."""
+    lim = OVERLAP_MAX_PIXELS.get(branch, 4 * 256 * 256)
+    if n * h * w > lim:
+        return 0
+    return 2 if branch in PAIR_BRANCHES else 1 if branch in OVERLAP_BRANCHES else 0
 
 
 def small_work(n: int, h: int, w: int, branch: Optional[str] = None) -> bool:
@@ -608,6 +623,16 @@ def conv2d(pc: PackedConv, x0: Tensor, x1: Optional[Tensor] = None, out: Optiona
     return out
 
 
+def conv2d_pair(a, b):
+    """two INDEPENDENT convolutions, ``a`` and ``b`` = ``(PackedConv, x0[, kwargs of conv2d])``, through ``scf_conv2d_pair``: ONE
+    launch where both fall to the same small-grid kernel instantiation and fit the chip together, else one after the other.
+    Returns the two outputs (bit-identical to two ``conv2d`` calls either way)."""
+    da, oa = conv2d(a[0], a[1], _launch=False, **(a[2] if len(a) > 2 else {}))
+    db, ob = conv2d(b[0], b[1], _launch=False, **(b[2] if len(b) > 2 else {}))
+    _lib.check(_lib.load().scf_conv2d_pair(C.byref(da), C.byref(db), _stream()), 'scf_conv2d_pair')
+    return oa, ob
+
+
 _CONV_EVENTS = None
 
 # ---- read-only constant tensors (the all-zero initial flow, the all-ones first-iteration mask): filled ONCE per
@@ -813,7 +838,7 @@ def conv_timing(enable: bool):
     return list(zip(_read_timers([e[0] for e in evs]), [e[1] for e in evs], [e[2] for e in evs]))
 
 
-TUNE_KEYS = {'wino_variant': 1, 'dma_force_ksplit': 2, 'dma_ksplit_groups': 3, 'wino1d4': 4, 'lookup_pipe': 5, 'lookup_store': 6, 'conv_autoslice': 7, 'iter_merge': 8, 'wino1d4_half': 9}
+TUNE_KEYS = {'wino_variant': 1, 'dma_force_ksplit': 2, 'dma_ksplit_groups': 3, 'wino1d4': 4, 'lookup_pipe': 5, 'lookup_store': 6, 'conv_autoslice': 7, 'iter_merge': 8, 'wino1d4_half': 9, 'conv_pair': 10}
 
 
 def tune(key: str, value: int) -> int:

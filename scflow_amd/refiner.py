@@ -16,7 +16,7 @@ from typing import Dict, Optional, Tuple, Union
 import torch
 
 from . import ops
-from .modules import HipModule
+from .modules import HipModule, raft_encoder_pair
 from .ops import ACT_RELU, ACT_TANH, small_work
 from .registry import REFINERS, build_decoder, build_encoder
 
@@ -81,6 +81,14 @@ class SCFlowRefiner(HipModule):
         rend = render_images.contiguous()
         ov_ctx = small_work(n, H, W, 'context')
         fork = ops.fork_point() if ov_ctx else None     # the context encoder may start from here
+        if not self.seperate_encoder and ops.branch_mode(n, H, W, 'context') == 2 and ops._CONV_EVENTS is None:
+            # r6: the context encoder's launches ride in the feature encoder's (modules.raft_encoder_pair)
+            both = torch.empty((2 * n, 3, H, W), dtype=torch.float32, device=dev)
+            ops.copy_channels(rend, both[:n])
+            ops.copy_channels(real_images.contiguous(), both[n:])
+            feats, _ = raft_encoder_pair(self.render_encoder, both, self.context, rend, out_c=hx[:, :hc + cc],
+                                         head_act=ACT_TANH, head_act2=ACT_RELU, head_split=hc)
+            return feats[:n], feats[n:], hx[:, :hc], hx[:, hc:hc + cc]
         if self.seperate_encoder:
             render_feat = self.render_encoder(rend)
             real_feat = self.real_encoder(real_images.contiguous())

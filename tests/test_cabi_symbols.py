@@ -69,6 +69,9 @@ def test_tune_knobs_validate_their_values():
         assert lib.scf_tune(ops.TUNE_KEYS['wino_variant'], 3) < 0 and lib.scf_tune(ops.TUNE_KEYS['wino_variant'], 4) < 0
         assert ops.tune('wino_variant', 2) == 0 and ops.tune('wino_variant', 0) == 2
         assert ops.tune('lookup_pipe', 6) == 0 and ops.tune('lookup_pipe', 0) == 6
+        # r6: merged launches of scf_conv2d_pair (default on), 0 / 1 only
+        assert ops.tune('conv_pair', 1) == 0 and ops.tune('conv_pair', 0) == 1
+        assert lib.scf_tune(ops.TUNE_KEYS['conv_pair'], 2) < 0
         # the lookup knobs (r5): pipelined variant 0..3, store policy 0..5
         assert lib.scf_tune(ops.TUNE_KEYS['lookup_pipe'], 7) < 0 and lib.scf_tune(ops.TUNE_KEYS['lookup_store'], 6) < 0
         assert ops.tune('lookup_pipe', 2) == 0 and ops.tune('lookup_pipe', 0) == 2
@@ -84,7 +87,7 @@ def test_tune_knobs_validate_their_values():
             ops.tune('wino1d4', 7)
     finally:                                          # a failed assertion must not leave a knob off its default
         for key, default in (('wino1d4', 1), ('wino_variant', 0), ('lookup_pipe', 0), ('lookup_store', 0), ('iter_merge', 1),
-                             ('wino1d4_half', 0)):
+                             ('wino1d4_half', 0), ('conv_pair', 0)):
             lib.scf_tune(ops.TUNE_KEYS[key], default)
 
 

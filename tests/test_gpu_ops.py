@@ -1475,3 +1475,39 @@ def test_conv2d_autoslice_small_grids():
     d = float((got - single).abs().max())
     print(f'[measured] GRU cell x3 at batch 1, K-sliced vs single launches: max |dh| {d:.2e}')
     assert 0.0 < d <= 2e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# r6: two independent small-grid layers in one launch (scf_conv2d_pair)
+# ------------------------------------------------------------------------------------------------
+PAIR_CASES = [
+    # (n, cin, cout, k, pad, hw) x 2, expect merged?
+    ((1, 128, 64, (3, 3), (1, 1), (32, 32)), (1, 64, 32, (3, 3), (1, 1), (32, 32)), True),      # delta-flow | mask encoders, 2nd layers
+    ((1, 2, 128, (7, 7), (3, 3), (32, 32)), (1, 1, 64, (3, 3), (1, 1), (32, 32)), True),        # ... 1st layers (thin inputs)
+    ((1, 256, 192, (3, 3), (1, 1), (32, 32)), (1, 128, 64, (3, 3), (1, 1), (32, 32)), True),    # corr_net.1 | flow_net.1 at batch 1
+    ((1, 256, 2, (3, 3), (1, 1), (32, 32)), (1, 256, 1, (1, 1), (0, 0), (32, 32)), True),       # flow | mask predictions (two thin instantiations)
+    ((2, 256, 192, (3, 3), (1, 1), (32, 32)), (2, 128, 64, (3, 3), (1, 1), (32, 32)), False),   # batch 2: 384 + 128 blocks > CUs
+    ((1, 128, 64, (3, 3), (1, 1), (32, 32)), (1, 2, 128, (7, 7), (3, 3), (32, 32)), False),     # different kernel families
+    ((32, 128, 64, (3, 3), (1, 1), (32, 32)), (32, 64, 32, (3, 3), (1, 1), (32, 32)), False),   # full grids (Winograd)
+    ((3, 224, 128, (3, 3), (1, 1), (12, 20)), (2, 30, 40, (1, 5), (0, 2), (9, 33)), None),      # ragged shapes, whatever it does
+]
+
+
+@pytest.mark.parametrize('case', PAIR_CASES)
+def test_conv2d_pair_equals_two_launches(case):
+    """scf_conv2d_pair == scf_conv2d(a); scf_conv2d(b) bit for bit, merged or not; the dispatch log names both layers."""
+    (na, cia, coa, ka, pa, hwa), (nb, cib, cob, kb, pb, hwb), merged = case
+    xa, xb = rnd((na, cia, *hwa), 201).to(DEV), rnd((nb, cib, *hwb), 202).to(DEV)
+    wa = rnd((coa, cia, *ka), 203, (1.0 / (cia * ka[0] * ka[1])) ** 0.5).to(DEV)
+    wb = rnd((cob, cib, *kb), 204, (1.0 / (cib * kb[0] * kb[1])) ** 0.5).to(DEV)
+    pca = ops.PackedConv.from_weight(wa, rnd((coa,), 205, 0.1).to(DEV), padding=pa)
+    pcb = ops.PackedConv.from_weight(wb, rnd((cob,), 206, 0.1).to(DEV), padding=pb)
+    want_a = ops.conv2d(pca, xa, act=ops.ACT_RELU)
+    want_b = ops.conv2d(pcb, xb, act=ops.ACT_NONE)
+    with ops.record_conv_kernels() as ran:
+        got_a, got_b = ops.conv2d_pair((pca, xa, dict(act=ops.ACT_RELU)), (pcb, xb, dict(act=ops.ACT_NONE)))
+    torch.cuda.synchronize()
+    assert torch.equal(got_a, want_a) and torch.equal(got_b, want_b)
+    assert len(ran) == 2 and ran[0][0].startswith(f'{cia}->{coa}') and ran[1][0].startswith(f'{cib}->{cob}'), ran
+    close(got_a, torch.relu(F.conv2d(xa.cpu(), wa.cpu(), pca.bias.cpu(), padding=pa)), atol=3e-5, what='pair a vs torch')
+    close(got_b, F.conv2d(xb.cpu(), wb.cpu(), pcb.bias.cpu(), padding=pb), atol=3e-5, what='pair b vs torch')

@@ -824,3 +824,37 @@ def test_edge_case_inputs_vs_oracle(golden_dir, model):
     close(got[2][-1], want[2][-1], atol=2e-5, what='rotation (edge inputs)')
     close(got[3][-1], want[3][-1], atol=1e-2, rtol=2e-5, what='translation (edge inputs)')
     close(got[4][-1], want[4][-1], atol=2e-4, what='mask (edge inputs)')
+
+
+@pytest.mark.parametrize('n', [1, 3])
+def test_branch_modes_are_bit_identical(golden_dir, model, n):
+    """the independent branches of a small batch in order / on the side stream / riding in shared launches (scf_conv2d_pair, the
+    r6 default): the same kernels on the same data -- every output of the pass bit for bit, eagerly and as hipGraph replays."""
+    from scflow_amd.graph import GraphedRefiner
+    inp = {k: v.to(DEV) for k, v in scflow_amd.make_inputs(n, 256, 256, seed=90 + n).items()}
+    keep = (set(ops.OVERLAP_BRANCHES), set(ops.PAIR_BRANCHES))
+    iters0 = model.decoder.iters
+    model.decoder.iters = 3
+    outs = {}
+    try:
+        for name, streams, pairs in (('in order', set(), set()), ('streams', {'context', 'flow', 'mask', 'upsample'}, set()),
+                                     ('pairs', set(), {'context', 'flow', 'mask'}), ('stream + pairs', {'context', 'upsample'}, {'flow', 'mask'})):
+            ops.OVERLAP_BRANCHES, ops.PAIR_BRANCHES = set(streams), set(pairs)
+            eager = model.get_pose(inp['render_images'], inp['real_images'], inp['ref_rotation'], inp['ref_translation'],
+                                   inp['depth'], inp['internel_k'], inp['label'])
+            eager = [[t.clone() for t in seq] for seq in eager]
+            g = GraphedRefiner(model, inp, warmup=1)
+            rep = g(inp)
+            torch.cuda.synchronize()
+            for a, b in zip(eager, rep):
+                for x, y in zip(a, b):
+                    assert torch.equal(x, y), name
+            outs[name] = eager
+            del g
+    finally:
+        ops.OVERLAP_BRANCHES, ops.PAIR_BRANCHES = keep
+        model.decoder.iters = iters0
+    for name in ('streams', 'pairs', 'stream + pairs'):
+        for a, b in zip(outs['in order'], outs[name]):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y), name

@@ -9,6 +9,7 @@ from scflow_amd import ops
 from scflow_amd.graph import GraphedRefiner
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+ops.PAIR_BRANCHES = set()      # streams only (r6 default: merged launches)
 model, _ = bench.build_model(8, 'cuda:0')
 d = bench.make_batch(n, 5, 'cuda:0')
 ALL = {'context', 'flow', 'mask', 'upsample'}

@@ -9,6 +9,7 @@ import bench
 from scflow_amd import ops
 from scflow_amd.graph import GraphedRefiner
 
+ops.PAIR_BRANCHES = set()      # streams only (r6 default: merged launches)
 model, _ = bench.build_model(8, 'cuda:0')
 d = bench.make_batch(1, 5, 'cuda:0')
 ops.OVERLAP_BRANCHES = set()
