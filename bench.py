@@ -53,7 +53,7 @@ LOOKUP_BYTES_PER_QUERY = 2904  # 4*(10*10*4) read + 8 flow + 4*(
 # hash, not `git rev-parse HEAD:scflow_amd/csrc`: the GPU box holds a snapshot without .git.
 LOOKUP_SOURCES = ('corr_lookup.hip', 'scf_common.h', 'scf_dma.h')
 CONV_SOURCES = ('conv_wino.hip', 'conv_wino1d.hip', 'conv_wino1d4.hip', 'conv_dma.hip', 'conv_mfma.hip', 'conv_taps.hip',
-                'conv_thin.hip', 'conv_kernels.h', 'fc.hip', 'corr_gemm.hip', 'scf_common.h', 'scf_dma.h')
+                'conv_thin.hip', 'conv_kernels.h', 'conv_taps_body.h', 'fc.hip', 'corr_gemm.hip', 'scf_common.h', 'scf_dma.h')
 
 
 def kernel_source_hashes(files):

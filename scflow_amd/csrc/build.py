@@ -19,7 +19,7 @@ def needs_build() -> bool:
         return True
     t = os.path.getmtime(OUT)
     deps = [os.path.join(HERE, s) for s in SOURCES] + [
-        os.path.join(HERE, 'scf_common.h'), os.path.join(HERE, 'conv_kernels.h'), os.path.join(HERE, 'scf_dma.h'),
+        os.path.join(HERE, 'scf_common.h'), os.path.join(HERE, 'conv_kernels.h'), os.path.join(HERE, 'scf_dma.h'), os.path.join(HERE, 'conv_taps_body.h'),
         os.path.join(HERE, '..', '..', 'include', 'scflow_hip.h'),
         os.path.join(HERE, '..', '..', 'include', 'scflow_hip_prof.h')]
     return any(os.path.getmtime(d) > t for d in deps)

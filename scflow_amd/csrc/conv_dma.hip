@@ -24,6 +24,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #include "conv_kernels.h"
 #include "scf_dma.h"
+#include "conv_taps_body.h"
 
 #define SCF_DMA_PU 20   // patch gathers per thread per chunk (256 * 20 floats)
 #define SCF_DMA_WU 7    // weight float4 per thread per chunk
@@ -760,6 +761,52 @@ int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t s
   return SCF_EUNSUPPORTED;
 }
 
+
+// r6: a K-split layer and a THIN-INPUT layer (conv_taps_body, WM = 1) in one launch: the motion encoder's corr_net.0 (1x1 324 -> 256) and
+// flow_net.0 (7x7 2 -> 128) read different tensors and feed different branches.  The thin-input blocks use the first four waves.
+template <bool PX4, int NG>
+__global__ __launch_bounds__(256 * NG, 1) void conv_dma_taps_pair_kernel(ConvK pa, ConvK pb, const float* __restrict__ wtb, int Kpb, int PWpb,
+                                                                         int nba) {
+  if ((int)blockIdx.x < nba) {
+    conv_dma_body<1, 1, 2, true, PX4, NG>(pa, (int)blockIdx.x, nba);
+  } else {
+    if (NG > 1 && threadIdx.x >= 256) return;      // (whole waves: the body's barriers count the waves that are still alive)
+    conv_taps_body<1>(pb, wtb, Kpb, PWpb, (int)blockIdx.x - nba, (int)gridDim.x - nba);
+  }
+}
+
+template <bool PX4, int NG>
+static int launch_dma_taps_pair(const ScfLaunchCap& a, const ScfLaunchCap& b, size_t lds_bytes, hipStream_t st) {
+  if (lds_bytes > 64 * 1024) {
+    static std::atomic<unsigned long long> raised{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return SCF_ELAUNCH;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(raised.load(std::memory_order_relaxed) & bit)) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_taps_pair_kernel<PX4, NG>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, SCF_DMA_LDS_DEEP) != hipSuccess)
+        return SCF_ELAUNCH;
+      raised.fetch_or(bit, std::memory_order_relaxed);
+    }
+  }
+  scf_launch((conv_dma_taps_pair_kernel<PX4, NG>), dim3((unsigned)(a.nblk + b.nblk)), dim3(256 * NG), lds_bytes, st, a.k, b.k, b.wt, b.Kp,
+             b.PWp, a.nblk);
+  return scf_launch_status();
+}
+
+// a = a captured K-split launch, b = a captured thin-input launch (one tile per block, 32 output channels per block)
+int scf_conv_dma_taps_pair_launch(const ScfLaunchCap& a, const ScfLaunchCap& b, hipStream_t st) {
+  if (a.variant < 0 || a.variant > 3 || b.variant != 1 || a.nblk <= 0 || b.nblk <= 0) return SCF_EUNSUPPORTED;
+  const size_t lds = a.ldsb > b.ldsb ? a.ldsb : b.ldsb;
+  if (lds > SCF_DMA_LDS_DEEP) return SCF_EUNSUPPORTED;
+  switch (a.variant) {
+    case 0: return launch_dma_taps_pair<false, 1>(a, b, lds, st);
+    case 1: return launch_dma_taps_pair<true, 1>(a, b, lds, st);
+    case 2: return launch_dma_taps_pair<false, 2>(a, b, lds, st);
+    case 3: return launch_dma_taps_pair<true, 2>(a, b, lds, st);
+  }
+  return SCF_EUNSUPPORTED;
+}
 
 // r6: two captured K-split launches of the same instantiation as one launch (see conv_dma_pair_kernel)
 template <bool PX4, int NG>

@@ -428,3 +428,4 @@ int scf_conv_thin_pair_launch(const ScfLaunchCap& a, const ScfLaunchCap& b, hipS
 // conv_dma.hip: same contract for the stride-1 LDS-DMA fp32 kernel.
 int scf_conv_dma_dispatch(ConvK k, int N, bool dry_run, int* info, hipStream_t st, ScfLaunchCap* cap = nullptr);
 int scf_conv_dma_pair_launch(const ScfLaunchCap& a, const ScfLaunchCap& b, hipStream_t st);
+int scf_conv_dma_taps_pair_launch(const ScfLaunchCap& dma, const ScfLaunchCap& taps, hipStream_t st);      // K-split layer | thin-input layer

@@ -792,8 +792,20 @@ extern "C" int scf_conv2d_pair(const scf_conv_desc* a, const scf_conv_desc* b, s
     // blocks that can be resident at once: thin-input and quarter-domain Winograd blocks fit two per CU, K-split blocks too while
     // their ring stays under half the LDS (the 32-channel-chunk packing of tiny grids takes up to 144 KB: one per CU)
     const size_t lmax = ca.ldsb > cb.ldsb ? ca.ldsb : cb.ldsb;
-    long long slots = (long long)scf_cu_count() * ((fa == SCF_KERNEL_DMA && lmax > 80 * 1024) ? 1 : 2);
+    long long slots = (long long)scf_cu_count() * (((fa == SCF_KERNEL_DMA || fb == SCF_KERNEL_DMA) && lmax > 80 * 1024) ? 1 : 2);
     if (g_pair_mode.load(std::memory_order_relaxed) == 1) slots = 0;      // scf_tune(SCF_TUNE_CONV_PAIR, 1): never one launch
+    if (((fa == SCF_KERNEL_DMA && fb == SCF_KERNEL_TAPS) || (fa == SCF_KERNEL_TAPS && fb == SCF_KERNEL_DMA)) &&
+        (long long)ca.nblk + cb.nblk <= slots && g_pair_mode.load(std::memory_order_relaxed) != 1) {
+      // a K-split layer beside a thin-input layer (corr_net.0 | flow_net.0): one launch, the K-split grid first
+      const bool a_dma = fa == SCF_KERNEL_DMA;
+      const int rc = scf_conv_dma_taps_pair_launch(a_dma ? ca : cb, a_dma ? cb : ca, scf_stream(stream));
+      if (rc == SCF_OK) {
+        conv_log_push(a, fa);
+        conv_log_push(b, fb);
+        return SCF_OK;
+      }
+      if (rc != SCF_EUNSUPPORTED) return rc;
+    }
     if (fb == fa && (long long)ca.nblk + cb.nblk <= slots) {
       const int rc = fa == SCF_KERNEL_WINO_Q ? scf_conv_wino_pair_launch(ca, cb, scf_stream(stream))
                    : fa == SCF_KERNEL_THIN ? scf_conv_thin_pair_launch(ca, cb, scf_stream(stream)) : fa == SCF_KERNEL_TAPS ? scf_conv_taps_pair_launch(ca, cb, scf_stream(stream))

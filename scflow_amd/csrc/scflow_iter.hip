@@ -116,11 +116,11 @@ extern "C" int scf_scflow_iteration(const scf_scflow_iter* it, scf_stream_t stre
     scf_stream_t fq = it->overlap_flow == 1 ? it->side_stream : stream;
     scf_conv_desc f0 = it->flow0;
     f0.in0 = flow_enc;
-    SCF_TRY(scf_conv2d(&f0, fq));
-    if (pair_flow) {            // flow1 (3x3 128 -> 64) beside corr1 (3x3 256 -> 192): both K-split launches
-      SCF_TRY(scf_conv2d(&it->corr0, stream));
+    if (pair_flow) {            // the flow branch layer by layer beside the correlation branch: [corr0 | flow0], [corr1 | flow1]
+      SCF_TRY(scf_conv2d_pair(&it->corr0, &f0, stream));
       SCF_TRY(scf_conv2d_pair(&it->corr1, &it->flow1, stream));
     } else {
+      SCF_TRY(scf_conv2d(&f0, fq));
       SCF_TRY(scf_conv2d(&it->flow1, fq));
       SCF_TRY(scf_conv2d(&it->corr0, stream));
       SCF_TRY(scf_conv2d(&it->corr1, stream));

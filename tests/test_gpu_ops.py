@@ -1487,7 +1487,9 @@ PAIR_CASES = [
     ((1, 256, 192, (3, 3), (1, 1), (32, 32)), (1, 128, 64, (3, 3), (1, 1), (32, 32)), True),    # corr_net.1 | flow_net.1 at batch 1
     ((1, 256, 2, (3, 3), (1, 1), (32, 32)), (1, 256, 1, (1, 1), (0, 0), (32, 32)), True),       # flow | mask predictions (two thin instantiations)
     ((2, 256, 192, (3, 3), (1, 1), (32, 32)), (2, 128, 64, (3, 3), (1, 1), (32, 32)), False),   # batch 2: 384 + 128 blocks > CUs
-    ((1, 128, 64, (3, 3), (1, 1), (32, 32)), (1, 2, 128, (7, 7), (3, 3), (32, 32)), False),     # different kernel families
+    ((1, 324, 256, (1, 1), (0, 0), (32, 32)), (1, 2, 128, (7, 7), (3, 3), (32, 32)), True),     # corr_net.0 | flow_net.0: K-split tile + thin-input kernel
+    ((1, 2, 128, (7, 7), (3, 3), (32, 32)), (1, 128, 64, (3, 3), (1, 1), (32, 32)), True),      # the same two families, thin-input layer first
+    ((1, 128, 64, (3, 3), (1, 1), (32, 32)), (1, 256, 2, (3, 3), (1, 1), (32, 32)), False),     # families without a shared launch (K-split | thin-output)
     ((32, 128, 64, (3, 3), (1, 1), (32, 32)), (32, 64, 32, (3, 3), (1, 1), (32, 32)), False),   # full grids (Winograd)
     ((3, 224, 128, (3, 3), (1, 1), (12, 20)), (2, 30, 40, (1, 5), (0, 2), (9, 33)), None),      # ragged shapes, whatever it does
 ]
