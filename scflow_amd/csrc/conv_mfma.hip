@@ -765,7 +765,7 @@ static int conv2d_capture(const scf_conv_desc* d, scf_stream_t stream, ScfLaunch
   if (d->wp_wino) {
     int quarter = 0;
     if (scf_conv_wino_dispatch(pl.k, d->wp_wino, d->N, true, info, nullptr, &quarter, cap) == SCF_OK)
-      return (quarter && cap->variant >= 10) ? SCF_KERNEL_WINO_Q : -1;
+      return (quarter && cap->variant >= 10 && cap->variant < 20) ? SCF_KERNEL_WINO_Q : (!quarter && cap->variant >= 20) ? SCF_KERNEL_WINO : -1;
   }
   if (d->wp_wino1d4 && g_wino1d4.load(std::memory_order_relaxed) &&
       scf_conv_wino1d4_dispatch(pl.k, d->wp_wino1d4, d->N, g_wino1d4.load(std::memory_order_relaxed) == 2, true, info, nullptr) == SCF_OK)
@@ -806,7 +806,25 @@ extern "C" int scf_conv2d_pair(const scf_conv_desc* a, const scf_conv_desc* b, s
       }
       if (rc != SCF_EUNSUPPORTED) return rc;
     }
-    if (fb == fa && (long long)ca.nblk + cb.nblk <= slots) {
+    // ... or, for the MFMA-bound quarter-domain Winograd kernel, while one launch needs fewer ROUNDS of resident blocks than two
+    // (batch 32: corr_net.1 768 + flow_net.1 256 blocks = 1.5 + 0.5 rounds apart, 2 full rounds together)
+    const bool fewer_rounds = fa == SCF_KERNEL_WINO_Q && fb == fa && g_pair_mode.load(std::memory_order_relaxed) != 1 &&
+                              (ca.nblk + cb.nblk + slots - 1) / slots < (ca.nblk + slots - 1) / slots + (cb.nblk + slots - 1) / slots;
+    if (((fa == SCF_KERNEL_WINO_Q && fb == SCF_KERNEL_WINO) || (fa == SCF_KERNEL_WINO && fb == SCF_KERNEL_WINO_Q)) &&
+        g_pair_mode.load(std::memory_order_relaxed) != 1 &&
+        ((long long)ca.nblk + cb.nblk <= slots ||
+         (ca.nblk + cb.nblk + slots - 1) / slots < (ca.nblk + slots - 1) / slots + (cb.nblk + slots - 1) / slots)) {
+      // a quarter-domain layer beside a pair-kernel layer (delta_flow_encoder.1 | mask_encoder.1): the quarter-domain grid first
+      const bool a_q = fa == SCF_KERNEL_WINO_Q;
+      const int rc = scf_conv_wino_pair_launch(a_q ? ca : cb, a_q ? cb : ca, scf_stream(stream));
+      if (rc == SCF_OK) {
+        conv_log_push(a, fa);
+        conv_log_push(b, fb);
+        return SCF_OK;
+      }
+      if (rc != SCF_EUNSUPPORTED) return rc;
+    }
+    if (fb == fa && fa != SCF_KERNEL_WINO && ((long long)ca.nblk + cb.nblk <= slots || fewer_rounds)) {
       const int rc = fa == SCF_KERNEL_WINO_Q ? scf_conv_wino_pair_launch(ca, cb, scf_stream(stream))
                    : fa == SCF_KERNEL_THIN ? scf_conv_thin_pair_launch(ca, cb, scf_stream(stream)) : fa == SCF_KERNEL_TAPS ? scf_conv_taps_pair_launch(ca, cb, scf_stream(stream))
                                            : scf_conv_dma_pair_launch(ca, cb, scf_stream(stream));

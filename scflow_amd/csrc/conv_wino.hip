@@ -79,9 +79,9 @@ __device__ __forceinline__ int wn_div(int e, int d, float rd) {
   return q;
 }
 
+// (body as a function of its arguments, block index and grid size; conv_wino_mixed_pair_kernel below, r6)
 template <int CW, int TW, bool PX4>
-__global__ __launch_bounds__(256, 2)
-void conv_wino_kernel(ConvK p, WinoK q) {
+__device__ __forceinline__ void conv_wino_body(const ConvK& p, const WinoK& q, const int bid, const int nblk) {
   static_assert(CW * TW == 2, "two fragments (four waves) per block");
   extern __shared__ __attribute__((aligned(16))) float wn_lds[];
   constexpr int USLOT = CW * 2048;                              // floats per ring slot
@@ -96,7 +96,7 @@ void conv_wino_kernel(ConvK p, WinoK q) {
   const int cw = CW == 2 ? fs : 0, tw = TW == 2 ? fs : 0;
   const int half = lane >> 5, l32 = lane & 31;
 
-  int lb = scf_xcd_remap(blockIdx.x, gridDim.x);
+  int lb = scf_xcd_remap(bid, nblk);
   const int mb = __builtin_amdgcn_readfirstlane(lb % q.mblocks);
   lb /= q.mblocks;
   const int xs = __builtin_amdgcn_readfirstlane(lb % q.sx);
@@ -382,6 +382,12 @@ void conv_wino_kernel(ConvK p, WinoK q) {
       scf_store2<(SCF_ST_SC1 & 8) != 0>(e.out + off + i * p.Wo, v[0], v[1]);
     }
   }
+}
+
+template <int CW, int TW, bool PX4>
+__global__ __launch_bounds__(256, 2)
+void conv_wino_kernel(ConvK p, WinoK q) {
+  conv_wino_body<CW, TW, PX4>(p, q, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ===================================================================================================
@@ -743,6 +749,15 @@ void conv_wino_q_pair_kernel(ConvK pa, WinoK qa, ConvK pb, WinoK qb, int nba) {
   else conv_wino_q_body<1, PX4>(pb, qb, (int)blockIdx.x - nba, (int)gridDim.x - nba);
 }
 
+// r6: a quarter-domain layer (even fragment count) beside a PAIR-kernel layer (one fragment): the delta-flow encoder's 128 -> 64 and the
+// mask encoder's 64 -> 32 at batch 32 are 256 + 128 blocks = half a round of resident blocks each
+template <bool PXA, bool PXB>
+__global__ __launch_bounds__(256, 2)
+void conv_wino_mixed_pair_kernel(ConvK pa, WinoK qa, ConvK pb, WinoK qb, int nba) {
+  if ((int)blockIdx.x < nba) conv_wino_q_body<1, PXA>(pa, qa, (int)blockIdx.x, nba);
+  else conv_wino_body<1, 2, PXB>(pb, qb, (int)blockIdx.x - nba, (int)gridDim.x - nba);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Host side: packing and launch
 // ---------------------------------------------------------------------------------------------------
@@ -914,7 +929,12 @@ int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* i
   const size_t ldsb = (size_t)(3 * CW * 2048 + 3 * npi * (px4 ? 1024 : 256)) * sizeof(float);
   if (ldsb > 80 * 1024) return SCF_EUNSUPPORTED;
   if (info) { info[0] = 16; info[1] = CW * TW; info[2] = (int)nblk; info[3] = (int)ldsb; }     // positions, fragments per block
-  if (cap) { cap->variant = -1; return SCF_OK; }
+  if (cap) {                  // r6: the pair kernel's launch, for a launch shared with a quarter-domain layer
+    cap->k = k; cap->nblk = (int)nblk; cap->ldsb = ldsb;
+    memcpy(cap->aux, &q, sizeof(WinoK));
+    cap->variant = 20 + cfg;
+    return SCF_OK;
+  }
   if (dry_run) return SCF_OK;
   {                                  // more than 64 KB of dynamic LDS needs the attribute, once per kernel and device
     static std::atomic<unsigned long long> raised[2];
@@ -928,7 +948,25 @@ int scf_conv_wino_dispatch(ConvK k, const float* wu, int N, bool dry_run, int* i
 }
 
 int scf_conv_wino_pair_launch(const ScfLaunchCap& a, const ScfLaunchCap& b, hipStream_t st) {
-  if (a.variant < 10 || a.variant != b.variant || a.nblk <= 0 || b.nblk <= 0) return SCF_EUNSUPPORTED;
+  if (a.variant >= 10 && a.variant < 20 && b.variant >= 20 && a.nblk > 0 && b.nblk > 0) {      // quarter-domain | pair kernel
+    const size_t ldsm = a.ldsb > b.ldsb ? a.ldsb : b.ldsb;
+    WinoK qa, qb;
+    memcpy(&qa, a.aux, sizeof(WinoK));
+    memcpy(&qb, b.aux, sizeof(WinoK));
+    const int ca = a.variant - 10, cb2 = b.variant - 20, id = ca * 2 + cb2;
+    static std::atomic<unsigned long long> raised_m[4];
+    const void* fn = id == 0 ? (const void*)conv_wino_mixed_pair_kernel<false, false> : id == 1 ? (const void*)conv_wino_mixed_pair_kernel<false, true>
+                   : id == 2 ? (const void*)conv_wino_mixed_pair_kernel<true, false> : (const void*)conv_wino_mixed_pair_kernel<true, true>;
+    const int rc = scf_raise_dynamic_lds(raised_m[id], fn, 80 * 1024);
+    if (rc != SCF_OK) return rc;
+    const dim3 grid((unsigned)(a.nblk + b.nblk));
+    if (id == 0) scf_launch((conv_wino_mixed_pair_kernel<false, false>), grid, dim3(256), ldsm, st, a.k, qa, b.k, qb, a.nblk);
+    else if (id == 1) scf_launch((conv_wino_mixed_pair_kernel<false, true>), grid, dim3(256), ldsm, st, a.k, qa, b.k, qb, a.nblk);
+    else if (id == 2) scf_launch((conv_wino_mixed_pair_kernel<true, false>), grid, dim3(256), ldsm, st, a.k, qa, b.k, qb, a.nblk);
+    else scf_launch((conv_wino_mixed_pair_kernel<true, true>), grid, dim3(256), ldsm, st, a.k, qa, b.k, qb, a.nblk);
+    return scf_launch_status();
+  }
+  if (a.variant < 10 || a.variant >= 20 || a.variant != b.variant || a.nblk <= 0 || b.nblk <= 0) return SCF_EUNSUPPORTED;
   const size_t lds = a.ldsb > b.ldsb ? a.ldsb : b.ldsb;
   WinoK qa, qb;
   memcpy(&qa, a.aux, sizeof(WinoK));

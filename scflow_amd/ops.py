@@ -129,14 +129,20 @@ OVERLAP_MAX_PIXELS = {'context': 4 * 256 * 256, 'flow': 4 * 256 * 256, 'mask': 4
 # r6: branches whose convolutions ride in the main branch's launches (scf_conv2d_pair: two small-grid layers, one launch) instead
 # of running on the side stream -- the C iteration only (SCFlowDecoder.c_iteration); takes precedence over OVERLAP_BRANCHES
 PAIR_BRANCHES = {'context', 'flow', 'mask'}
+# ... up to this many pixels per batch (None: any size -- scf_conv2d_pair itself merges a pair only where one launch needs fewer
+# rounds of resident blocks than two; the flow branch gains at EVERY batch size: at batch 32 corr_net.1 (768 blocks) and flow_net.1
+# (256) are 1.5 + 0.5 rounds apart and 2 full rounds together, 14.00 -> 13.89 ms per step; batch 16: 8.40 -> 8.17).  The two encoders
+# walked together lose at batch 32 (they evict each other's activations), the mask branch has no mergeable pair there.
+PAIR_MAX_PIXELS = {'context': 4 * 256 * 256, 'flow': None, 'mask': None}
 
 
 def branch_mode(n: int, h: int, w: int, branch: str) -> int:
     """0 = in order, 1 = side stream, 2 = merged launches, for the C iteration's ``overlap_*`` fields."""
+    if branch in PAIR_BRANCHES:
+        lim = PAIR_MAX_PIXELS.get(branch, 4 * 256 * 256)
+        return 2 if lim is None or n * h * w <= lim else 0
     lim = OVERLAP_MAX_PIXELS.get(branch, 4 * 256 * 256)
-    if n * h * w > lim:
-        return 0
-    return 2 if branch in PAIR_BRANCHES else 1 if branch in OVERLAP_BRANCHES else 0
+    return 1 if n * h * w <= lim and branch in OVERLAP_BRANCHES else 0
 
 
 def small_work(n: int, h: int, w: int, branch: Optional[str] = None) -> bool:
