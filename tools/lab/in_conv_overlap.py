@@ -1,4 +1,6 @@
-"""r6: do an InstanceNorm pass (HBM-bound) and a Winograd convolution (MFMA-bound) hide each other?  Two streams, launch-bound wall time.
+"""r6: do an InstanceNorm pass (HBM-bound) and a Winograd convolution (MFMA-bound) hide each other?  Two streams, launch-bound wall time;
+"ONE LAUNCH" needs the lab entry point scf_conv2d_instance_norm (conv_wino_q_in_kernel: built, measured 387 vs 299 us, removed -- notebook
+R6.10) and is skipped without it.
     python tools/lab/in_conv_overlap.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
