@@ -808,8 +808,10 @@ extern "C" int scf_conv2d_pair(const scf_conv_desc* a, const scf_conv_desc* b, s
     }
     // ... or, for the MFMA-bound quarter-domain Winograd kernel, while one launch needs fewer ROUNDS of resident blocks than two
     // (batch 32: corr_net.1 768 + flow_net.1 256 blocks = 1.5 + 0.5 rounds apart, 2 full rounds together)
-    const bool fewer_rounds = fa == SCF_KERNEL_WINO_Q && fb == fa && g_pair_mode.load(std::memory_order_relaxed) != 1 &&
-                              (ca.nblk + cb.nblk + slots - 1) / slots < (ca.nblk + slots - 1) / slots + (cb.nblk + slots - 1) / slots;
+    // (thin-input blocks are light -- ~30 KB of LDS, ~100 registers -- four are resident per CU)
+    const long long rslots = fa == SCF_KERNEL_TAPS ? 2 * slots : slots;
+    const bool fewer_rounds = (fa == SCF_KERNEL_WINO_Q || fa == SCF_KERNEL_TAPS) && fb == fa && g_pair_mode.load(std::memory_order_relaxed) != 1 &&
+                              (ca.nblk + cb.nblk + rslots - 1) / rslots < (ca.nblk + rslots - 1) / rslots + (cb.nblk + rslots - 1) / rslots;
     if (((fa == SCF_KERNEL_WINO_Q && fb == SCF_KERNEL_WINO) || (fa == SCF_KERNEL_WINO && fb == SCF_KERNEL_WINO_Q)) &&
         g_pair_mode.load(std::memory_order_relaxed) != 1 &&
         ((long long)ca.nblk + cb.nblk <= slots ||

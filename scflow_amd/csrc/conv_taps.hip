@@ -30,11 +30,11 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(ConvK p, const float*
 }
 
 // r6: two independent thin-input layers (the delta-flow and mask encoders' first layers) in one launch; see conv_dma_pair_kernel
-template <int WM>
+template <int WMA, int WMB>
 __global__ __launch_bounds__(256, 2) void conv_taps_pair_kernel(ConvK pa, const float* __restrict__ wta, int Kpa, int PWpa, ConvK pb,
                                                                 const float* __restrict__ wtb, int Kpb, int PWpb, int nba) {
-  if ((int)blockIdx.x < nba) conv_taps_body<WM>(pa, wta, Kpa, PWpa, (int)blockIdx.x, nba);
-  else conv_taps_body<WM>(pb, wtb, Kpb, PWpb, (int)blockIdx.x - nba, (int)gridDim.x - nba);
+  if ((int)blockIdx.x < nba) conv_taps_body<WMA>(pa, wta, Kpa, PWpa, (int)blockIdx.x, nba);
+  else conv_taps_body<WMB>(pb, wtb, Kpb, PWpb, (int)blockIdx.x - nba, (int)gridDim.x - nba);
 }
 
 #define CT_MAXU 12      // patch cells per lane the gather table keeps in registers (256 * 12 floats per patch)
@@ -286,13 +286,17 @@ int scf_conv_taps_dispatch(ConvK k, const float* wt, int N, bool dry_run, int* i
 }
 
 int scf_conv_taps_pair_launch(const ScfLaunchCap& a, const ScfLaunchCap& b, hipStream_t st) {
-  if (a.variant < 1 || a.variant != b.variant || a.nblk <= 0 || b.nblk <= 0) return SCF_EUNSUPPORTED;
+  // variant = output channels per block / 32 (1 or 2) of the one-tile-per-block kernel; the two layers may differ (the delta-flow
+  // encoder's 2 -> 128 takes 64 channels per block on full grids, the mask encoder's 1 -> 64 takes 32)
+  if (a.variant < 1 || a.variant > 2 || b.variant < 1 || b.variant > 2 || a.nblk <= 0 || b.nblk <= 0) return SCF_EUNSUPPORTED;
   const size_t lds = a.ldsb > b.ldsb ? a.ldsb : b.ldsb;
   if (lds > 64 * 1024) return SCF_EUNSUPPORTED;
-  const unsigned grid = (unsigned)(a.nblk + b.nblk);
-  if (a.variant == 2)
-    scf_launch((conv_taps_pair_kernel<2>), dim3(grid), dim3(256), lds, st, a.k, a.wt, a.Kp, a.PWp, b.k, b.wt, b.Kp, b.PWp, a.nblk);
-  else
-    scf_launch((conv_taps_pair_kernel<1>), dim3(grid), dim3(256), lds, st, a.k, a.wt, a.Kp, a.PWp, b.k, b.wt, b.Kp, b.PWp, a.nblk);
+  const dim3 grid((unsigned)(a.nblk + b.nblk)), blk(256);
+#define SCF_GO(A_, B_) scf_launch((conv_taps_pair_kernel<A_, B_>), grid, blk, lds, st, a.k, a.wt, a.Kp, a.PWp, b.k, b.wt, b.Kp, b.PWp, a.nblk)
+  if (a.variant == 1 && b.variant == 1) SCF_GO(1, 1);
+  else if (a.variant == 1) SCF_GO(1, 2);
+  else if (b.variant == 1) SCF_GO(2, 1);
+  else SCF_GO(2, 2);
+#undef SCF_GO
   return scf_launch_status();
 }
