@@ -362,14 +362,23 @@ class MotionEncoder(HipModule):
             if overlap:
                 raise ValueError('overlap=True needs a cf buffer allocated before the fork point')
             cf = torch.empty((n, 256, h, w), dtype=torch.float32, device=dev)
-        br = ops.side_stream(overlap, after=fork)
-        with br:
-            f1 = self.flow_net[0](flow)
-            self.flow_net[1](f1, out=cf[:, 192:])
-            del f1
-        c1 = self.corr_net[0](corr)
-        self.corr_net[1](c1, out=cf[:, :192])
-        br.join()
+        if not overlap and 'flow' in ops.PAIR_BRANCHES and ops._CONV_EVENTS is None:
+            # r6: the flow branch rides in the correlation branch's launches, layer by layer (ops.conv2d_pair: one launch where
+            # the two grids need fewer rounds of resident blocks together, else one after the other; same bits)
+            cn, fn = self.corr_net, self.flow_net
+            c1, f1 = ops.conv2d_pair((cn[0].packed, corr, dict(act=cn[0].act)), (fn[0].packed, flow, dict(act=fn[0].act)))
+            ops.conv2d_pair((cn[1].packed, c1, dict(out=cf[:, :192], act=cn[1].act)),
+                            (fn[1].packed, f1, dict(out=cf[:, 192:], act=fn[1].act)))
+            del c1, f1
+        else:
+            br = ops.side_stream(overlap, after=fork)
+            with br:
+                f1 = self.flow_net[0](flow)
+                self.flow_net[1](f1, out=cf[:, 192:])
+                del f1
+            c1 = self.corr_net[0](corr)
+            self.corr_net[1](c1, out=cf[:, :192])
+            br.join()
         self.out_net[0](cf, out=out[:, :126])
         ops.copy_channels(flow, out[:, 126:128])
         return out
